@@ -1,0 +1,108 @@
+"""ctypes loader for libdiqt_hip.so (the C ABI declared in include/diqt.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, this module
+raises.  ``call(name, *args)`` converts torch tensors to device pointers, appends nothing on its
+own (the caller passes the stream explicitly) and raises ``RuntimeError(diqt_last_error())`` on a
+non-zero return code.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_float, c_size_t, c_void_p, c_longlong, c_char_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdiqt_hip.so")
+
+P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_longlong
+
+# name -> (restype, argtypes)   — must list every function declared in include/diqt.h
+PROTOTYPES = {
+    "diqt_version": (I, []),
+    "diqt_last_error": (c_char_p, []),
+    "diqt_conv_packed_elems": (Z, [I, I, I, I, I]),
+    "diqt_conv_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),
+    "diqt_conv3d_fwd": (I, [P, P, P, P, P] + [I] * 12 + [P]),
+    "diqt_conv3d_lds_bytes": (L, [I] * 9),
+    "diqt_trilinear_up_fwd": (I, [P, P, I, I, I, I, I, I, P]),
+    "diqt_trilinear_up_bwd": (I, [P, P, I, I, I, I, I, I, P]),
+    "diqt_conv3d_bwd_weight_workspace_bytes": (Z, [I] * 12),
+    "diqt_conv3d_bwd_weight": (I, [P, P, P, P, P, Z] + [I] * 12 + [P]),
+    "diqt_conv3d_direct_fwd": (I, [P, P, P, P] + [I] * 16 + [P]),
+    "diqt_conv3d_direct_bwd_data": (I, [P, P, P] + [I] * 16 + [P]),
+    "diqt_conv3d_direct_bwd_weight": (I, [P, P, P, P] + [I] * 16 + [P]),
+    "diqt_reduce_workspace_bytes": (Z, [I, I]),
+    "diqt_groupnorm_stats": (I, [P, P, P, P, Z, I, I, I, I, F, P]),
+    "diqt_gn_act_fwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
+    "diqt_gn_act_bwd": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "diqt_chan_layernorm_fwd": (I, [P, P, P, P, P, I, I, F, P]),
+    "diqt_chan_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, P]),
+    "diqt_act_fwd": (I, [P, P, Z, I, P]),
+    "diqt_act_bwd": (I, [P, P, P, Z, I, P]),
+    "diqt_learned_sinu_fwd": (I, [P, P, P, I, I, P]),
+    "diqt_learned_sinu_bwd": (I, [P, P, P, P, I, I, P]),
+    "diqt_channel_mean": (I, [P, P, P, Z, I, I, I, P]),
+    "diqt_gate_residual_fwd": (I, [P, P, P, P, F, P, I, I, I, P]),
+    "diqt_gate_residual_bwd": (I, [P, P, P, P, Z, I, I, I, P]),
+    "diqt_se_mlp_fwd": (I, [P, P, P, P, P, I, I, I, P]),
+    "diqt_se_mlp_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "diqt_add_channel_broadcast": (I, [P, P, F, I, I, I, P]),
+    "diqt_space_to_depth2": (I, [P, P, I, I, I, I, I, P]),
+    "diqt_depth_to_space2": (I, [P, P, I, I, I, I, I, P]),
+    "diqt_concat_channels": (I, [P, I, P, I, P, Z, P]),
+    "diqt_split_channels": (I, [P, P, I, P, I, Z, P]),
+    "diqt_subvolume_gather": (I, [P, P, I, I, I, I, P]),
+    "diqt_subvolume_scatter": (I, [P, P, I, I, I, I, I, P]),
+    "diqt_q_sample": (I, [P, P, P, P, P, I, Z, P]),
+    "diqt_ddpm_step": (I, [P, P, P, P, P, P, F, F, I, P, P, I, Z, P]),
+    "diqt_axpby3": (I, [P, P, P, P, P, P, F, F, I, P, I, Z, P]),
+    "diqt_mse_clamp_fwd": (I, [P, P, P, F, I, P, P, I, Z, P]),
+    "diqt_mse_clamp_bwd": (I, [P, P, P, F, I, F, P, I, Z, P]),
+    "diqt_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, F, F, I, P]),
+    "diqt_ema_lerp": (I, [P, P, Z, F, P]),
+    "diqt_softmax_fwd": (I, [P, P, Z, I, I, F, P]),
+    "diqt_softmax_bwd": (I, [P, P, P, Z, I, I, F, P]),
+    "diqt_bgemm": (I, [P, P, P, I, I, I, I, I, I, L, L, L, I, I, I, F, F, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libdiqt_hip.so once; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"diffusioniqt_amd: {LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `bash diffusioniqt_amd/csrc/build.sh`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().diqt_last_error().decode("utf-8", "replace")
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a
+
+
+def call(name, *args):
+    """Calls a status-returning entry point; tensors become raw pointers."""
+    lib = load()
+    rc = getattr(lib, name)(*[_ptr(a) for a in args])
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

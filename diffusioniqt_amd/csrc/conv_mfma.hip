@@ -1,0 +1,588 @@
+// Implicit-GEMM 3-D convolution for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32).
+//
+// Forward / backward-data kernel (conv_fwd_kernel):
+//   GEMM view  M = B*Do*Ho*Wo voxels, N = Cout, K = taps*Cin.  One 256-thread workgroup (4 waves)
+//   owns a 128-voxel spatial tile (TD x TH x TW) x 64 output channels.  The input HALO tile
+//   (TD+kd-1)(TH+kh-1)(TW+kw-1) x 32 channels is staged ONCE per 32-channel chunk into LDS and reused
+//   by all taps (no im2col, each input voxel is read from HBM/L2 once per chunk and tile);  the
+//   64x32 weight panel of the current tap is double-buffered in LDS and prefetched through registers
+//   one tap ahead.  Each wave computes 32 voxels x 64 channels = two 32x32 accumulators.
+//   K order inside an 8-wide group is permuted (lane half h takes k = 8q+4h..+3) so that both
+//   operands are read with ds_read_b128 along the channel axis; A and B use the same permutation.
+//   LDS rows are padded to 36 floats: 36*i mod 64 hits all sixteen 16-B slots -> conflict-free
+//   weight reads, <=3-way on the strided halo reads (1 read per 8 MFMAs: irrelevant at the f32 rate).
+//   ~76 KB LDS for a 3x3x3 filter -> 2 workgroups per CU, so one workgroup's halo staging overlaps
+//   the other's MFMA phase.  Block ids are remapped so each XCD gets a contiguous run of tiles.
+//
+// Backward-weight kernel (conv_bwd_weight_kernel):
+//   dW[co][ci][tap] = sum_v dY[v][co] * X[v+tap][ci]:  M = co (64/WG), N = ci (32/WG), K = voxels.
+//   A workgroup owns one kd-plane x one tap group (<=10 (kh,kw) taps) x 32 ci x 64 co and walks a
+//   contiguous range of voxel tiles (split-K); per tile it stages the X halo plane and the dY tile in
+//   LDS and issues one MFMA per (tap, 2 voxels).  Partial slabs go to the workspace in the packed
+//   layout and are reduced in a fixed order (deterministic) by conv_reduce_dw_kernel.
+#include "common.h"
+
+namespace diqt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 32;          // channels per K-chunk
+constexpr int LDSROW = CK + 4;  // padded LDS row (floats)
+constexpr int NT = 64;          // output channels per workgroup
+constexpr int MTILE = 128;      // output voxels per workgroup
+
+struct ConvGeom {
+    int B, D, H, W, Cin, Cout;
+    int Do, Ho, Wo;
+    int kd, kh, kw, pd, ph, pw;
+    int TD, TH, TW;
+    int tilesD, tilesH, tilesW;
+    int nNt, nChunks, CoutPad;
+    int HD, HH, HWd;            // halo extents
+};
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: packed[((chunk*T + tap)*CoutPad + co)*32 + k]
+// ---------------------------------------------------------------------------------------------
+__global__ void conv_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed,
+                                        int Cout, int Cin, int T, int mode, int CoutPadEff,
+                                        int nChunksEff, size_t total) {
+    // mode 0: effective (out,in) = (Cout,Cin), value w[co][ci][tap]
+    // mode 1: effective (out,in) = (Cin,Cout), value w[in_eff][out_eff][T-1-tap]
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % CK);
+        size_t r = i / CK;
+        const int o = (int)(r % CoutPadEff);
+        r /= CoutPadEff;
+        const int tap = (int)(r % T);
+        const int chunk = (int)(r / T);
+        const int in = chunk * CK + k;
+        float v = 0.f;
+        if (mode == 0) {
+            if (o < Cout && in < Cin) v = w[((size_t)o * Cin + in) * T + tap];
+        } else {
+            if (o < Cin && in < Cout) v = w[((size_t)in * Cin + o) * T + (T - 1 - tap)];
+        }
+        packed[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / backward-data
+// ---------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ wp,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ residual,
+                                                          float* __restrict__ y, ConvGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HV = g.HD * g.HH * g.HWd;
+    float* halo = smem;                                  // [HV][36]
+    float* wbuf = smem + (size_t)HV * LDSROW;            // [2][64][36]
+    int* out_off = reinterpret_cast<int*>(wbuf + 2 * NT * LDSROW);   // [128] voxel -> output row or -1
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const unsigned nwg = gridDim.x;
+    const unsigned L = xcd_remap(blockIdx.x, nwg);
+    const int nt = L % g.nNt;
+    int mt = L / g.nNt;
+    const int tx = mt % g.tilesW; mt /= g.tilesW;
+    const int ty = mt % g.tilesH; mt /= g.tilesH;
+    const int tz = mt % g.tilesD;
+    const int b = mt / g.tilesD;
+    const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
+    const int n0 = nt * NT;
+    const int T = g.kd * g.kh * g.kw;
+
+    if (tid < MTILE) {
+        const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
+        const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+        int off = -1;
+        if (od < g.Do && oh < g.Ho && ow < g.Wo) off = ((b * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+        out_off[tid] = off;
+    }
+
+    // this lane's voxel (row of the A operand) -> halo index at tap (0,0,0)
+    int hidx_lane;
+    {
+        const int v = wave * 32 + l31;
+        const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
+        hidx_lane = (td * g.HH + th) * g.HWd + tw;
+    }
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    const int wrow = tid >> 3, wc4 = (tid & 7) * 4;      // weight staging: rows wrow, wrow+32
+
+    for (int chunk = 0; chunk < g.nChunks; ++chunk) {
+        const int ci0 = chunk * CK;
+        __syncthreads();   // all reads of the previous chunk's halo and of both weight buffers are done
+        // ---- stage halo chunk ----
+        for (int idx = tid; idx < HV * 8; idx += 256) {
+            const int hv = idx >> 3, c4 = (idx & 7) * 4;
+            const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+            const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+                const size_t base = ((((size_t)b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin + ci0 + c4;
+                if (VEC4) {
+                    if (ci0 + c4 < g.Cin) v = *reinterpret_cast<const float4*>(x + base);
+                } else {
+                    const int rem = g.Cin - (ci0 + c4);
+                    if (rem > 0) v.x = x[base];
+                    if (rem > 1) v.y = x[base + 1];
+                    if (rem > 2) v.z = x[base + 2];
+                    if (rem > 3) v.w = x[base + 3];
+                }
+            }
+            *reinterpret_cast<float4*>(halo + hv * LDSROW + c4) = v;
+        }
+        // ---- weights of tap 0 ----
+        const float* wchunk = wp + ((size_t)chunk * T * g.CoutPad + n0) * CK;
+        {
+            const float4 r0 = *reinterpret_cast<const float4*>(wchunk + (size_t)wrow * CK + wc4);
+            const float4 r1 = *reinterpret_cast<const float4*>(wchunk + (size_t)(wrow + 32) * CK + wc4);
+            *reinterpret_cast<float4*>(wbuf + wrow * LDSROW + wc4) = r0;
+            *reinterpret_cast<float4*>(wbuf + (wrow + 32) * LDSROW + wc4) = r1;
+        }
+        __syncthreads();
+
+        int tap = 0;
+        for (int kz = 0; kz < g.kd; ++kz)
+            for (int ky = 0; ky < g.kh; ++ky)
+                for (int kx = 0; kx < g.kw; ++kx, ++tap) {
+                    // prefetch next tap's weight panel into registers
+                    float4 r0, r1;
+                    const bool more = (tap + 1 < T);
+                    if (more) {
+                        const float* wt = wchunk + (size_t)(tap + 1) * g.CoutPad * CK;
+                        r0 = *reinterpret_cast<const float4*>(wt + (size_t)wrow * CK + wc4);
+                        r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
+                    }
+                    const float* wcur = wbuf + (tap & 1) * (NT * LDSROW);
+                    const float* ap = halo + (hidx_lane + (kz * g.HH + ky) * g.HWd + kx) * LDSROW + 4 * h;
+                    const float* bp = wcur + l31 * LDSROW + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 a = *reinterpret_cast<const float4*>(ap + 8 * q);
+                        const float4 b0 = *reinterpret_cast<const float4*>(bp + 8 * q);
+                        const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * q);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+                    }
+                    if (more) {
+                        float* wnext = wbuf + ((tap + 1) & 1) * (NT * LDSROW);
+                        *reinterpret_cast<float4*>(wnext + wrow * LDSROW + wc4) = r0;
+                        *reinterpret_cast<float4*>(wnext + (wrow + 32) * LDSROW + wc4) = r1;
+                    }
+                    __syncthreads();
+                }
+    }
+
+    // ---- epilogue: D[row=voxel][col=co]; row = (r&3) + 8*(r>>2) + 4*h ----
+    const int co0 = n0 + l31, co1 = n0 + 32 + l31;
+    const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
+    const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int off = out_off[wave * 32 + row];
+        if (off < 0) continue;
+        const size_t o = (size_t)off * g.Cout;
+        if (co0 < g.Cout) {
+            float v = acc0[r] + bias0;
+            if (residual) v += residual[o + co0];
+            y[o + co0] = v;
+        }
+        if (co1 < g.Cout) {
+            float v = acc1[r] + bias1;
+            if (residual) v += residual[o + co1];
+            y[o + co1] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward-weight (split-K partial slabs)
+// ---------------------------------------------------------------------------------------------
+constexpr int BW_MAXT = 5;       // taps per wave pair
+struct BwGeom {
+    ConvGeom g;
+    int tapGroups;               // groups of <=10 (kh,kw) taps per kd plane
+    int tilesPerSplit, MT;       // voxel tiles per grid.y block, total voxel tiles
+};
+
+template <bool VEC4>
+__global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy,
+                                                                 float* __restrict__ slabs, BwGeom bg) {
+    const ConvGeom& g = bg.g;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HHp = g.HH, HWp = g.HWd;                    // halo plane extents (TD x HH x HWd)
+    const int HVp = g.TD * HHp * HWp;
+    float* xh = smem;                                     // [HVp][32]
+    float* dyt = smem + (size_t)HVp * CK;                 // [128][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int coHalf = wave & 1, tapHalf = wave >> 1;
+
+    // blockIdx.x -> (chunk, coTile, kz, tapGroup)
+    int bx = blockIdx.x;
+    const int tg = bx % bg.tapGroups; bx /= bg.tapGroups;
+    const int kz = bx % g.kd; bx /= g.kd;
+    const int ct = bx % g.nNt;
+    const int chunk = bx / g.nNt;
+    const int ci0 = chunk * CK, n0 = ct * NT;
+    const int planeT = g.kh * g.kw;
+    const int tapBase = tg * (2 * BW_MAXT) + tapHalf * BW_MAXT;       // first (kh,kw) tap of this wave
+    int ntap = planeT - tapBase;
+    ntap = ntap < 0 ? 0 : (ntap > BW_MAXT ? BW_MAXT : ntap);
+
+    int tapoff[BW_MAXT];
+#pragma unroll
+    for (int t = 0; t < BW_MAXT; ++t) {
+        const int tp = tapBase + t;
+        const int ky = tp / g.kw, kx = tp % g.kw;
+        tapoff[t] = (t < ntap) ? (ky * HWp + kx) * CK : 0;
+    }
+
+    f32x16 acc[BW_MAXT];
+#pragma unroll
+    for (int t = 0; t < BW_MAXT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int mtBegin = blockIdx.y * bg.tilesPerSplit;
+    int mtEnd = mtBegin + bg.tilesPerSplit;
+    if (mtEnd > bg.MT) mtEnd = bg.MT;
+
+    for (int mt0 = mtBegin; mt0 < mtEnd; ++mt0) {
+        int mt = mt0;
+        const int tx = mt % g.tilesW; mt /= g.tilesW;
+        const int ty = mt % g.tilesH; mt /= g.tilesH;
+        const int tz = mt % g.tilesD;
+        const int b = mt / g.tilesD;
+        const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
+        __syncthreads();
+        // x halo plane for this kz: input depth rows d0 + td + kz - pd
+        for (int idx = tid; idx < HVp * 8; idx += 256) {
+            const int hv = idx >> 3, c4 = (idx & 7) * 4;
+            const int hx = hv % HWp, hy = (hv / HWp) % HHp, hz = hv / (HWp * HHp);
+            const int iz = d0 + hz + kz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+                const size_t base = ((((size_t)b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin + ci0 + c4;
+                if (VEC4) {
+                    if (ci0 + c4 < g.Cin) v = *reinterpret_cast<const float4*>(x + base);
+                } else {
+                    const int rem = g.Cin - (ci0 + c4);
+                    if (rem > 0) v.x = x[base];
+                    if (rem > 1) v.y = x[base + 1];
+                    if (rem > 2) v.z = x[base + 2];
+                    if (rem > 3) v.w = x[base + 3];
+                }
+            }
+            *reinterpret_cast<float4*>(xh + hv * CK + c4) = v;
+        }
+        // dY tile [128][64]
+        for (int idx = tid; idx < MTILE * 16; idx += 256) {
+            const int v = idx >> 4, c4 = (idx & 15) * 4;
+            const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
+            const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (od < g.Do && oh < g.Ho && ow < g.Wo) {
+                const size_t base = ((((size_t)b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout + n0 + c4;
+                const int rem = g.Cout - (n0 + c4);
+                if ((g.Cout & 3) == 0) {
+                    if (rem > 0) r = *reinterpret_cast<const float4*>(dy + base);
+                } else {
+                    if (rem > 0) r.x = dy[base];
+                    if (rem > 1) r.y = dy[base + 1];
+                    if (rem > 2) r.z = dy[base + 2];
+                    if (rem > 3) r.w = dy[base + 3];
+                }
+            }
+            *reinterpret_cast<float4*>(dyt + v * NT + c4) = r;
+        }
+        __syncthreads();
+        if (ntap > 0) {
+            // K loop over voxel pairs; lane half h takes voxel 2s+h
+            const float* ap0 = dyt + coHalf * 32 + l31;
+            for (int td = 0; td < g.TD; ++td)
+                for (int th = 0; th < g.TH; ++th) {
+                    const int vrow = (td * g.TH + th) * g.TW;
+                    const float* bprow = xh + ((td * HHp + th) * HWp) * CK + l31;
+                    for (int tw = 0; tw < g.TW; tw += 2) {
+                        const float a = ap0[(vrow + tw + h) * NT];
+                        const float* bp = bprow + (tw + h) * CK;
+#pragma unroll
+                        for (int t = 0; t < BW_MAXT; ++t) {
+                            if (t < ntap) {
+                                const float bv = bp[tapoff[t]];
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+        }
+    }
+
+    // slab layout == packed layout: [ksplit][chunk][tap][CoutPad][32]
+    const int T = g.kd * planeT;
+    float* slab = slabs + (size_t)blockIdx.y * g.nChunks * T * g.CoutPad * CK;
+#pragma unroll
+    for (int t = 0; t < BW_MAXT; ++t) {
+        if (t < ntap) {
+            const int tap = kz * planeT + tapBase + t;
+            float* dst = slab + (((size_t)chunk * T + tap) * g.CoutPad + n0 + coHalf * 32) * CK + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;      // co within the half
+                dst[(size_t)row * CK] = acc[t][r];
+            }
+        }
+    }
+}
+
+// dW[co][ci][tap] = sum_ks slab[ks][ci/32][tap][co][ci%32]
+__global__ void conv_reduce_dw_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                      int Cout, int Cin, int T, int CoutPad, int nChunks, int ksplit) {
+    const size_t total = (size_t)Cout * Cin * T;
+    const size_t slabElems = (size_t)nChunks * T * CoutPad * CK;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        // iterate in slab-friendly order: i -> (tap, co, ci) with ci fastest
+        const int ci = (int)(i % Cin);
+        size_t r = i / Cin;
+        const int co = (int)(r % Cout);
+        const int tap = (int)(r / Cout);
+        const size_t src = (((size_t)(ci / CK) * T + tap) * CoutPad + co) * CK + (ci % CK);
+        float s = 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slabs[(size_t)k * slabElems + src];
+        dw[((size_t)co * Cin + ci) * T + tap] = s;
+    }
+}
+
+// column sums: out[c] = sum_rows x[row][c]; stage 1 -> partial[block][C], stage 2 -> out
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ x,
+                                                            float* __restrict__ partial, size_t rows, int C) {
+    const size_t rowsPer = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = blockIdx.x * rowsPer;
+    size_t r1 = r0 + rowsPer;
+    if (r1 > rows) r1 = rows;
+    // thread t owns channels t, t+256, ... when C > 256; for C <= 256 several rows go in parallel
+    extern __shared__ float sh[];
+    if (C <= 256) {
+        const int rpar = 256 / C;                 // rows in flight
+        const int c = threadIdx.x % C, rr = threadIdx.x / C;
+        float s = 0.f;
+        if (rr < rpar)
+            for (size_t r = r0 + rr; r < r1; r += rpar) s += x[r * C + c];
+        sh[threadIdx.x] = (rr < rpar) ? s : 0.f;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float t = 0.f;
+            for (int k = 0; k < rpar; ++k) t += sh[k * C + threadIdx.x];
+            partial[(size_t)blockIdx.x * C + threadIdx.x] = t;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float s = 0.f;
+            for (size_t r = r0; r < r1; ++r) s += x[r * C + c];
+            partial[(size_t)blockIdx.x * C + c] = s;
+        }
+    }
+}
+__global__ void colsum_stage2_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += partial[(size_t)k * C + c];
+    out[c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static void choose_tile(int Do, int Ho, int Wo, int kd, int kh, int kw, int& TD, int& TH, int& TW) {
+    if (kd == 1 && kh == 1 && kw == 1) { TD = 1; TH = 1; TW = 128; return; }   // caller flattens voxels
+    // candidates with TD*TH*TW == 128; minimise halo volume x tile count (wasted lanes on ragged edges)
+    static const int cand[][3] = {{2, 8, 8}, {8, 4, 4}, {4, 4, 8}, {4, 8, 4}, {1, 8, 16}, {1, 16, 8}, {16, 4, 2},
+                                  {32, 2, 2}, {8, 8, 2}, {2, 4, 16}, {128, 1, 1}, {1, 1, 128}, {16, 8, 1}, {1, 2, 64}};
+    double best = 1e300;
+    for (auto& c : cand) {
+        if (c[2] & 1) continue;   // bwd-weight pairs voxels along W
+        const double tiles = (double)cdiv(Do, c[0]) * cdiv(Ho, c[1]) * cdiv(Wo, c[2]);
+        const double halo = (double)(c[0] + kd - 1) * (c[1] + kh - 1) * (c[2] + kw - 1);
+        if (halo * LDSROW * 4 + 2 * NT * LDSROW * 4 + 512 > 150 * 1024) continue;
+        const double cost = tiles * (halo * 0.15 + 128.0 * kd * kh * kw);   // staging + MFMA work
+        if (cost < best) { best = cost; TD = c[0]; TH = c[1]; TW = c[2]; }
+    }
+}
+
+static int make_geom(ConvGeom& g, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                     int pd, int ph, int pw) {
+    DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DIQT_E_SHAPE, "conv3d: non-positive extent");
+    DIQT_REQUIRE(kd > 0 && kh > 0 && kw > 0 && pd >= 0 && ph >= 0 && pw >= 0, DIQT_E_SHAPE, "conv3d: bad filter/pad");
+    if (kd == 1 && kh == 1 && kw == 1 && pd == 0 && ph == 0 && pw == 0) {   // 1x1x1: flatten all voxels into W
+        const long long rows = (long long)B * D * H * W;
+        DIQT_REQUIRE(rows < (1ll << 31), DIQT_E_SHAPE, "conv3d: too many rows");
+        B = 1; D = 1; H = 1; W = (int)rows;
+    }
+    g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+    g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw;
+    g.Do = D + 2 * pd - kd + 1; g.Ho = H + 2 * ph - kh + 1; g.Wo = W + 2 * pw - kw + 1;
+    DIQT_REQUIRE(g.Do > 0 && g.Ho > 0 && g.Wo > 0, DIQT_E_SHAPE, "conv3d: empty output");
+    g.TD = 2; g.TH = 8; g.TW = 8;
+    choose_tile(g.Do, g.Ho, g.Wo, kd, kh, kw, g.TD, g.TH, g.TW);
+    g.tilesD = cdiv(g.Do, g.TD); g.tilesH = cdiv(g.Ho, g.TH); g.tilesW = cdiv(g.Wo, g.TW);
+    g.nNt = cdiv(Cout, NT); g.CoutPad = g.nNt * NT; g.nChunks = cdiv(Cin, CK);
+    g.HD = g.TD + kd - 1; g.HH = g.TH + kh - 1; g.HWd = g.TW + kw - 1;
+    const long long nwg = (long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
+    DIQT_REQUIRE(nwg < (1ll << 31), DIQT_E_SHAPE, "conv3d: grid too large");
+    DIQT_REQUIRE((long long)g.B * g.Do * g.Ho * g.Wo < (1ll << 31), DIQT_E_SHAPE, "conv3d: too many output voxels");
+    return DIQT_OK;
+}
+
+}  // namespace diqt
+
+using namespace diqt;
+
+extern "C" size_t diqt_conv_packed_elems(int Cout, int Cin, int kd, int kh, int kw) {
+    if (Cout <= 0 || Cin <= 0 || kd <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (size_t)cdiv(Cin, CK) * kd * kh * kw * (cdiv(Cout, NT) * NT) * CK;
+}
+
+extern "C" long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, int kw, int pd, int ph, int pw) {
+    ConvGeom g;
+    if (make_geom(g, 1, D, H, W, 4, 4, kd, kh, kw, pd, ph, pw)) return -1;
+    return (long long)(((size_t)g.HD * g.HH * g.HWd * LDSROW + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int));
+}
+
+extern "C" int diqt_conv_pack_weight(const float* w, float* packed, int Cout, int Cin, int kd, int kh, int kw,
+                                     int mode, void* stream) {
+    DIQT_REQUIRE(w && packed, DIQT_E_ALIGN, "conv_pack_weight: null pointer");
+    DIQT_REQUIRE(Cout > 0 && Cin > 0 && kd > 0 && kh > 0 && kw > 0 && (mode == 0 || mode == 1), DIQT_E_SHAPE,
+                 "conv_pack_weight: bad shape/mode");
+    const int T = kd * kh * kw;
+    const int outEff = mode == 0 ? Cout : Cin, inEff = mode == 0 ? Cin : Cout;
+    const int CoutPadEff = cdiv(outEff, NT) * NT, nChunksEff = cdiv(inEff, CK);
+    const size_t total = (size_t)nChunksEff * T * CoutPadEff * CK;
+    hipLaunchKernelGGL(conv_pack_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       packed, Cout, Cin, T, mode, CoutPadEff, nChunksEff, total);
+    return check_launch("conv_pack_weight");
+}
+
+extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
+                               float* y, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                               int pd, int ph, int pw, void* stream) {
+    DIQT_REQUIRE(x && packed && y, DIQT_E_ALIGN, "conv3d_fwd: null pointer");
+    ConvGeom g;
+    int rc = make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw);
+    if (rc) return rc;
+    DIQT_REQUIRE(aligned16(packed), DIQT_E_ALIGN, "conv3d_fwd: packed weights must be 16-byte aligned");
+    const bool vec4 = (Cin % 4 == 0) && aligned16(x);
+    const size_t lds = ((size_t)g.HD * g.HH * g.HWd * LDSROW + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int);
+    DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_fwd: halo tile needs %zu B of LDS", lds);
+    const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
+    auto kern = vec4 ? conv_fwd_kernel<true> : conv_fwd_kernel<false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
+    return check_launch("conv3d_fwd");
+}
+
+static int bw_plan(BwGeom& bg, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
+                   int ph, int pw, int& ksplit) {
+    int rc = make_geom(bg.g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw);
+    if (rc) return rc;
+    const ConvGeom& g = bg.g;
+    bg.tapGroups = cdiv(kh * kw, 2 * BW_MAXT);
+    bg.MT = g.B * g.tilesD * g.tilesH * g.tilesW;
+    const int gx = g.nChunks * g.nNt * g.kd * bg.tapGroups;
+    ksplit = cdiv(1024, gx);
+    if (ksplit > bg.MT) ksplit = bg.MT;
+    if (ksplit < 1) ksplit = 1;
+    bg.tilesPerSplit = cdiv(bg.MT, ksplit);
+    ksplit = cdiv(bg.MT, bg.tilesPerSplit);
+    return DIQT_OK;
+}
+
+extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd,
+                                                         int kh, int kw, int pd, int ph, int pw) {
+    BwGeom bg;
+    int ksplit;
+    if (bw_plan(bg, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, ksplit)) return 0;
+    const size_t slab = (size_t)bg.g.nChunks * kd * kh * kw * bg.g.CoutPad * CK * sizeof(float);
+    const size_t colsum = (size_t)1024 * Cout * sizeof(float);
+    const size_t need = (size_t)ksplit * slab;
+    return need > colsum ? need : colsum;
+}
+
+extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, void* workspace,
+                                      size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout, int kd,
+                                      int kh, int kw, int pd, int ph, int pw, void* stream) {
+    DIQT_REQUIRE(x && dy && dw && workspace, DIQT_E_ALIGN, "conv3d_bwd_weight: null pointer");
+    BwGeom bg;
+    int ksplit;
+    int rc = bw_plan(bg, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, ksplit);
+    if (rc) return rc;
+    const ConvGeom& g = bg.g;
+    const int T = kd * kh * kw;
+    const size_t need = diqt_conv3d_bwd_weight_workspace_bytes(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw);
+    DIQT_REQUIRE(workspace_bytes >= need, DIQT_E_WORKSPACE, "conv3d_bwd_weight: workspace %zu < %zu", workspace_bytes, need);
+    DIQT_REQUIRE(aligned16(workspace), DIQT_E_ALIGN, "conv3d_bwd_weight: workspace must be 16-byte aligned");
+    const bool vec4 = (Cin % 4 == 0) && aligned16(x) && aligned16(dy);
+    const size_t lds = ((size_t)g.TD * g.HH * g.HWd * CK + (size_t)MTILE * NT) * sizeof(float);
+    DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_bwd_weight: tile needs %zu B of LDS", lds);
+    auto kern = vec4 ? conv_bwd_weight_kernel<true> : conv_bwd_weight_kernel<false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_bwd_weight: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* slabs = static_cast<float*>(workspace);
+    const dim3 grid(g.nChunks * g.nNt * g.kd * bg.tapGroups, ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, dy, slabs, bg);
+    rc = check_launch("conv3d_bwd_weight");
+    if (rc) return rc;
+    const size_t total = (size_t)Cout * Cin * T;
+    hipLaunchKernelGGL(conv_reduce_dw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, slabs, dw, Cout, Cin, T,
+                       g.CoutPad, g.nChunks, ksplit);
+    rc = check_launch("conv_reduce_dw");
+    if (rc) return rc;
+    if (dbias) {
+        const size_t rows = (size_t)g.B * g.Do * g.Ho * g.Wo;
+        unsigned nblk = (unsigned)((rows + 255) / 256);
+        if (nblk > 1024) nblk = 1024;
+        if (nblk < 1) nblk = 1;
+        // the slabs were consumed by the reduce kernel above (same stream) -> reuse the workspace
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), s, dy, slabs, rows, Cout);
+        rc = check_launch("colsum_stage1");
+        if (rc) return rc;
+        hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(Cout, 256)), dim3(256), 0, s, slabs, dbias, (int)nblk, Cout);
+        rc = check_launch("colsum_stage2");
+    }
+    return rc;
+}

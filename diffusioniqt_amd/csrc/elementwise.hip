@@ -1,0 +1,1147 @@
+// HBM-bound kernels of the DiffusionIQT hot path: GroupNorm statistics + fused normalise/scale-shift/
+// activation (fwd/bwd), channel LayerNorm, squeeze-excite pooling/gating, pixel (un)shuffle, channel
+// concat/split, sub-volume gather/scatter, diffusion step math, loss, Adam/EMA, softmax.
+// All activations are fp32 channels-last rows x[row][C]; every streaming access is 16 B per lane when
+// C % 4 == 0 and the pointers are 16-byte aligned (the scalar variants cover the rest).
+#include "common.h"
+
+namespace diqt {
+
+constexpr int RED_NBLK = 64;   // row slices per batch element in the column reductions
+
+// ---------------------------------------------------------------------------------------------
+// generic per-(b,c) column reduction: partial[b][blk][NV][C] = sum over the block's rows of f(...)
+// ---------------------------------------------------------------------------------------------
+template <int NV, class F>
+__global__ __launch_bounds__(256) void colreduce_kernel(F f, float* __restrict__ partial, int rows, int C) {
+    __shared__ float4 sh[NV][256];
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int rowsPer = (rows + nblk - 1) / nblk;
+    const int r0 = blk * rowsPer;
+    int r1 = r0 + rowsPer;
+    if (r1 > rows) r1 = rows;
+    float* dst = partial + ((size_t)b * nblk + blk) * NV * C;
+    if ((C & 3) == 0 && C <= 1024) {
+        const int tpr = C >> 2, rpar = 256 / tpr;
+        const int rr = threadIdx.x / tpr, cq = threadIdx.x % tpr;
+        float acc[NV][4];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[v][j] = 0.f;
+        if (rr < rpar) {
+            for (int r = r0 + rr; r < r1; r += rpar) {
+                float o[NV][4];
+                f.vec4(((size_t)b * rows + r) * C + cq * 4, b, cq * 4, o);
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[v][j] += o[v][j];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) sh[v][threadIdx.x] = make_float4(acc[v][0], acc[v][1], acc[v][2], acc[v][3]);
+        __syncthreads();
+        if (threadIdx.x < tpr) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float4 s = sh[v][threadIdx.x];
+                for (int k = 1; k < rpar; ++k) {
+                    const float4 t = sh[v][k * tpr + threadIdx.x];
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
+                *reinterpret_cast<float4*>(dst + v * C + threadIdx.x * 4) = s;
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float acc[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+            for (int r = r0; r < r1; ++r) {
+                float o[NV];
+                f.scalar(((size_t)b * rows + r) * C + c, b, c, o);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += o[v];
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dst[v * C + c] = acc[v];
+        }
+    }
+}
+
+static inline int red_nblk(int rows) {
+    int n = rows / 64;
+    if (n > RED_NBLK) n = RED_NBLK;
+    if (n < 1) n = 1;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics
+// ---------------------------------------------------------------------------------------------
+struct MomentsF {
+    const float* x;
+    __device__ void vec4(size_t i, int, int, float (&o)[2][4]) const {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        o[0][0] = v.x; o[0][1] = v.y; o[0][2] = v.z; o[0][3] = v.w;
+        o[1][0] = v.x * v.x; o[1][1] = v.y * v.y; o[1][2] = v.z * v.z; o[1][3] = v.w * v.w;
+    }
+    __device__ void scalar(size_t i, int, int, float (&o)[2]) const {
+        const float v = x[i];
+        o[0] = v; o[1] = v * v;
+    }
+};
+
+__global__ void gn_stats_final_kernel(const float* __restrict__ partial, float* __restrict__ mean,
+                                      float* __restrict__ rstd, int B, int C, int G, int nblk, double count,
+                                      float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i % G, Cg = C / G;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        const float* p = partial + ((size_t)b * nblk + k) * 2 * C;
+        for (int c = g * Cg; c < (g + 1) * Cg; ++c) { s += p[c]; ss += p[C + c]; }
+    }
+    const double m = s / count;
+    double var = ss / count - m * m;
+    if (var < 0) var = 0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused GN-apply + (scale+1)x+shift + activation
+// ---------------------------------------------------------------------------------------------
+struct GnCoef {   // y = act(A*x + Bc) per (b,c)
+    const float *mean, *rstd, *gamma, *beta, *scale, *shift;
+    int C, G, cs;   // cs: floats between consecutive batch rows of scale/shift
+    __device__ __forceinline__ void get(int b, int c, float& A, float& Bc) const {
+        const int g = c / (C / G);
+        const float m = mean[b * G + g], r = rstd[b * G + g];
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        const float sc = scale ? scale[b * cs + c] + 1.f : 1.f, sf = shift ? shift[b * cs + c] : 0.f;
+        A = r * ga * sc;
+        Bc = (be - m * r * ga) * sc + sf;
+    }
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         GnCoef k, int rows, int act) {
+    const int b = blockIdx.y, C = k.C;
+    const size_t per = (size_t)rows * C;
+    const float* xb = x + (size_t)b * per;
+    float* yb = y + (size_t)b * per;
+    if (VEC) {
+        const size_t n4 = per >> 2;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const int c = (int)((i * 4) % C);
+            float4 v = *reinterpret_cast<const float4*>(xb + i * 4);
+            float A, Bc;
+            k.get(b, c, A, Bc);     v.x = act_fwd(A * v.x + Bc, act);
+            k.get(b, c + 1, A, Bc); v.y = act_fwd(A * v.y + Bc, act);
+            k.get(b, c + 2, A, Bc); v.z = act_fwd(A * v.z + Bc, act);
+            k.get(b, c + 3, A, Bc); v.w = act_fwd(A * v.w + Bc, act);
+            *reinterpret_cast<float4*>(yb + i * 4) = v;
+        }
+    } else {
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+            float A, Bc;
+            k.get(b, (int)(i % C), A, Bc);
+            yb[i] = act_fwd(A * xb[i] + Bc, act);
+        }
+    }
+}
+
+// pass 1 of the backward: S1[b][c] = sum dz, S2[b][c] = sum dz*xhat, dz = dy*act'(z)
+struct GnBwdF {
+    const float *x, *dy;
+    GnCoef k;
+    int act;
+    __device__ __forceinline__ void one(float xv, float dyv, int b, int c, float& s1, float& s2) const {
+        float A, Bc;
+        k.get(b, c, A, Bc);
+        const int g = c / (k.C / k.G);
+        const float xhat = (xv - k.mean[b * k.G + g]) * k.rstd[b * k.G + g];
+        const float dz = dyv * act_grad(A * xv + Bc, act);
+        s1 = dz; s2 = dz * xhat;
+    }
+    __device__ void vec4(size_t i, int b, int c, float (&o)[2][4]) const {
+        const float4 xv = *reinterpret_cast<const float4*>(x + i);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + i);
+        one(xv.x, dv.x, b, c, o[0][0], o[1][0]);
+        one(xv.y, dv.y, b, c + 1, o[0][1], o[1][1]);
+        one(xv.z, dv.z, b, c + 2, o[0][2], o[1][2]);
+        one(xv.w, dv.w, b, c + 3, o[0][3], o[1][3]);
+    }
+    __device__ void scalar(size_t i, int b, int c, float (&o)[2]) const { one(x[i], dy[i], b, c, o[0], o[1]); }
+};
+
+// pass 2: reduce partials -> S[b][2][C] (in place at the head of the workspace tail), param grads, group means
+__global__ void gn_bwd_final_kernel(const float* __restrict__ partial, float* __restrict__ S, GnCoef k,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    float* __restrict__ dscale, float* __restrict__ dshift,
+                                    float* __restrict__ m12, int B, int nblk, float inv_count) {
+    // one block; thread loops
+    const int C = k.C, G = k.G, Cg = C / G;
+    for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
+        const int b = i / C, c = i % C;
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = 0; q < nblk; ++q) {
+            const float* p = partial + ((size_t)b * nblk + q) * 2 * C;
+            s1 += p[c]; s2 += p[C + c];
+        }
+        S[(size_t)b * 2 * C + c] = s1;
+        S[(size_t)b * 2 * C + C + c] = s2;
+        const float ga = k.gamma ? k.gamma[c] : 1.f, be = k.beta ? k.beta[c] : 0.f;
+        if (dscale) dscale[b * k.cs + c] = ga * s2 + be * s1;
+        if (dshift) dshift[b * k.cs + c] = s1;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float dg = 0.f, db = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float sc = k.scale ? k.scale[b * k.cs + c] + 1.f : 1.f;
+            dg += sc * S[(size_t)b * 2 * C + C + c];
+            db += sc * S[(size_t)b * 2 * C + c];
+        }
+        if (dgamma) dgamma[c] = dg;
+        if (dbeta) dbeta[c] = db;
+    }
+    for (int i = threadIdx.x; i < B * G; i += blockDim.x) {
+        const int b = i / G, g = i % G;
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
+            const float ga = k.gamma ? k.gamma[c] : 1.f;
+            const float sc = k.scale ? k.scale[b * k.cs + c] + 1.f : 1.f;
+            a1 += ga * sc * S[(size_t)b * 2 * C + c];
+            a2 += ga * sc * S[(size_t)b * 2 * C + C + c];
+        }
+        m12[2 * i] = a1 * inv_count;
+        m12[2 * i + 1] = a2 * inv_count;
+    }
+}
+
+// pass 3: dx = rstd * (gamma*(scale+1)*dz - m1 - xhat*m2)
+template <bool VEC>
+__global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dx, GnCoef k,
+                                                            const float* __restrict__ m12, int rows, int act) {
+    const int b = blockIdx.y, C = k.C, G = k.G, Cg = C / G;
+    const size_t per = (size_t)rows * C;
+    const float* xb = x + (size_t)b * per;
+    const float* dyb = dy + (size_t)b * per;
+    float* dxb = dx + (size_t)b * per;
+    auto one = [&](float xv, float dyv, int c) -> float {
+        float A, Bc;
+        k.get(b, c, A, Bc);
+        const int g = c / Cg;
+        const float r = k.rstd[b * G + g];
+        const float xhat = (xv - k.mean[b * G + g]) * r;
+        const float dz = dyv * act_grad(A * xv + Bc, act);
+        // A = r*gamma*(scale+1)  ->  gamma*(scale+1)*dz*r = A*dz
+        return A * dz - r * (m12[2 * (b * G + g)] + xhat * m12[2 * (b * G + g) + 1]);
+    };
+    if (VEC) {
+        const size_t n4 = per >> 2;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const int c = (int)((i * 4) % C);
+            const float4 xv = *reinterpret_cast<const float4*>(xb + i * 4);
+            const float4 dv = *reinterpret_cast<const float4*>(dyb + i * 4);
+            float4 o;
+            o.x = one(xv.x, dv.x, c); o.y = one(xv.y, dv.y, c + 1);
+            o.z = one(xv.z, dv.z, c + 2); o.w = one(xv.w, dv.w, c + 3);
+            *reinterpret_cast<float4*>(dxb + i * 4) = o;
+        }
+    } else {
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256)
+            dxb[i] = one(xb[i], dyb[i], (int)(i % C));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel LayerNorm (per row over C), gain only
+// ---------------------------------------------------------------------------------------------
+// one wave per row; C <= 64*16
+__global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          float* __restrict__ y, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb) {
+        const float* xr = x + (size_t)r * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += xr[c];
+        const float m = wave_sum(s) / C;
+        float v = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = xr[c] - m; v += d * d; }
+        const float rs = rsqrtf(wave_sum(v) / C + eps);
+        for (int c = lane; c < C; c += 64) y[(size_t)r * C + c] = (xr[c] - m) * rs * g[c];
+        if (lane == 0) { if (mean) mean[r] = m; if (rstd) rstd[r] = rs; }
+    }
+}
+
+// dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)), dxhat = dy*g ; dg partial via colreduce
+__global__ __launch_bounds__(256) void chan_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ g, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ dx,
+                                                             int rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb) {
+        const float* xr = x + (size_t)r * C;
+        const float* dr = dy + (size_t)r * C;
+        const float m = mean[r], rs = rstd[r];
+        float a = 0.f, bsum = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float dxh = dr[c] * g[c], xh = (xr[c] - m) * rs;
+            a += dxh; bsum += dxh * xh;
+        }
+        a = wave_sum(a) / C; bsum = wave_sum(bsum) / C;
+        for (int c = lane; c < C; c += 64) {
+            const float dxh = dr[c] * g[c], xh = (xr[c] - m) * rs;
+            dx[(size_t)r * C + c] = rs * (dxh - a - xh * bsum);
+        }
+    }
+}
+struct ChanLnDgF {
+    const float *x, *dy, *mean, *rstd;
+    int C;
+    __device__ __forceinline__ float one(size_t i) const {
+        const size_t r = i / C;
+        return dy[i] * (x[i] - mean[r]) * rstd[r];
+    }
+    __device__ void vec4(size_t i, int, int, float (&o)[1][4]) const {
+        o[0][0] = one(i); o[0][1] = one(i + 1); o[0][2] = one(i + 2); o[0][3] = one(i + 3);
+    }
+    __device__ void scalar(size_t i, int, int, float (&o)[1]) const { o[0] = one(i); }
+};
+__global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int NVC,
+                                    int total, float alpha) {
+    // out[b][j] = alpha * sum_k partial[b][k][j], j in [0,NVC); total = B*NVC
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / NVC, j = i % NVC;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += partial[((size_t)b * nblk + k) * NVC + j];
+    out[i] = alpha * s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise activation
+// ---------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
+    if (VEC) {
+        const size_t n4 = n >> 2;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+            v.x = act_fwd(v.x, act); v.y = act_fwd(v.y, act); v.z = act_fwd(v.z, act); v.w = act_fwd(v.w, act);
+            *reinterpret_cast<float4*>(y + i * 4) = v;
+        }
+        for (size_t i = (n4 << 2) + blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+            y[i] = act_fwd(x[i], act);
+    } else {
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = act_fwd(x[i], act);
+    }
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, size_t n, int act) {
+    if (VEC) {
+        const size_t n4 = n >> 2;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+            float4 d = *reinterpret_cast<const float4*>(dy + i * 4);
+            d.x *= act_grad(v.x, act); d.y *= act_grad(v.y, act); d.z *= act_grad(v.z, act); d.w *= act_grad(v.w, act);
+            *reinterpret_cast<float4*>(dx + i * 4) = d;
+        }
+        for (size_t i = (n4 << 2) + blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+            dx[i] = dy[i] * act_grad(x[i], act);
+    } else {
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+            dx[i] = dy[i] * act_grad(x[i], act);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// squeeze-excite helpers
+// ---------------------------------------------------------------------------------------------
+struct IdentF {
+    const float* x;
+    __device__ void vec4(size_t i, int, int, float (&o)[1][4]) const {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        o[0][0] = v.x; o[0][1] = v.y; o[0][2] = v.z; o[0][3] = v.w;
+    }
+    __device__ void scalar(size_t i, int, int, float (&o)[1]) const { o[0] = x[i]; }
+};
+struct ProdF {
+    const float *a, *b;
+    __device__ void vec4(size_t i, int, int, float (&o)[1][4]) const {
+        const float4 u = *reinterpret_cast<const float4*>(a + i);
+        const float4 v = *reinterpret_cast<const float4*>(b + i);
+        o[0][0] = u.x * v.x; o[0][1] = u.y * v.y; o[0][2] = u.z * v.z; o[0][3] = u.w * v.w;
+    }
+    __device__ void scalar(size_t i, int, int, float (&o)[1]) const { o[0] = a[i] * b[i]; }
+};
+
+// y = h*gate[b][c] (+ res)  |  mode 1: y = h*gate (dh = dy*gate uses the same kernel with res = NULL)
+template <bool VEC>
+__global__ __launch_bounds__(256) void gate_residual_kernel(const float* __restrict__ h, const float* __restrict__ gate,
+                                                            const float* __restrict__ res, const float* __restrict__ addc,
+                                                            float alpha, float* __restrict__ y, int rows, int C) {
+    const int b = blockIdx.y;
+    const size_t per = (size_t)rows * C;
+    const float* hb = h + (size_t)b * per;
+    const float* rb = res ? res + (size_t)b * per : nullptr;
+    const float* gb = gate + (size_t)b * C;
+    const float* ab = addc ? addc + (size_t)b * C : nullptr;
+    float* yb = y + (size_t)b * per;
+    if (VEC) {
+        const size_t n4 = per >> 2;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const int c = (int)((i * 4) % C);
+            float4 v = *reinterpret_cast<const float4*>(hb + i * 4);
+            const float4 gq = *reinterpret_cast<const float4*>(gb + c);
+            v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
+            if (ab) {
+                const float4 a = *reinterpret_cast<const float4*>(ab + c);
+                v.x += alpha * a.x; v.y += alpha * a.y; v.z += alpha * a.z; v.w += alpha * a.w;
+            }
+            if (rb) {
+                const float4 r = *reinterpret_cast<const float4*>(rb + i * 4);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            *reinterpret_cast<float4*>(yb + i * 4) = v;
+        }
+    } else {
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+            float v = hb[i] * gb[i % C];
+            if (ab) v += alpha * ab[i % C];
+            if (rb) v += rb[i];
+            yb[i] = v;
+        }
+    }
+}
+
+// SE3D.fc on [B][C] (single block: B*C*Cr MACs is a few 100k at most)
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, float* __restrict__ hidden,
+                                                         float* __restrict__ gate, int B, int C, int Cr) {
+    for (int i = threadIdx.x; i < B * Cr; i += 256) {
+        const int b = i / Cr, r = i % Cr;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += w1[r * C + c] * pooled[b * C + c];
+        hidden[i] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * C; i += 256) {
+        const int b = i / C, c = i % C;
+        float s = 0.f;
+        for (int r = 0; r < Cr; ++r) s += w2[c * Cr + r] * hidden[b * Cr + r];
+        gate[i] = 1.f / (1.f + __expf(-s));
+    }
+}
+__global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, const float* __restrict__ hidden,
+                                                         const float* __restrict__ gate, const float* __restrict__ dgate,
+                                                         float* __restrict__ dpooled, float* __restrict__ dw1,
+                                                         float* __restrict__ dw2, float* __restrict__ scratch, int B,
+                                                         int C, int Cr) {
+    float* dz2 = scratch;              // [B][C]
+    float* dhid = scratch + B * C;     // [B][Cr]
+    for (int i = threadIdx.x; i < B * C; i += 256) { const float g = gate[i]; dz2[i] = dgate[i] * g * (1.f - g); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * Cr; i += 256) {
+        const int c = i / Cr, r = i % Cr;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dz2[b * C + c] * hidden[b * Cr + r];
+        dw2[i] = s;
+    }
+    for (int i = threadIdx.x; i < B * Cr; i += 256) {
+        const int b = i / Cr, r = i % Cr;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += dz2[b * C + c] * w2[c * Cr + r];
+        dhid[i] = hidden[i] > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cr * C; i += 256) {
+        const int r = i / C, c = i % C;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dhid[b * Cr + r] * pooled[b * C + c];
+        dw1[i] = s;
+    }
+    for (int i = threadIdx.x; i < B * C; i += 256) {
+        const int b = i / C, c = i % C;
+        float s = 0.f;
+        for (int r = 0; r < Cr; ++r) s += dhid[b * Cr + r] * w1[r * C + c];
+        dpooled[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_channel_broadcast_kernel(float* __restrict__ x, const float* __restrict__ v,
+                                                                    float alpha, int rows, int C) {
+    const int b = blockIdx.y;
+    const size_t per = (size_t)rows * C;
+    float* xb = x + (size_t)b * per;
+    const float* vb = v + (size_t)b * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256)
+        xb[i] += alpha * vb[i % C];
+}
+
+// ---------------------------------------------------------------------------------------------
+// data movement
+// ---------------------------------------------------------------------------------------------
+// toSpace = 0: y[b][d][h][w][c*8 + s1*4+s2*2+s3] = x[b][2d+s1][2h+s2][2w+s3][c]; toSpace = 1: inverse
+__global__ __launch_bounds__(256) void shuffle2_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                       int D, int H, int W, int C, int toSpace) {
+    // iterate over the "space" side elements (B,2D,2H,2W,C), c fastest -> coalesced on that side
+    const size_t total = (size_t)B * 8 * D * H * W * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int w2 = (int)(r % (2 * W)); r /= 2 * W;
+        const int h2 = (int)(r % (2 * H)); r /= 2 * H;
+        const int d2 = (int)(r % (2 * D));
+        const int b = (int)(r / (2 * D));
+        const int s = ((d2 & 1) << 2) | ((h2 & 1) << 1) | (w2 & 1);
+        const size_t j = ((((size_t)b * D + (d2 >> 1)) * H + (h2 >> 1)) * W + (w2 >> 1)) * (8 * (size_t)C) + c * 8 + s;
+        if (toSpace) dst[i] = src[j]; else dst[j] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void concat_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b,
+                                                     int Cb, float* __restrict__ y, size_t rows) {
+    const int C = Ca + Cb;
+    const size_t total = rows * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / C;
+        const int c = (int)(i % C);
+        y[i] = c < Ca ? a[r * Ca + c] : b[r * Cb + (c - Ca)];
+    }
+}
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ y, float* __restrict__ a, int Ca,
+                                                    float* __restrict__ b, int Cb, size_t rows) {
+    const int C = Ca + Cb;
+    const size_t total = rows * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / C;
+        const int c = (int)(i % C);
+        if (c < Ca) { if (a) a[r * Ca + c] = y[i]; } else { if (b) b[r * Cb + (c - Ca)] = y[i]; }
+    }
+}
+
+// trilinear up-sampling, align_corners=True: src coord = o * (I-1)/(O-1)
+__global__ __launch_bounds__(256) void trilinear_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int D,
+                                                        int H, int W, int C, int scale, int adjoint) {
+    const int Do = D * scale, Ho = H * scale, Wo = W * scale;
+    const float rd = Do > 1 ? (float)(D - 1) / (Do - 1) : 0.f, rh = Ho > 1 ? (float)(H - 1) / (Ho - 1) : 0.f,
+                rw = Wo > 1 ? (float)(W - 1) / (Wo - 1) : 0.f;
+    const size_t total = (size_t)B * Do * Ho * Wo * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int od = (int)(r % Do);
+        const int b = (int)(r / Do);
+        const float fd = od * rd, fh = oh * rh, fw = ow * rw;
+        const int d0 = (int)fd, h0 = (int)fh, w0 = (int)fw;
+        const int d1 = d0 + (d0 < D - 1), h1 = h0 + (h0 < H - 1), w1 = w0 + (w0 < W - 1);
+        const float ld = fd - d0, lh = fh - h0, lw = fw - w0;
+        const float* sb = src + (size_t)b * D * H * W * C;
+        float* db_ = dst + (size_t)b * D * H * W * C;
+#define IDX(d, h, w) ((((size_t)(d) * H + (h)) * W + (w)) * C + c)
+        if (!adjoint) {
+            const float v = (1 - ld) * ((1 - lh) * ((1 - lw) * sb[IDX(d0, h0, w0)] + lw * sb[IDX(d0, h0, w1)]) +
+                                        lh * ((1 - lw) * sb[IDX(d0, h1, w0)] + lw * sb[IDX(d0, h1, w1)])) +
+                            ld * ((1 - lh) * ((1 - lw) * sb[IDX(d1, h0, w0)] + lw * sb[IDX(d1, h0, w1)]) +
+                                  lh * ((1 - lw) * sb[IDX(d1, h1, w0)] + lw * sb[IDX(d1, h1, w1)]));
+            dst[i] = v;
+        } else {
+            const float g = src[i];
+            atomicAdd(db_ + IDX(d0, h0, w0), g * (1 - ld) * (1 - lh) * (1 - lw));
+            atomicAdd(db_ + IDX(d0, h0, w1), g * (1 - ld) * (1 - lh) * lw);
+            atomicAdd(db_ + IDX(d0, h1, w0), g * (1 - ld) * lh * (1 - lw));
+            atomicAdd(db_ + IDX(d0, h1, w1), g * (1 - ld) * lh * lw);
+            atomicAdd(db_ + IDX(d1, h0, w0), g * ld * (1 - lh) * (1 - lw));
+            atomicAdd(db_ + IDX(d1, h0, w1), g * ld * (1 - lh) * lw);
+            atomicAdd(db_ + IDX(d1, h1, w0), g * ld * lh * (1 - lw));
+            atomicAdd(db_ + IDX(d1, h1, w1), g * ld * lh * lw);
+        }
+#undef IDX
+    }
+}
+
+// sub[n][A'][A'][A'][C] <-> vol[fA][fA][fA][C], n = b2 + f*b3 + f*f*b4 (axis 2 fastest), A' = A + 2*halo
+__global__ __launch_bounds__(256) void subvolume_kernel(const float* __restrict__ src, float* __restrict__ dst, int f,
+                                                        int A, int C, int halo, int scatter, int accumulate) {
+    const int Ap = A + 2 * halo, S = f * A;
+    const size_t total = (size_t)f * f * f * Ap * Ap * Ap * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int z = (int)(r % Ap); r /= Ap;
+        const int yy = (int)(r % Ap); r /= Ap;
+        const int xx = (int)(r % Ap);
+        const int n = (int)(r / Ap);
+        const int b2 = n % f, b3 = (n / f) % f, b4 = n / (f * f);
+        const int gx = b2 * A + xx - halo, gy = b3 * A + yy - halo, gz = b4 * A + z - halo;
+        const bool in = gx >= 0 && gx < S && gy >= 0 && gy < S && gz >= 0 && gz < S;
+        const size_t j = (((size_t)gx * S + gy) * S + gz) * C + c;
+        if (!scatter) dst[i] = in ? src[j] : 0.f;
+        else if (in) {
+            if (accumulate) atomicAdd(dst + j, src[i]); else dst[j] = src[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// diffusion step math
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void axpby3_kernel(const float* __restrict__ a, const float* __restrict__ b_,
+                                                     const float* __restrict__ c_, const float* __restrict__ c0,
+                                                     const float* __restrict__ c1, const float* __restrict__ c2,
+                                                     float lo, float hi, int clamp_mode, float* __restrict__ out,
+                                                     size_t per) {
+    const int b = blockIdx.y;
+    const float k0 = c0[b], k1 = (b_ && c1) ? c1[b] : 0.f, k2 = (c_ && c2) ? c2[b] : 0.f;
+    const size_t o = (size_t)b * per;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+        float v = k0 * a[o + i];
+        if (b_) v += k1 * b_[o + i];
+        if (c_) v += k2 * c_[o + i];
+        if (clamp_mode == 1) v = fmaxf(v, lo);
+        else if (clamp_mode == 2) v = fminf(fmaxf(v, lo), hi);
+        out[o + i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ x_t, const float* __restrict__ pred,
+                                                        const float* __restrict__ noise, const float* __restrict__ ca,
+                                                        const float* __restrict__ cb, const float* __restrict__ cn,
+                                                        float lo, float hi, int clamp_mode, float* __restrict__ x_next,
+                                                        float* __restrict__ x0_out, size_t per) {
+    const int b = blockIdx.y;
+    const float ka = ca[b], kb = cb[b], kn = cn[b];
+    const size_t o = (size_t)b * per;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+        float x0 = pred[o + i];
+        x0 = clamp_mode == 0 ? fmaxf(x0, lo) : fminf(fmaxf(x0, lo), hi);
+        if (x0_out) x0_out[o + i] = x0;
+        x_next[o + i] = ka * x_t[o + i] + kb * x0 + kn * noise[o + i];
+    }
+}
+
+__global__ __launch_bounds__(256) void mse_clamp_fwd_kernel(float* __restrict__ pred, const float* __restrict__ target,
+                                                            const float* __restrict__ w, float lo, int do_clamp,
+                                                            float* __restrict__ partials, int B, size_t per) {
+    __shared__ float sh[4];
+    const size_t total = (size_t)B * per;
+    float s = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float p = pred[i];
+        if (do_clamp) { p = fmaxf(p, lo); pred[i] = p; }
+        const float d = p - target[i];
+        s += (w ? w[i / per] : 1.f) * d * d;
+    }
+    s = block_sum256(s, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict__ partials, int n, float inv,
+                                                        float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    s = block_sum256(s, sh);
+    if (threadIdx.x == 0) *out = s * inv;
+}
+__global__ __launch_bounds__(256) void mse_clamp_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                            const float* __restrict__ w, float lo, int do_clamp,
+                                                            float coef, float* __restrict__ dpred, int B, size_t per) {
+    const size_t total = (size_t)B * per;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float p = pred[i];
+        // the reference clamps in place (imagen_pytorch3D.py:2362): no gradient where pred was floored
+        float gq = coef * (w ? w[i / per] : 1.f) * (p - target[i]);
+        if (do_clamp && !(p > lo)) gq = 0.f;
+        dpred[i] = gq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimiser
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, float lr, float b1, float b2,
+                                                   float eps, float wd, float bc1, float bc2_sqrt, int zero_grad) {
+    const float step = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // lerp, as torch's exp_avg.lerp_
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, size_t n, float w) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        e[i] += (p[i] - e[i]) * w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax over the middle axis of [outer][n][inner]
+// ---------------------------------------------------------------------------------------------
+// inner == 1: one wave per row
+__global__ __launch_bounds__(256) void softmax_row_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          size_t rows, int n, float scale) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (size_t r = blockIdx.x * (size_t)wpb + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * wpb) {
+        const float* xr = x + r * n;
+        float mx = -INFINITY;
+        for (int i = lane; i < n; i += 64) mx = fmaxf(mx, xr[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s += __expf(xr[i] - mx);
+        s = wave_sum(s);
+        const float inv = scale / s;
+        for (int i = lane; i < n; i += 64) y[r * n + i] = __expf(xr[i] - mx) * inv;
+    }
+}
+__global__ __launch_bounds__(256) void softmax_row_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, size_t rows, int n, float scale) {
+    // y = scale*p ; dx = p*(scale*dy - sum(scale*dy*p)) = y*(dy - sum(dy*y)/scale)
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (size_t r = blockIdx.x * (size_t)wpb + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * wpb) {
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s += y[r * n + i] * dy[r * n + i];
+        s = wave_sum(s) / scale;
+        for (int i = lane; i < n; i += 64) dx[r * n + i] = y[r * n + i] * (dy[r * n + i] - s);
+    }
+}
+// inner > 1: one thread per (outer, inner) column
+__global__ __launch_bounds__(256) void softmax_col_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          size_t outer, int n, int inner, float scale) {
+    const size_t total = outer * inner;
+    for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const size_t o = t / inner, j = t % inner;
+        const float* xc = x + o * n * inner + j;
+        float mx = -INFINITY;
+        for (int i = 0; i < n; ++i) mx = fmaxf(mx, xc[(size_t)i * inner]);
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += __expf(xc[(size_t)i * inner] - mx);
+        const float inv = scale / s;
+        float* yc = y + o * n * inner + j;
+        for (int i = 0; i < n; ++i) yc[(size_t)i * inner] = __expf(xc[(size_t)i * inner] - mx) * inv;
+    }
+}
+__global__ __launch_bounds__(256) void softmax_col_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, size_t outer, int n, int inner,
+                                                              float scale) {
+    const size_t total = outer * inner;
+    for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const size_t base = (t / inner) * n * inner + (t % inner);
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += y[base + (size_t)i * inner] * dy[base + (size_t)i * inner];
+        s /= scale;
+        for (int i = 0; i < n; ++i) {
+            const size_t k = base + (size_t)i * inner;
+            dx[k] = y[k] * (dy[k] - s);
+        }
+    }
+}
+
+
+__global__ void learned_sinu_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w, float* __restrict__ out,
+                                        int B, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i % half, D = 2 * half + 1;
+    const float f = t[b] * w[j] * 6.283185307179586f;
+    if (j == 0) out[b * D] = t[b];
+    out[b * D + 1 + j] = sinf(f);
+    out[b * D + 1 + half + j] = cosf(f);
+}
+__global__ void learned_sinu_bwd_kernel(const float* __restrict__ t, const float* __restrict__ w,
+                                        const float* __restrict__ dout, float* __restrict__ dw, int B, int half) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= half) return;
+    const int D = 2 * half + 1;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float k = t[b] * 6.283185307179586f, f = k * w[j];
+        s += k * (dout[b * D + 1 + j] * cosf(f) - dout[b * D + 1 + half + j] * sinf(f));
+    }
+    dw[j] = s;
+}
+
+}  // namespace diqt
+
+using namespace diqt;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+#define STREAM ((hipStream_t)stream)
+
+extern "C" size_t diqt_reduce_workspace_bytes(int B, int C) {
+    if (B <= 0 || C <= 0) return 0;
+    return ((size_t)B * RED_NBLK * 2 * C + (size_t)2 * B * C + (size_t)2 * B * C + 64) * sizeof(float);
+}
+
+static bool vec_ok(const void* a, const void* b, const void* c, size_t per_batch_elems, int C) {
+    return (C % 4 == 0) && (per_batch_elems % 4 == 0) && aligned16(a) && (!b || aligned16(b)) && (!c || aligned16(c));
+}
+
+extern "C" int diqt_groupnorm_stats(const float* x, float* mean, float* rstd, void* workspace, size_t workspace_bytes,
+                                    int B, int rows, int C, int G, float eps, void* stream) {
+    DIQT_REQUIRE(x && mean && rstd && workspace, DIQT_E_ALIGN, "groupnorm_stats: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "groupnorm_stats: bad shape (C=%d,G=%d)", C, G);
+    DIQT_REQUIRE(workspace_bytes >= diqt_reduce_workspace_bytes(B, C), DIQT_E_WORKSPACE, "groupnorm_stats: workspace too small");
+    DIQT_REQUIRE(aligned16(workspace) && (C % 4 != 0 || aligned16(x)), DIQT_E_ALIGN, "groupnorm_stats: misaligned pointer");
+    const int nblk = red_nblk(rows);
+    float* partial = static_cast<float*>(workspace);
+    MomentsF f{x};
+    hipLaunchKernelGGL((colreduce_kernel<2, MomentsF>), dim3(nblk, B), dim3(256), 0, STREAM, f, partial, rows, C);
+    int rc = check_launch("groupnorm_stats/reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_stats_final_kernel, dim3((B * G + 63) / 64), dim3(64), 0, STREAM, partial, mean, rstd, B, C, G,
+                       nblk, (double)rows * (C / G), eps);
+    return check_launch("groupnorm_stats/final");
+}
+
+extern "C" int diqt_gn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const float* scale, const float* shift, int cond_stride, float* y,
+                               int B, int rows, int C, int G, int act, void* stream) {
+    DIQT_REQUIRE(x && mean && rstd && y, DIQT_E_ALIGN, "gn_act_fwd: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_act_fwd: bad shape");
+    DIQT_REQUIRE((scale == nullptr) == (shift == nullptr), DIQT_E_SHAPE, "gn_act_fwd: scale and shift go together");
+    DIQT_REQUIRE(!scale || cond_stride >= C, DIQT_E_SHAPE, "gn_act_fwd: cond_stride < C");
+    GnCoef k{mean, rstd, gamma, beta, scale, shift, C, G, cond_stride};
+    const size_t per = (size_t)rows * C;
+    const dim3 grid(grid_for(per / 4 + 1, 256, 1024), B);
+    if (vec_ok(x, y, nullptr, per, C))
+        hipLaunchKernelGGL(gn_act_fwd_kernel<true>, grid, dim3(256), 0, STREAM, x, y, k, rows, act);
+    else
+        hipLaunchKernelGGL(gn_act_fwd_kernel<false>, grid, dim3(256), 0, STREAM, x, y, k, rows, act);
+    return check_launch("gn_act_fwd");
+}
+
+extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, const float* scale, const float* shift,
+                               int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
+                               size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream) {
+    DIQT_REQUIRE(x && dy && mean && rstd && dx && workspace, DIQT_E_ALIGN, "gn_act_bwd: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_act_bwd: bad shape");
+    DIQT_REQUIRE(workspace_bytes >= diqt_reduce_workspace_bytes(B, C), DIQT_E_WORKSPACE, "gn_act_bwd: workspace too small");
+    DIQT_REQUIRE(aligned16(workspace), DIQT_E_ALIGN, "gn_act_bwd: misaligned workspace");
+    DIQT_REQUIRE(!scale || cond_stride >= C, DIQT_E_SHAPE, "gn_act_bwd: cond_stride < C");
+    GnCoef k{mean, rstd, gamma, beta, scale, shift, C, G, cond_stride};
+    const int nblk = red_nblk(rows);
+    float* partial = static_cast<float*>(workspace);
+    float* S = partial + (size_t)B * RED_NBLK * 2 * C;
+    float* m12 = S + (size_t)2 * B * C;
+    const size_t per = (size_t)rows * C;
+    const bool vec = vec_ok(x, dy, dx, per, C);
+    GnBwdF f{x, dy, k, act};
+    if (vec || C % 4 != 0 || C > 1024) {
+        hipLaunchKernelGGL((colreduce_kernel<2, GnBwdF>), dim3(nblk, B), dim3(256), 0, STREAM, f, partial, rows, C);
+    } else {
+        set_error("gn_act_bwd: C %% 4 == 0 requires 16-byte aligned x, dy, dx");
+        return DIQT_E_ALIGN;
+    }
+    int rc = check_launch("gn_act_bwd/reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(1), dim3(256), 0, STREAM, partial, S, k, dgamma, dbeta, dscale, dshift,
+                       m12, B, nblk, 1.f / ((float)rows * (C / G)));
+    rc = check_launch("gn_act_bwd/final");
+    if (rc) return rc;
+    const dim3 grid(grid_for(per / 4 + 1, 256, 1024), B);
+    if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
+    else hipLaunchKernelGGL(gn_act_bwd_dx_kernel<false>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
+    return check_launch("gn_act_bwd/dx");
+}
+
+extern "C" int diqt_chan_layernorm_fwd(const float* x, const float* g, float* y, float* mean, float* rstd, int rows,
+                                       int C, float eps, void* stream) {
+    DIQT_REQUIRE(x && g && y, DIQT_E_ALIGN, "chan_layernorm_fwd: null pointer");
+    DIQT_REQUIRE(rows > 0 && C > 0, DIQT_E_SHAPE, "chan_layernorm_fwd: bad shape");
+    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3(grid_for((size_t)rows, 4, 4096)), dim3(256), 0, STREAM, x, g, y, mean, rstd,
+                       rows, C, eps);
+    return check_launch("chan_layernorm_fwd");
+}
+
+extern "C" int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean,
+                                       const float* rstd, float* dx, float* dg, void* workspace,
+                                       size_t workspace_bytes, int rows, int C, void* stream) {
+    DIQT_REQUIRE(x && dy && g && mean && rstd && dx, DIQT_E_ALIGN, "chan_layernorm_bwd: null pointer");
+    DIQT_REQUIRE(rows > 0 && C > 0, DIQT_E_SHAPE, "chan_layernorm_bwd: bad shape");
+    hipLaunchKernelGGL(chan_ln_bwd_dx_kernel, dim3(grid_for((size_t)rows, 4, 4096)), dim3(256), 0, STREAM, x, dy, g, mean,
+                       rstd, dx, rows, C);
+    int rc = check_launch("chan_layernorm_bwd/dx");
+    if (rc || !dg) return rc;
+    DIQT_REQUIRE(workspace && workspace_bytes >= diqt_reduce_workspace_bytes(1, C), DIQT_E_WORKSPACE,
+                 "chan_layernorm_bwd: workspace too small");
+    const int nblk = red_nblk(rows);
+    float* partial = static_cast<float*>(workspace);
+    ChanLnDgF f{x, dy, mean, rstd, C};
+    hipLaunchKernelGGL((colreduce_kernel<1, ChanLnDgF>), dim3(nblk, 1), dim3(256), 0, STREAM, f, partial, rows, C);
+    rc = check_launch("chan_layernorm_bwd/dg");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, STREAM, partial, dg, nblk, C, C, 1.f);
+    return check_launch("chan_layernorm_bwd/dg-final");
+}
+
+extern "C" int diqt_act_fwd(const float* x, float* y, size_t n, int act, void* stream) {
+    DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "act_fwd: null pointer");
+    if (n == 0) return DIQT_OK;
+    if (aligned16(x) && aligned16(y))
+        hipLaunchKernelGGL(act_fwd_kernel<true>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, STREAM, x, y, n, act);
+    else
+        hipLaunchKernelGGL(act_fwd_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, x, y, n, act);
+    return check_launch("act_fwd");
+}
+extern "C" int diqt_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, void* stream) {
+    DIQT_REQUIRE(x && dy && dx, DIQT_E_ALIGN, "act_bwd: null pointer");
+    if (n == 0) return DIQT_OK;
+    if (aligned16(x) && aligned16(dy) && aligned16(dx))
+        hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, STREAM, x, dy, dx, n, act);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, x, dy, dx, n, act);
+    return check_launch("act_bwd");
+}
+
+template <class F>
+static int colreduce1(F f, float* out, float alpha, void* workspace, size_t workspace_bytes, int B, int rows, int C,
+                      void* stream, const char* what) {
+    DIQT_REQUIRE(workspace && workspace_bytes >= diqt_reduce_workspace_bytes(B, C), DIQT_E_WORKSPACE, "%s: workspace too small", what);
+    DIQT_REQUIRE(aligned16(workspace), DIQT_E_ALIGN, "%s: misaligned workspace", what);
+    const int nblk = red_nblk(rows);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL((colreduce_kernel<1, F>), dim3(nblk, B), dim3(256), 0, STREAM, f, partial, rows, C);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((B * C + 255) / 256), dim3(256), 0, STREAM, partial, out, nblk, C, B * C, alpha);
+    return check_launch(what);
+}
+
+extern "C" int diqt_channel_mean(const float* x, float* pooled, void* workspace, size_t workspace_bytes, int B,
+                                 int rows, int C, void* stream) {
+    DIQT_REQUIRE(x && pooled, DIQT_E_ALIGN, "channel_mean: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0, DIQT_E_SHAPE, "channel_mean: bad shape");
+    DIQT_REQUIRE(C % 4 != 0 || aligned16(x), DIQT_E_ALIGN, "channel_mean: misaligned x");
+    return colreduce1(IdentF{x}, pooled, 1.f / rows, workspace, workspace_bytes, B, rows, C, stream, "channel_mean");
+}
+
+extern "C" int diqt_gate_residual_fwd(const float* h, const float* gate, const float* res, const float* addc,
+                                      float alpha, float* y, int B, int rows, int C, void* stream) {
+    DIQT_REQUIRE(h && gate && y, DIQT_E_ALIGN, "gate_residual_fwd: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0, DIQT_E_SHAPE, "gate_residual_fwd: bad shape");
+    const size_t per = (size_t)rows * C;
+    const dim3 grid(grid_for(per / 4 + 1, 256, 1024), B);
+    if (vec_ok(h, res, y, per, C) && aligned16(gate) && (!addc || aligned16(addc)))
+        hipLaunchKernelGGL(gate_residual_kernel<true>, grid, dim3(256), 0, STREAM, h, gate, res, addc, alpha, y, rows, C);
+    else
+        hipLaunchKernelGGL(gate_residual_kernel<false>, grid, dim3(256), 0, STREAM, h, gate, res, addc, alpha, y, rows, C);
+    return check_launch("gate_residual_fwd");
+}
+
+extern "C" int diqt_gate_residual_bwd(const float* h, const float* dy, float* dgate, void* workspace,
+                                      size_t workspace_bytes, int B, int rows, int C, void* stream) {
+    DIQT_REQUIRE(h && dy && dgate, DIQT_E_ALIGN, "gate_residual_bwd: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0, DIQT_E_SHAPE, "gate_residual_bwd: bad shape");
+    DIQT_REQUIRE(C % 4 != 0 || (aligned16(h) && aligned16(dy)), DIQT_E_ALIGN, "gate_residual_bwd: misaligned pointer");
+    return colreduce1(ProdF{dy, h}, dgate, 1.f, workspace, workspace_bytes, B, rows, C, stream, "gate_residual_bwd");
+}
+
+extern "C" int diqt_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* hidden, float* gate, int B,
+                               int C, int Cr, void* stream) {
+    DIQT_REQUIRE(pooled && w1 && w2 && hidden && gate, DIQT_E_ALIGN, "se_mlp_fwd: null pointer");
+    DIQT_REQUIRE(B > 0 && C > 0 && Cr > 0, DIQT_E_SHAPE, "se_mlp_fwd: bad shape");
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(1), dim3(256), 0, STREAM, pooled, w1, w2, hidden, gate, B, C, Cr);
+    return check_launch("se_mlp_fwd");
+}
+extern "C" int diqt_se_mlp_bwd(const float* pooled, const float* w1, const float* w2, const float* hidden,
+                               const float* gate, const float* dgate, float* dpooled, float* dw1, float* dw2,
+                               float* scratch, int B, int C, int Cr, void* stream) {
+    DIQT_REQUIRE(pooled && w1 && w2 && hidden && gate && dgate && dpooled && dw1 && dw2 && scratch, DIQT_E_ALIGN,
+                 "se_mlp_bwd: null pointer");
+    DIQT_REQUIRE(B > 0 && C > 0 && Cr > 0, DIQT_E_SHAPE, "se_mlp_bwd: bad shape");
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(256), 0, STREAM, pooled, w1, w2, hidden, gate, dgate, dpooled, dw1,
+                       dw2, scratch, B, C, Cr);
+    return check_launch("se_mlp_bwd");
+}
+
+extern "C" int diqt_add_channel_broadcast(float* x, const float* v, float alpha, int B, int rows, int C, void* stream) {
+    DIQT_REQUIRE(x && v, DIQT_E_ALIGN, "add_channel_broadcast: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0, DIQT_E_SHAPE, "add_channel_broadcast: bad shape");
+    hipLaunchKernelGGL(add_channel_broadcast_kernel, dim3(grid_for((size_t)rows * C, 256, 1024), B), dim3(256), 0, STREAM, x,
+                       v, alpha, rows, C);
+    return check_launch("add_channel_broadcast");
+}
+
+extern "C" int diqt_space_to_depth2(const float* x, float* y, int B, int D, int H, int W, int C, void* stream) {
+    DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "space_to_depth2: null pointer");
+    DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, DIQT_E_SHAPE, "space_to_depth2: bad shape");
+    hipLaunchKernelGGL(shuffle2_kernel, dim3(grid_for((size_t)B * 8 * D * H * W * C, 256)), dim3(256), 0, STREAM, x, y, B, D,
+                       H, W, C, 0);
+    return check_launch("space_to_depth2");
+}
+extern "C" int diqt_depth_to_space2(const float* x, float* y, int B, int D, int H, int W, int C, void* stream) {
+    DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "depth_to_space2: null pointer");
+    DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, DIQT_E_SHAPE, "depth_to_space2: bad shape");
+    hipLaunchKernelGGL(shuffle2_kernel, dim3(grid_for((size_t)B * 8 * D * H * W * C, 256)), dim3(256), 0, STREAM, x, y, B, D,
+                       H, W, C, 1);
+    return check_launch("depth_to_space2");
+}
+extern "C" int diqt_concat_channels(const float* a, int Ca, const float* b, int Cb, float* y, size_t rows, void* stream) {
+    DIQT_REQUIRE(a && b && y, DIQT_E_ALIGN, "concat_channels: null pointer");
+    DIQT_REQUIRE(Ca > 0 && Cb > 0, DIQT_E_SHAPE, "concat_channels: bad shape");
+    if (rows == 0) return DIQT_OK;
+    hipLaunchKernelGGL(concat_kernel, dim3(grid_for(rows * (Ca + Cb), 256)), dim3(256), 0, STREAM, a, Ca, b, Cb, y, rows);
+    return check_launch("concat_channels");
+}
+extern "C" int diqt_split_channels(const float* y, float* a, int Ca, float* b, int Cb, size_t rows, void* stream) {
+    DIQT_REQUIRE(y && (a || b), DIQT_E_ALIGN, "split_channels: null pointer");
+    DIQT_REQUIRE(Ca > 0 && Cb > 0, DIQT_E_SHAPE, "split_channels: bad shape");
+    if (rows == 0) return DIQT_OK;
+    hipLaunchKernelGGL(split_kernel, dim3(grid_for(rows * (Ca + Cb), 256)), dim3(256), 0, STREAM, y, a, Ca, b, Cb, rows);
+    return check_launch("split_channels");
+}
+extern "C" int diqt_subvolume_gather(const float* vol, float* sub, int f, int A, int C, int halo, void* stream) {
+    DIQT_REQUIRE(vol && sub, DIQT_E_ALIGN, "subvolume_gather: null pointer");
+    DIQT_REQUIRE(f > 0 && A > 0 && C > 0 && halo >= 0, DIQT_E_SHAPE, "subvolume_gather: bad shape");
+    const size_t Ap = A + 2 * halo;
+    hipLaunchKernelGGL(subvolume_kernel, dim3(grid_for((size_t)f * f * f * Ap * Ap * Ap * C, 256)), dim3(256), 0, STREAM, vol,
+                       sub, f, A, C, halo, 0, 0);
+    return check_launch("subvolume_gather");
+}
+extern "C" int diqt_subvolume_scatter(const float* sub, float* vol, int f, int A, int C, int halo, int accumulate,
+                                      void* stream) {
+    DIQT_REQUIRE(vol && sub, DIQT_E_ALIGN, "subvolume_scatter: null pointer");
+    DIQT_REQUIRE(f > 0 && A > 0 && C > 0 && halo >= 0, DIQT_E_SHAPE, "subvolume_scatter: bad shape");
+    DIQT_REQUIRE(halo == 0 || accumulate, DIQT_E_UNSUPPORTED, "subvolume_scatter: overlapping halo blocks need accumulate=1");
+    const size_t Ap = A + 2 * halo;
+    hipLaunchKernelGGL(subvolume_kernel, dim3(grid_for((size_t)f * f * f * Ap * Ap * Ap * C, 256)), dim3(256), 0, STREAM, sub,
+                       vol, f, A, C, halo, 1, accumulate);
+    return check_launch("subvolume_scatter");
+}
+
+extern "C" int diqt_axpby3(const float* a, const float* b_, const float* c_, const float* c0, const float* c1,
+                           const float* c2, float lo, float hi, int clamp_mode, float* out, int B, size_t per,
+                           void* stream) {
+    DIQT_REQUIRE(a && c0 && out, DIQT_E_ALIGN, "axpby3: null pointer");
+    DIQT_REQUIRE(B > 0 && per > 0, DIQT_E_SHAPE, "axpby3: bad shape");
+    hipLaunchKernelGGL(axpby3_kernel, dim3(grid_for(per, 256, 1024), B), dim3(256), 0, STREAM, a, b_, c_, c0, c1, c2, lo, hi,
+                       clamp_mode, out, per);
+    return check_launch("axpby3");
+}
+extern "C" int diqt_q_sample(const float* x0, const float* noise, const float* alpha, const float* sigma, float* xt,
+                             int B, size_t per, void* stream) {
+    DIQT_REQUIRE(x0 && noise && alpha && sigma && xt, DIQT_E_ALIGN, "q_sample: null pointer");
+    return diqt_axpby3(x0, noise, nullptr, alpha, sigma, nullptr, 0.f, 0.f, 0, xt, B, per, stream);
+}
+extern "C" int diqt_ddpm_step(const float* x_t, const float* pred, const float* noise, const float* ca, const float* cb,
+                              const float* cn, float lo, float hi, int clamp_mode, float* x_next, float* x0_out, int B,
+                              size_t per, void* stream) {
+    DIQT_REQUIRE(x_t && pred && noise && ca && cb && cn && x_next, DIQT_E_ALIGN, "ddpm_step: null pointer");
+    DIQT_REQUIRE(B > 0 && per > 0, DIQT_E_SHAPE, "ddpm_step: bad shape");
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(per, 256, 1024), B), dim3(256), 0, STREAM, x_t, pred, noise, ca, cb, cn,
+                       lo, hi, clamp_mode, x_next, x0_out, per);
+    return check_launch("ddpm_step");
+}
+extern "C" int diqt_mse_clamp_fwd(float* pred, const float* target, const float* w, float lo, int do_clamp,
+                                  float* partials, float* loss_out, int B, size_t per, void* stream) {
+    DIQT_REQUIRE(pred && target && partials && loss_out, DIQT_E_ALIGN, "mse_clamp_fwd: null pointer");
+    DIQT_REQUIRE(B > 0 && per > 0, DIQT_E_SHAPE, "mse_clamp_fwd: bad shape");
+    const unsigned nblk = grid_for((size_t)B * per, 256, 1024);
+    hipLaunchKernelGGL(mse_clamp_fwd_kernel, dim3(nblk), dim3(256), 0, STREAM, pred, target, w, lo, do_clamp, partials, B, per);
+    int rc = check_launch("mse_clamp_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, STREAM, partials, (int)nblk, 1.f / ((float)B * (float)per),
+                       loss_out);
+    return check_launch("mse_final");
+}
+extern "C" int diqt_mse_clamp_bwd(const float* pred, const float* target, const float* w, float lo, int do_clamp,
+                                  float gscale, float* dpred, int B, size_t per, void* stream) {
+    DIQT_REQUIRE(pred && target && dpred, DIQT_E_ALIGN, "mse_clamp_bwd: null pointer");
+    DIQT_REQUIRE(B > 0 && per > 0, DIQT_E_SHAPE, "mse_clamp_bwd: bad shape");
+    const float coef = gscale * 2.f / ((float)B * (float)per);
+    hipLaunchKernelGGL(mse_clamp_bwd_kernel, dim3(grid_for((size_t)B * per, 256, 2048)), dim3(256), 0, STREAM, pred, target, w,
+                       lo, do_clamp, coef, dpred, B, per);
+    return check_launch("mse_clamp_bwd");
+}
+
+extern "C" int diqt_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                              float bias_correction2, int zero_grad, void* stream) {
+    DIQT_REQUIRE(param && grad && exp_avg && exp_avg_sq, DIQT_E_ALIGN, "adam_step: null pointer");
+    if (n == 0) return DIQT_OK;
+    DIQT_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, DIQT_E_SHAPE, "adam_step: bad bias correction");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, STREAM, param, grad, exp_avg, exp_avg_sq, n,
+                       lr, beta1, beta2, eps, weight_decay, bias_correction1, sqrtf(bias_correction2), zero_grad);
+    return check_launch("adam_step");
+}
+extern "C" int diqt_ema_lerp(float* ema, const float* param, size_t n, float one_minus_decay, void* stream) {
+    DIQT_REQUIRE(ema && param, DIQT_E_ALIGN, "ema_lerp: null pointer");
+    if (n == 0) return DIQT_OK;
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, STREAM, ema, param, n, one_minus_decay);
+    return check_launch("ema_lerp");
+}
+
+extern "C" int diqt_softmax_fwd(const float* x, float* y, size_t outer, int n, int inner, float scale, void* stream) {
+    DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "softmax_fwd: null pointer");
+    DIQT_REQUIRE(n > 0 && inner > 0, DIQT_E_SHAPE, "softmax_fwd: bad shape");
+    if (outer == 0) return DIQT_OK;
+    if (inner == 1)
+        hipLaunchKernelGGL(softmax_row_kernel, dim3(grid_for(outer, 4, 8192)), dim3(256), 0, STREAM, x, y, outer, n, scale);
+    else
+        hipLaunchKernelGGL(softmax_col_kernel, dim3(grid_for(outer * inner, 256)), dim3(256), 0, STREAM, x, y, outer, n, inner, scale);
+    return check_launch("softmax_fwd");
+}
+extern "C" int diqt_softmax_bwd(const float* y, const float* dy, float* dx, size_t outer, int n, int inner, float scale,
+                                void* stream) {
+    DIQT_REQUIRE(y && dy && dx, DIQT_E_ALIGN, "softmax_bwd: null pointer");
+    DIQT_REQUIRE(n > 0 && inner > 0 && scale != 0.f, DIQT_E_SHAPE, "softmax_bwd: bad shape");
+    if (outer == 0) return DIQT_OK;
+    if (inner == 1)
+        hipLaunchKernelGGL(softmax_row_bwd_kernel, dim3(grid_for(outer, 4, 8192)), dim3(256), 0, STREAM, y, dy, dx, outer, n, scale);
+    else
+        hipLaunchKernelGGL(softmax_col_bwd_kernel, dim3(grid_for(outer * inner, 256)), dim3(256), 0, STREAM, y, dy, dx, outer, n, inner, scale);
+    return check_launch("softmax_bwd");
+}
+
+extern "C" int diqt_learned_sinu_fwd(const float* t, const float* w, float* out, int B, int half, void* stream) {
+    DIQT_REQUIRE(t && w && out, DIQT_E_ALIGN, "learned_sinu_fwd: null pointer");
+    DIQT_REQUIRE(B > 0 && half > 0, DIQT_E_SHAPE, "learned_sinu_fwd: bad shape");
+    hipLaunchKernelGGL(learned_sinu_fwd_kernel, dim3((B * half + 63) / 64), dim3(64), 0, STREAM, t, w, out, B, half);
+    return check_launch("learned_sinu_fwd");
+}
+extern "C" int diqt_learned_sinu_bwd(const float* t, const float* w, const float* dout, float* dw, int B, int half,
+                                     void* stream) {
+    DIQT_REQUIRE(t && w && dout && dw, DIQT_E_ALIGN, "learned_sinu_bwd: null pointer");
+    DIQT_REQUIRE(B > 0 && half > 0, DIQT_E_SHAPE, "learned_sinu_bwd: bad shape");
+    hipLaunchKernelGGL(learned_sinu_bwd_kernel, dim3((half + 63) / 64), dim3(64), 0, STREAM, t, w, dout, dw, B, half);
+    return check_launch("learned_sinu_bwd");
+}
+
+extern "C" int diqt_trilinear_up_fwd(const float* x, float* y, int B, int D, int H, int W, int C, int scale, void* stream) {
+    DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "trilinear_up_fwd: null pointer");
+    DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && scale > 0, DIQT_E_SHAPE, "trilinear_up_fwd: bad shape");
+    const size_t total = (size_t)B * D * H * W * C * scale * scale * scale;
+    hipLaunchKernelGGL(trilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, x, y, B, D, H, W, C, scale, 0);
+    return check_launch("trilinear_up_fwd");
+}
+extern "C" int diqt_trilinear_up_bwd(const float* dy, float* dx, int B, int D, int H, int W, int C, int scale, void* stream) {
+    DIQT_REQUIRE(dy && dx, DIQT_E_ALIGN, "trilinear_up_bwd: null pointer");
+    DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && scale > 0, DIQT_E_SHAPE, "trilinear_up_bwd: bad shape");
+    const size_t total = (size_t)B * D * H * W * C * scale * scale * scale;
+    hipLaunchKernelGGL(trilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, dy, dx, B, D, H, W, C, scale, 1);
+    return check_launch("trilinear_up_bwd");
+}

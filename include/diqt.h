@@ -1,0 +1,241 @@
+/*
+ * diqt.h — C ABI of libdiqt_hip.so: the MI355X (gfx950) device kernels behind the
+ * DiffusionIQT hot path (3-D conditional-diffusion U-Net forward/backward, DDPM/EDM sampler
+ * step, loss, optimiser step).
+ *
+ * Drop-in boundary: the reference has no native layer — every FLOP is an ATen op
+ * called from imagen_pytorch3D.py / imagen_video.py / elucidated_imagen.py / trainer.py.  Each entry
+ * point below names the reference call site(s) (file:line, relative to the reference root) whose
+ * ATen op(s) it replaces.  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, ints, floats; `stream` is a hipStream_t passed as void*
+ *     (NULL = the null stream).  Every call is asynchronous on `stream`, holds no pointer past the
+ *     completion of the work it enqueues and keeps no global mutable state.
+ *   - activations are fp32, channels-last ("NDHWC"): x[b][d][h][w][c], c fastest.
+ *     `rows` = b*d*h*w when an op does not care about the spatial structure.
+ *   - weights cross the boundary in the reference's own layout (OIDHW for Conv3d, [out][in] for
+ *     Linear); diqt_conv_pack_weight re-lays them for the MFMA kernels.
+ *   - every entry returns DIQT_OK (0) or a negative DIQT_E_* code; it never throws, never exits.
+ *     diqt_last_error() returns a thread-local message for the most recent failure.
+ */
+#ifndef DIQT_H
+#define DIQT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIQT_OK             0
+#define DIQT_E_SHAPE       -1   /* an extent is <= 0 or inconsistent with another          */
+#define DIQT_E_ALIGN       -2   /* a pointer is NULL or not aligned as the kernel requires  */
+#define DIQT_E_UNSUPPORTED -3   /* valid request the library has no kernel for              */
+#define DIQT_E_LAUNCH      -4   /* HIP reported an error at launch                          */
+#define DIQT_E_WORKSPACE   -5   /* workspace too small (see the *_workspace_bytes query)    */
+
+/* activation selectors (imagen_pytorch3D.py:547 Mish; imagen_video.py:690 SiLU; :1113 GELU; :623 ReLU; :625 Sigmoid) */
+#define DIQT_ACT_NONE    0
+#define DIQT_ACT_MISH    1
+#define DIQT_ACT_SILU    2
+#define DIQT_ACT_GELU    3
+#define DIQT_ACT_RELU    4
+#define DIQT_ACT_SIGMOID 5
+
+int         diqt_version(void);
+const char* diqt_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution (stride 1, zero padding) as an im2col-free implicit GEMM on v_mfma_f32_32x32x2_f32.
+ * Replaces nn.Conv3d / nn.Linear / nn.Conv1d at: Block.project imagen_pytorch3D.py:551-553,566;
+ * init_conv :1289-1291,1589; 1x1 convs :467,495,597,1388,1477; Linear :588,622-624,1310,1315;
+ * pseudo-3D convs imagen_video.py:352-406,529-543.
+ * Output extent per axis: O = I + 2*pad - k + 1.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* number of floats in the packed-weight buffer for a (Cout,Cin,kd,kh,kw) filter */
+size_t diqt_conv_packed_elems(int Cout, int Cin, int kd, int kh, int kw);
+
+/* mode 0: forward packing of w[Cout][Cin][kd][kh][kw];
+ * mode 1: backward-data packing (taps flipped, in/out swapped) — feed to diqt_conv3d_fwd with
+ *         (Cin,Cout) swapped and pad' = k-1-pad to obtain dX from dY.                               */
+int diqt_conv_pack_weight(const float* w_oidhw, float* packed, int Cout, int Cin,
+                          int kd, int kh, int kw, int mode, void* stream);
+
+/* y[B][Do][Ho][Wo][Cout] = conv(x[B][D][H][W][Cin], packed) + bias   (bias may be NULL).
+ * If `residual` != NULL it is added in the epilogue (same shape as y).                              */
+int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
+                    float* y, int B, int D, int H, int W, int Cin, int Cout,
+                    int kd, int kh, int kw, int pd, int ph, int pw, void* stream);
+
+/* LDS bytes the MFMA kernel needs for this geometry (> 160 KiB: use diqt_conv3d_direct_*); < 0 on bad shape */
+long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, int kw, int pd, int ph, int pw);
+
+/* dW[Cout][Cin][kd][kh][kw] (OIDHW, overwritten) and dbias[Cout] (may be NULL) from x and dY.
+ * Deterministic: split-K partial slabs in `workspace` are reduced in a fixed order.                  */
+size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout,
+                                              int kd, int kh, int kw, int pd, int ph, int pw);
+int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw_oidhw, float* dbias,
+                           void* workspace, size_t workspace_bytes,
+                           int B, int D, int H, int W, int Cin, int Cout,
+                           int kd, int kh, int kw, int pd, int ph, int pw, void* stream);
+
+/* Direct (non-MFMA) grouped / strided convolution for the FLOP-trivial shapes: depthwise 3^3 and
+ * patchify k=s=p convs of the attention blocks (imagen_pytorch3D.py:858-869, 913-924, 960-976),
+ * temporal depthwise (3,1,1) PEG (imagen_video.py:1351-1352).  Weights OIDHW with I = Cin/groups.   */
+int diqt_conv3d_direct_fwd(const float* x, const float* w, const float* bias, float* y,
+                           int B, int D, int H, int W, int Cin, int Cout, int groups,
+                           int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                           void* stream);
+int diqt_conv3d_direct_bwd_data(const float* dy, const float* w, float* dx,
+                                int B, int D, int H, int W, int Cin, int Cout, int groups,
+                                int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                                void* stream);
+int diqt_conv3d_direct_bwd_weight(const float* x, const float* dy, float* dw, float* dbias,
+                                  int B, int D, int H, int W, int Cin, int Cout, int groups,
+                                  int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm + (scale+1)*x+shift + activation  — Block.forward imagen_pytorch3D.py:555-562,
+ * imagen_video.py:683-699.  Statistics per (batch, group) over rows_per_batch x (C/G).
+ * ---------------------------------------------------------------------------------------------- */
+/* workspace: diqt_reduce_workspace_bytes(B, C) bytes, 16-byte aligned (per-(b,c) partial moments) */
+size_t diqt_reduce_workspace_bytes(int B, int C);
+int diqt_groupnorm_stats(const float* x, float* mean, float* rstd, void* workspace, size_t workspace_bytes,
+                         int B, int rows_per_batch, int C, int G, float eps, void* stream);
+
+/* y = act( ((x-mean)*rstd*gamma+beta) * (scale+1) + shift ); scale/shift are both NULL or point at
+ * rows of `cond_stride` floats per batch element (the reference chunks one [B][2C] time embedding,
+ * imagen_pytorch3D.py:603-605: scale = emb, shift = emb + C, cond_stride = 2C).                       */
+int diqt_gn_act_fwd(const float* x, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, const float* scale, const float* shift,
+                    int cond_stride, float* y, int B, int rows_per_batch, int C, int G, int act, void* stream);
+
+/* dx, dgamma[C], dbeta[C], dscale[B][C], dshift[B][C] (last two NULL when scale/shift are).
+ * `workspace` holds per-(b,c) partial sums: diqt_reduce_workspace_bytes(B,C).                         */
+int diqt_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, const float* scale, const float* shift,
+                    int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift,
+                    void* workspace, size_t workspace_bytes,
+                    int B, int rows_per_batch, int C, int G, int act, void* stream);
+
+/* Per-position LayerNorm over the channel axis, gain only, biased variance
+ * (ChanLayerNorm imagen_pytorch3D.py:361-382; LayerNorm imagen_video.py:172-200).                    */
+int diqt_chan_layernorm_fwd(const float* x, const float* g, float* y, float* mean, float* rstd,
+                            int rows, int C, float eps, void* stream);
+/* dg[C] is reduced through `workspace` (diqt_reduce_workspace_bytes(1, C)) */
+int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean,
+                            const float* rstd, float* dx, float* dg, void* workspace, size_t workspace_bytes,
+                            int rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise activations (n floats) — nn.Mish / SiLU / GELU / ReLU / Sigmoid call sites above.
+ * ---------------------------------------------------------------------------------------------- */
+int diqt_act_fwd(const float* x, float* y, size_t n, int act, void* stream);
+int diqt_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, void* stream);
+
+/* LearnedSinusoidalPosEmb (imagen_pytorch3D.py:518-533): out[b] = [t, sin(2 pi t w), cos(2 pi t w)] */
+int diqt_learned_sinu_fwd(const float* t, const float* w, float* out, int B, int half, void* stream);
+/* dw[half] (overwritten) from dout[B][2*half+1] */
+int diqt_learned_sinu_bwd(const float* t, const float* w, const float* dout, float* dw, int B, int half, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Squeeze-excite + residual — SE3D imagen_pytorch3D.py:617-632 and `h + res_conv(x)` :610-612.
+ * ---------------------------------------------------------------------------------------------- */
+/* pooled[b][c] = mean over rows_per_batch of x[b][.][c]  (AdaptiveAvgPool3d(1) :620,630) */
+int diqt_channel_mean(const float* x, float* pooled, void* workspace, size_t workspace_bytes,
+                      int B, int rows_per_batch, int C, void* stream);
+/* y = h*gate[b][c] + res + alpha*addc[b][c]   (res, addc may be NULL).  The same entry yields the
+ * backward dh = dy*gate + (1/rows)*dpooled[b][c] of the gate AND of the mean pool in one pass.        */
+int diqt_gate_residual_fwd(const float* h, const float* gate, const float* res, const float* addc, float alpha,
+                           float* y, int B, int rows_per_batch, int C, void* stream);
+/* dgate[b][c] = sum_rows dy*h */
+int diqt_gate_residual_bwd(const float* h, const float* dy, float* dgate, void* workspace, size_t workspace_bytes,
+                           int B, int rows_per_batch, int C, void* stream);
+/* SE3D.fc (imagen_pytorch3D.py:621-626,631): hidden = relu(pooled w1^T), gate = sigmoid(hidden w2^T);
+ * w1[Cr][C], w2[C][Cr], no biases.  bwd: dpooled, dw1, dw2 from dgate; scratch >= B*(C+Cr) floats.     */
+int diqt_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* hidden, float* gate,
+                    int B, int C, int Cr, void* stream);
+int diqt_se_mlp_bwd(const float* pooled, const float* w1, const float* w2, const float* hidden, const float* gate,
+                    const float* dgate, float* dpooled, float* dw1, float* dw2, float* scratch,
+                    int B, int C, int Cr, void* stream);
+/* x[b][.][c] += v[b][c] broadcast (backward of the mean pool, scaled by caller) and friends */
+int diqt_add_channel_broadcast(float* x, const float* v, float alpha, int B, int rows_per_batch, int C,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data movement — Downsample rearrange imagen_pytorch3D.py:494, PixelShuffle3D :427-439,
+ * torch.cat on channels :1576,1653, sub-volume split/merge utils_mine.py:25-67, halo :37-46.
+ * ---------------------------------------------------------------------------------------------- */
+/* x[B][2D][2H][2W][C] -> y[B][D][H][W][C*8], out channel = c*8 + s1*4 + s2*2 + s3 */
+int diqt_space_to_depth2(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
+/* exact inverse (x[B][D][H][W][C*8] -> y[B][2D][2H][2W][C]); also PixelShuffle3D(2) forward */
+int diqt_depth_to_space2(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
+/* y[rows][Ca+Cb] = cat(a[rows][Ca], b[rows][Cb]) ; and the inverse split */
+int diqt_concat_channels(const float* a, int Ca, const float* b, int Cb, float* y, size_t rows, void* stream);
+int diqt_split_channels(const float* y, float* a, int Ca, float* b, int Cb, size_t rows, void* stream);
+/* trilinear x`scale` up-sampling with align_corners=True (nn.Upsample imagen_pytorch3D.py:954) and its
+ * adjoint (dx must be zeroed by the caller; accumulated with float atomics)                          */
+int diqt_trilinear_up_fwd(const float* x, float* y, int B, int D, int H, int W, int C, int scale, void* stream);
+int diqt_trilinear_up_bwd(const float* dy, float* dx, int B, int D, int H, int W, int C, int scale, void* stream);
+/* sub-volume batch <-> merged volume, NDHWC; sub-volume n = b2 + f*b3 + f*f*b4 (utils_mine.py:41).
+ * halo>0 gathers (A+2*halo)^3 blocks from the zero-padded merged volume (boundary_pad).             */
+int diqt_subvolume_gather(const float* vol, float* sub, int f, int A, int C, int halo, void* stream);
+int diqt_subvolume_scatter(const float* sub, float* vol, int f, int A, int C, int halo, int accumulate,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Diffusion elementwise steps.
+ * ---------------------------------------------------------------------------------------------- */
+/* x_t = alpha[b]*x0 + sigma[b]*noise   — q_sample imagen_pytorch3D.py:311-322 */
+int diqt_q_sample(const float* x0, const float* noise, const float* alpha, const float* sigma,
+                  float* xt, int B, size_t per_batch, void* stream);
+/* DDPM ancestral step — p_mean_variance/p_sample imagen_pytorch3D.py:1996-2055, q_posterior :290-309.
+ * x0 = clamp(pred) [clamp_mode 0: min=lo ; 1: [lo,hi]]; x_next = ca[b]*x_t + cb[b]*x0 + cn[b]*noise,
+ * where the caller precomputes ca = alpha_next*(1-c)/alpha, cb = alpha_next*c, cn = nonzero*exp(.5*logvar). */
+int diqt_ddpm_step(const float* x_t, const float* pred, const float* noise,
+                   const float* ca, const float* cb, const float* cn, float lo, float hi, int clamp_mode,
+                   float* x_next, float* x0_out, int B, size_t per_batch, void* stream);
+/* generic per-batch affine combination used by the EDM Heun sampler (elucidated_imagen.py:476-516):
+ * out = clamp( c0[b]*a + c1[b]*b_ + c2[b]*c_ ) ; b_/c_ may be NULL; clamp_mode 0 none, 1 min=lo, 2 [lo,hi] */
+int diqt_axpby3(const float* a, const float* b_, const float* c_, const float* c0, const float* c1,
+                const float* c2, float lo, float hi, int clamp_mode, float* out,
+                int B, size_t per_batch, void* stream);
+/* loss = mean_b mean_i (clamp_min(pred,lo) - target)^2, per-batch weights w[b] (NULL = 1)
+ * — p_losses imagen_pytorch3D.py:2361-2364; writes clamped pred in place like the reference.
+ * loss_out: single float (atomic-free two-stage reduce through `partials`, >= 1024 floats).          */
+int diqt_mse_clamp_fwd(float* pred, const float* target, const float* w, float lo, int do_clamp,
+                       float* partials, float* loss_out, int B, size_t per_batch, void* stream);
+/* dpred = gscale * 2*(pred-target)*w[b]/(B*per_batch), zero where pred was clamped (pred <= lo)      */
+int diqt_mse_clamp_bwd(const float* pred_clamped, const float* target, const float* w, float lo,
+                       int do_clamp, float gscale, float* dpred, int B, size_t per_batch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser — Adam (trainer.py:352-359, step at :1056) fused with zero_grad, and the EMA lerp
+ * (ema_pytorch, trainer.py:1059-1061), over one flat fp32 arena.
+ * ---------------------------------------------------------------------------------------------- */
+int diqt_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float bias_correction1, float bias_correction2, int zero_grad, void* stream);
+int diqt_ema_lerp(float* ema, const float* param, size_t n, float one_minus_decay, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention over flattened volumetric tokens.
+ * ---------------------------------------------------------------------------------------------- */
+/* softmax over the middle axis of x[outer][n][inner] (inner = 1: row softmax), scaled by `scale`
+ * after normalisation (LinearAttention imagen_pytorch3D.py:1003-1006; Attention imagen_video.py:511) */
+int diqt_softmax_fwd(const float* x, float* y, size_t outer, int n, int inner, float scale, void* stream);
+int diqt_softmax_bwd(const float* y, const float* dy, float* dx, size_t outer, int n, int inner, float scale,
+                     void* stream);
+/* batched fp32 MFMA GEMM: C[g] = alpha * op(A[g]) * op(B[g]) (+ beta*C[g]); row-major, strides in floats */
+int diqt_bgemm(const float* A, const float* Bm, float* C, int batch, int M, int N, int K,
+               int transA, int transB, long long strideA, long long strideB, long long strideC,
+               int lda, int ldb, int ldc, float alpha, float beta, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIQT_H */

@@ -1,0 +1,331 @@
+"""Per-kernel parity on a real MI355X: every HIP operator (through the C ABI via diffusioniqt_amd.ops)
+against plain PyTorch fp32/fp64 on the CPU with the same seeded inputs.
+
+Tolerance (fp32 path, SURVEY.md §8d / BASELINE.md §4): the MFMA f32 conv is a k-ordered fmaf chain, so
+|err| <= ~1e-6 * sum|a*b|; tests use max-abs error <= 2e-5 * max|ref| (+1e-6) unless noted.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from diffusioniqt_amd import ops as _ops, _lib
+    _lib.load()
+    return _ops
+
+
+DEV = "cuda"
+
+
+def close(got, ref, tol=2e-5, what=""):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale + 1e-6, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def cl(x):      # NCDHW -> NDHWC on device
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+
+
+def cf(x):      # NDHWC device -> NCDHW cpu
+    return x.detach().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+CONV_CASES = [
+    # B, (D,H,W), Cin, Cout, k, pad
+    (2, (16, 16, 16), 64, 64, (3, 3, 3), (1, 1, 1)),
+    (1, (8, 8, 8), 128, 128, (3, 3, 3), (1, 1, 1)),
+    (2, (8, 8, 8), 2, 16, (3, 3, 3), (1, 1, 1)),          # init conv: Cin=2 (scalar staging path)
+    (1, (8, 8, 8), 192, 128, (3, 3, 3), (1, 1, 1)),        # concat skip: 3 K-chunks, 2 N-tiles
+    (3, (10, 10, 10), 16, 16, (3, 3, 3), (0, 0, 0)),       # un-padded 'boundary' conv 10^3 -> 8^3
+    (1, (7, 9, 10), 20, 24, (3, 3, 3), (1, 1, 1)),         # ragged extents, Cin % 32 != 0, Cout % 32 != 0
+    (2, (4, 4, 4), 512, 64, (1, 1, 1), (0, 0, 0)),         # 1x1x1 after space-to-depth
+    (1, (16, 16, 16), 64, 1, (1, 1, 1), (0, 0, 0)),        # final conv Cout = 1
+    (2, (6, 8, 8), 32, 32, (1, 3, 3), (0, 1, 1)),          # pseudo-3D spatial conv
+    (2, (6, 8, 8), 8, 40, (1, 7, 7), (0, 3, 3)),           # cross-embed (1,7,7)
+    (2, (5, 1, 1), 33, 7, (3, 1, 1), (1, 0, 0)),           # temporal conv, odd channels
+]
+
+
+@pytest.mark.parametrize("B,sp,Cin,Cout,k,pad", CONV_CASES)
+def test_conv3d_fwd_bwd(ops, B, sp, Cin, Cout, k, pad):
+    g = torch.Generator().manual_seed(hash((B, sp, Cin, Cout, k)) % 2 ** 31)
+    x = torch.randn(B, Cin, *sp, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.conv3d(xr, wr, br, padding=pad)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+
+    xd, wd, bd = cl(x).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.conv3d(xd, wd, bd, pad)
+    close(cf(y), yr, what="conv fwd")
+    y.backward(cl(dy))
+    close(cf(xd.grad), xr.grad, what="conv dx")
+    close(wd.grad, wr.grad, tol=5e-5, what="conv dw")
+    close(bd.grad, br.grad, tol=5e-5, what="conv db")
+
+
+def test_conv3d_residual_epilogue_and_linear(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 8, 8, 8, generator=g)
+    w = torch.randn(16, 16, 3, 3, 3, generator=g) * 0.05
+    r = torch.randn(2, 16, 8, 8, 8, generator=g)
+    y = ops.conv3d(cl(x), w.to(DEV), None, (1, 1, 1), residual=cl(r))
+    close(cf(y), F.conv3d(x, w, padding=1) + r, what="conv+residual")
+    xl = torch.randn(3, 17, generator=g)
+    wl = torch.randn(64, 17, generator=g)
+    bl = torch.randn(64, generator=g)
+    xld, wld, bld = xl.to(DEV).requires_grad_(), wl.to(DEV).requires_grad_(), bl.to(DEV).requires_grad_()
+    yl = ops.linear(xld, wld, bld)
+    close(yl, F.linear(xl, wl, bl), what="linear")
+    yl.sum().backward()
+    close(wld.grad, xl.sum(0)[None, :].expand(64, 17), what="linear dw")
+    close(xld.grad, wl.sum(0)[None, :].expand(3, 17), what="linear dx")
+
+
+@pytest.mark.parametrize("groups,stride,k,pad,Cin,Cout", [(16, 1, 3, 1, 16, 16), (8, 4, 4, 0, 8, 8), (1, 2, 2, 0, 4, 6),
+                                                            (12, 1, (3, 1, 1), (1, 0, 0), 12, 12)])
+def test_conv3d_direct(ops, groups, stride, k, pad, Cin, Cout):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, Cin, 8, 8, 8, generator=g)
+    kk = (k,) * 3 if isinstance(k, int) else k
+    w = torch.randn(Cout, Cin // groups, *kk, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.conv3d(xr, wr, br, stride=stride, padding=pad, groups=groups)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xd, wd, bd = cl(x).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.conv3d_direct(xd, wd, bd, stride, pad, groups)
+    close(cf(y), yr, what="direct fwd")
+    y.backward(cl(dy))
+    close(cf(xd.grad), xr.grad, what="direct dx")
+    close(wd.grad, wr.grad, tol=1e-4, what="direct dw")
+    close(bd.grad, br.grad, tol=1e-4, what="direct db")
+
+
+@pytest.mark.parametrize("C,G,with_ss,act", [(64, 8, True, "mish"), (192, 8, False, "mish"), (16, 8, True, "silu"), (6, 3, True, "mish")])
+def test_groupnorm_scale_shift_act(ops, C, G, with_ss, act):
+    g = torch.Generator().manual_seed(3)
+    B, S = 3, 6
+    x = torch.randn(B, C, S, S, S, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ss = torch.randn(B, 2 * C, generator=g) * 0.5 if with_ss else None
+    fn = F.mish if act == "mish" else F.silu
+    xr, gr, br = x.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    ssr = ss.double().requires_grad_() if with_ss else None
+    h = F.group_norm(xr, G, gr, br, eps=1e-5)
+    if with_ss:
+        sc, sh = ssr[:, :C, None, None, None], ssr[:, C:, None, None, None]
+        h = h * (sc + 1) + sh
+    yr = fn(h)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xd, gd, bd = cl(x).requires_grad_(), gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    ssd = ss.to(DEV).requires_grad_() if with_ss else None
+    y = ops.groupnorm_act(xd, gd, bd, ssd, G, ops.ACT_MISH if act == "mish" else ops.ACT_SILU, 1e-5)
+    close(cf(y), yr, what="gn fwd")
+    y.backward(cl(dy))
+    close(cf(xd.grad), xr.grad, tol=1e-4, what="gn dx")
+    close(gd.grad, gr.grad, tol=1e-4, what="gn dgamma")
+    close(bd.grad, br.grad, tol=1e-4, what="gn dbeta")
+    if with_ss:
+        close(ssd.grad, ssr.grad, tol=1e-4, what="gn dss")
+
+
+@pytest.mark.parametrize("name,fn", [("mish", F.mish), ("silu", F.silu), ("gelu", F.gelu), ("relu", F.relu), ("sigmoid", torch.sigmoid)])
+def test_activations(ops, name, fn):
+    x = torch.linspace(-30, 30, 4099)
+    xr = x.double().requires_grad_()
+    yr = fn(xr)
+    yr.sum().backward()
+    xd = x.to(DEV).requires_grad_()
+    y = ops.activation(xd, getattr(ops, "ACT_" + name.upper()))
+    close(y, yr, tol=2e-6, what=name)
+    y.sum().backward()
+    close(xd.grad, xr.grad, tol=1e-5, what=name + " grad")
+
+
+def test_se_gate_residual(ops):
+    g = torch.Generator().manual_seed(8)
+    B, C, S = 2, 32, 6
+    h, res = torch.randn(B, C, S, S, S, generator=g), torch.randn(B, C, S, S, S, generator=g)
+    w1, w2 = torch.randn(C // 16, C, generator=g) * 0.3, torch.randn(C, C // 16, generator=g) * 0.3
+    hr, rr, w1r, w2r = (t.double().requires_grad_() for t in (h, res, w1, w2))
+    yv = torch.sigmoid(F.linear(F.relu(F.linear(hr.mean(dim=(2, 3, 4)), w1r)), w2r))
+    yr = hr * yv[:, :, None, None, None] + rr
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    hd, rd, w1d, w2d = cl(h).requires_grad_(), cl(res).requires_grad_(), w1.to(DEV).requires_grad_(), w2.to(DEV).requires_grad_()
+    y = ops.se_gate_residual(hd, w1d, w2d, rd)
+    close(cf(y), yr, what="se fwd")
+    y.backward(cl(dy))
+    close(cf(hd.grad), hr.grad, tol=1e-4, what="se dh")
+    close(cf(rd.grad), rr.grad, what="se dres")
+    close(w1d.grad, w1r.grad, tol=1e-4, what="se dw1")
+    close(w2d.grad, w2r.grad, tol=1e-4, what="se dw2")
+
+
+def test_chan_layernorm_and_learned_sinu(ops):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 24, 4, 4, 4, generator=g)
+    gn = torch.randn(24, 1, 1, 1, generator=g)
+    xr, gr = x.double().requires_grad_(), gn.double().requires_grad_()
+    var = torch.var(xr, dim=1, unbiased=False, keepdim=True)
+    yr = (xr - xr.mean(dim=1, keepdim=True)) * (var + 1e-5).rsqrt() * gr
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xd, gd = cl(x).requires_grad_(), gn.to(DEV).requires_grad_()
+    y = ops.chan_layernorm(xd, gd)
+    close(cf(y), yr, what="chanln")
+    y.backward(cl(dy))
+    close(cf(xd.grad), xr.grad, tol=1e-4, what="chanln dx")
+    close(gd.grad, gr.grad, tol=1e-4, what="chanln dg")
+
+    t, w = torch.randn(5, generator=g) * 3, torch.randn(8, generator=g)
+    tr, wr = t.double(), w.double().requires_grad_()
+    fr = tr[:, None] * wr[None, :] * 2 * math.pi
+    er = torch.cat((tr[:, None], fr.sin(), fr.cos()), dim=-1)
+    de = torch.randn(er.shape, generator=g)
+    er.backward(de.double())
+    wd = w.to(DEV).requires_grad_()
+    e = ops.learned_sinusoidal(t.to(DEV), wd)
+    close(e, er, tol=2e-5, what="sinu")
+    e.backward(de.to(DEV))
+    close(wd.grad, wr.grad, tol=1e-4, what="sinu dw")
+
+
+def test_shuffles_concat_subvolumes_bit_exact(ops):
+    from oracle import iqt_oracle as O
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 3, 8, 6, 4, generator=g)
+    y = ops.space_to_depth(cl(x))
+    assert torch.equal(cf(y), O._space_to_depth(x))
+    z = torch.randn(2, 16, 4, 3, 2, generator=g)
+    assert torch.equal(cf(ops.depth_to_space(cl(z))), O._pixel_shuffle3d(z))
+    assert torch.equal(cf(ops.depth_to_space(y)), x)                      # exact inverse
+    a, b = torch.randn(2, 5, 3, 3, 3, generator=g), torch.randn(2, 7, 3, 3, 3, generator=g)
+    assert torch.equal(cf(ops.concat_channels(cl(a), cl(b))), torch.cat((a, b), 1))
+    vol = torch.arange(2 * 12 ** 3, dtype=torch.float32).reshape(1, 2, 12, 12, 12)
+    sub = ops.split_volume(cl(vol), 3, 4)
+    assert torch.equal(cf(sub), O.convert_volume_to_subvolume(vol, (27, 2, 4, 4, 4)))
+    assert torch.equal(cf(ops.merge_volume(sub, 3)), vol)
+    halo = ops.split_volume(ops.merge_volume(sub, 3), 3, 4, halo=1)
+    assert torch.equal(cf(halo), O.boundary_pad(cf(sub), 3))
+    # gradients of the data-movement ops (adjoints)
+    v = cl(vol).requires_grad_()
+    hs = ops.split_volume(v, 3, 4, halo=1)
+    wgt = torch.randn(hs.shape, generator=g).to(DEV)
+    (hs * wgt).sum().backward()
+    vr = vol.clone().requires_grad_()
+    (O.boundary_pad(O.convert_volume_to_subvolume(vr, (27, 2, 4, 4, 4)), 3) * cf(wgt)).sum().backward()
+    close(cf(v.grad), vr.grad, what="halo adjoint")
+
+
+def test_trilinear_softmax_bmm(ops):
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 6, 2, 3, 2, generator=g)
+    xr = x.double().requires_grad_()
+    yr = F.interpolate(xr, scale_factor=4, mode='trilinear', align_corners=True)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xd = cl(x).requires_grad_()
+    y = ops.trilinear_upsample(xd, 4)
+    close(cf(y), yr, what="trilinear")
+    y.backward(cl(dy))
+    close(cf(xd.grad), xr.grad, tol=1e-4, what="trilinear adjoint")
+
+    s = torch.randn(7, 33, 5, generator=g)
+    for dim in (-1, 1, 0):
+        sr = s.double().requires_grad_()
+        pr = sr.softmax(dim=dim) * 0.25
+        dp = torch.randn(pr.shape, generator=g)
+        pr.backward(dp.double())
+        sd = s.to(DEV).requires_grad_()
+        p = ops.softmax(sd, dim, scale=0.25)
+        close(p, pr, what=f"softmax dim {dim}")
+        p.backward(dp.to(DEV))
+        close(sd.grad, sr.grad, tol=1e-4, what=f"softmax bwd dim {dim}")
+
+    A, Bm = torch.randn(3, 70, 45, generator=g), torch.randn(3, 45, 66, generator=g)
+    for tA in (False, True):
+        for tB in (False, True):
+            Ar, Br = A.double().requires_grad_(), Bm.double().requires_grad_()
+            Cr = 0.5 * torch.bmm(Ar.transpose(1, 2) if False else Ar, Br)
+            Ain = A.transpose(1, 2).contiguous() if tA else A
+            Bin = Bm.transpose(1, 2).contiguous() if tB else Bm
+            Ad, Bd = Ain.to(DEV).requires_grad_(), Bin.to(DEV).requires_grad_()
+            C = ops.bmm(Ad, Bd, tA, tB, 0.5)
+            close(C, Cr, what=f"bmm {tA}{tB}")
+            dC = torch.randn(Cr.shape, generator=g)
+            Cr.backward(dC.double())
+            C.backward(dC.to(DEV))
+            close(Ad.grad, Ar.grad.transpose(1, 2) if tA else Ar.grad, tol=1e-4, what=f"bmm dA {tA}{tB}")
+            close(Bd.grad, Br.grad.transpose(1, 2) if tB else Br.grad, tol=1e-4, what=f"bmm dB {tA}{tB}")
+
+
+def test_diffusion_steps_loss_adam(ops):
+    from oracle import iqt_oracle as O
+    g = torch.Generator().manual_seed(13)
+    B, n = 3, 4 * 5 * 6
+    x0, noise, pred = (torch.randn(B, 1, 4, 5, 6, generator=g) for _ in range(3))
+    t, tn = torch.tensor([0.9, 0.5, 0.1]), torch.tensor([0.8, 0.25, 0.0])
+    xt, _, alpha, sigma = O.q_sample(x0, t, noise)
+    close(ops.q_sample(x0.to(DEV), noise.to(DEV), alpha.flatten().to(DEV), sigma.flatten().to(DEV)), xt, what="q_sample")
+    from diffusioniqt_amd.imagen_pytorch3D import GaussianDiffusionContinuousTimes
+    sched = GaussianDiffusionContinuousTimes(noise_schedule='cosine', timesteps=10)
+    ca, cb, cn = sched.posterior_coefficients(t, tn)
+    lo = -0.72
+    x_next, x0c = ops.ddpm_step(xt.to(DEV), pred.to(DEV), noise.to(DEV), ca.to(DEV), cb.to(DEV), cn.to(DEV), lo, 0.0, 0)
+    xs = pred.clamp(min=lo)
+    mean, _, logvar = O.q_posterior(xs, xt, t, tn)
+    nz = (1 - (tn == 0).float()).reshape(B, 1, 1, 1, 1)
+    close(x0c, xs, tol=1e-7, what="ddpm x0")
+    close(x_next, mean + nz * (0.5 * logvar).exp() * noise, what="ddpm step")
+
+    p = torch.randn(B, 1, 4, 5, 6, generator=g)
+    pr = p.clone().requires_grad_()
+    lr_ = ((pr.clamp(min=lo) - x0) ** 2).flatten(1).mean(1).mean()
+    lr_.backward()
+    pd = p.to(DEV).requires_grad_()
+    pin = pd * 1.0
+    loss, pc = ops.mse_clamp(pin, x0.to(DEV), lo=lo, do_clamp=True)
+    close(loss, lr_, what="mse loss")
+    close(pc, p.clamp(min=lo), tol=1e-7, what="clamped pred")
+    (loss * 0.5).backward()
+    close(pd.grad, 0.5 * pr.grad, what="mse grad")
+
+    w, gr = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    wr = w.clone().requires_grad_()
+    opt = torch.optim.Adam([wr], lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    wd, gd = w.to(DEV), gr.to(DEV)
+    m, v = torch.zeros_like(wd), torch.zeros_like(wd)
+    for step in range(1, 4):
+        wr.grad = gr.clone() * step
+        opt.step()
+        gd2 = gd * step
+        ops.adam_step(wd, gd2, m, v, 1e-2, 0.9, 0.99, 1e-8, 0.0, step, zero_grad=True)
+        assert float(gd2.abs().max()) == 0.0
+    close(wd, wr, tol=1e-5, what="adam")
+    e = torch.randn(1000, generator=g)
+    ed = e.to(DEV)
+    ops.ema_lerp(ed, wd, 0.25)
+    close(ed, e + (wr.detach() - e) * 0.25, tol=1e-5, what="ema")
+
+
+def test_ops_refuse_cpu_tensors(ops):
+    with pytest.raises(RuntimeError):
+        ops.mish(torch.randn(4))

@@ -7,6 +7,11 @@ non-zero return code.
 """
 import ctypes
 import os
+
+# torch must load ITS bundled HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) before this
+# library is dlopen'ed, so that both share one runtime; the other order gives two runtimes in one process
+# ("no ROCm-capable device is detected" on the second).
+import torch  # noqa: F401
 from ctypes import c_int, c_float, c_size_t, c_void_p, c_longlong, c_char_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -54,7 +59,7 @@ PROTOTYPES = {
     "diqt_q_sample": (I, [P, P, P, P, P, I, Z, P]),
     "diqt_ddpm_step": (I, [P, P, P, P, P, P, F, F, I, P, P, I, Z, P]),
     "diqt_axpby3": (I, [P, P, P, P, P, P, F, F, I, P, I, Z, P]),
-    "diqt_mse_clamp_fwd": (I, [P, P, P, F, I, P, P, I, Z, P]),
+    "diqt_mse_clamp_fwd": (I, [P, P, P, P, F, I, P, P, I, Z, P]),
     "diqt_mse_clamp_bwd": (I, [P, P, P, F, I, F, P, I, Z, P]),
     "diqt_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, F, F, I, P]),
     "diqt_ema_lerp": (I, [P, P, Z, F, P]),

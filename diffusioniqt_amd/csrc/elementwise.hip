@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void mse_clamp_fwd_kernel(float* __restrict__ pred, const float* __restrict__ target,
+__global__ __launch_bounds__(256) void mse_clamp_fwd_kernel(const float* pred, float* pred_out, const float* __restrict__ target,
                                                             const float* __restrict__ w, float lo, int do_clamp,
                                                             float* __restrict__ partials, int B, size_t per) {
     __shared__ float sh[4];
@@ -643,7 +643,8 @@ __global__ __launch_bounds__(256) void mse_clamp_fwd_kernel(float* __restrict__ 
     float s = 0.f;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         float p = pred[i];
-        if (do_clamp) { p = fmaxf(p, lo); pred[i] = p; }
+        if (do_clamp) p = fmaxf(p, lo);
+        if (pred_out) pred_out[i] = p;
         const float d = p - target[i];
         s += (w ? w[i / per] : 1.f) * d * d;
     }
@@ -1056,12 +1057,12 @@ extern "C" int diqt_ddpm_step(const float* x_t, const float* pred, const float* 
                        lo, hi, clamp_mode, x_next, x0_out, per);
     return check_launch("ddpm_step");
 }
-extern "C" int diqt_mse_clamp_fwd(float* pred, const float* target, const float* w, float lo, int do_clamp,
-                                  float* partials, float* loss_out, int B, size_t per, void* stream) {
+extern "C" int diqt_mse_clamp_fwd(const float* pred, float* pred_clamped, const float* target, const float* w, float lo,
+                                  int do_clamp, float* partials, float* loss_out, int B, size_t per, void* stream) {
     DIQT_REQUIRE(pred && target && partials && loss_out, DIQT_E_ALIGN, "mse_clamp_fwd: null pointer");
     DIQT_REQUIRE(B > 0 && per > 0, DIQT_E_SHAPE, "mse_clamp_fwd: bad shape");
     const unsigned nblk = grid_for((size_t)B * per, 256, 1024);
-    hipLaunchKernelGGL(mse_clamp_fwd_kernel, dim3(nblk), dim3(256), 0, STREAM, pred, target, w, lo, do_clamp, partials, B, per);
+    hipLaunchKernelGGL(mse_clamp_fwd_kernel, dim3(nblk), dim3(256), 0, STREAM, pred, pred_clamped, target, w, lo, do_clamp, partials, B, per);
     int rc = check_launch("mse_clamp_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, STREAM, partials, (int)nblk, 1.f / ((float)B * (float)per),

@@ -697,24 +697,20 @@ class _MseClampFn(Function):
         per = pred.numel() // B
         partials = torch.empty(1024, dtype=torch.float32, device=pred.device)
         loss = torch.empty((), dtype=torch.float32, device=pred.device)
-        _lib.call("diqt_mse_clamp_fwd", pred, target, weight, float(lo), int(do_clamp), partials, loss, B, per, _stream())
-        ctx.mark_dirty(pred)
-        ctx.set_materialize_grads(False)
-        ctx.save_for_backward(pred, target, weight)
+        clamped = torch.empty_like(pred)
+        _lib.call("diqt_mse_clamp_fwd", pred, clamped, target, weight, float(lo), int(do_clamp), partials, loss, B, per,
+                  _stream())
+        ctx.mark_non_differentiable(clamped)
+        ctx.save_for_backward(clamped, target, weight)
         ctx.cfg = (float(lo), int(do_clamp), B, per)
-        return loss, pred
+        return loss, clamped
 
     @staticmethod
-    def backward(ctx, dloss, dpred_unused):
-        pred, target, weight = ctx.saved_tensors
+    def backward(ctx, dloss, _dclamped):
+        clamped, target, weight = ctx.saved_tensors
         lo, do_clamp, B, per = ctx.cfg
-        if dloss is None:
-            return None, None, None, None, None
-        dpred = torch.empty_like(pred)
-        # dloss is a device scalar; fold it in with a tiny host read-free path: scale afterwards
-        _lib.call("diqt_mse_clamp_bwd", pred, target, weight, lo, do_clamp, 1.0, dpred, B, per, _stream())
-        if dpred_unused is not None:
-            raise RuntimeError("mse_clamp: gradient through the returned clamped prediction is not supported")
+        dpred = torch.empty_like(clamped)
+        _lib.call("diqt_mse_clamp_bwd", clamped, target, weight, lo, do_clamp, 1.0, dpred, B, per, _stream())
         return _ScaleByScalar.apply_raw(dpred, dloss), None, None, None, None
 
 
@@ -729,9 +725,10 @@ class _ScaleByScalar:
 
 
 def mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=None):
-    """mean((clamp_min_(pred, lo) - target)^2 * weight[b]); returns (loss, pred) — pred clamped IN PLACE like
-    the reference (imagen_pytorch3D.py:2361-2364)."""
-    return _MseClampFn.apply(pred, target.contiguous(), weight, lo, do_clamp)
+    """mean((clamp_min(pred, lo) - target)^2 * weight[b]); returns (loss, clamped_pred).  The reference clamps
+    ``pred`` in place and returns it (imagen_pytorch3D.py:2361-2364); here the clamped values come back as a
+    separate (non-differentiable) tensor — same numbers, no aliasing of an autograd view."""
+    return _MseClampFn.apply(pred.contiguous(), target.contiguous(), weight, lo, do_clamp)
 
 
 # --------------------------------------------------------------------------------------------

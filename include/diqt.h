@@ -205,10 +205,11 @@ int diqt_axpby3(const float* a, const float* b_, const float* c_, const float* c
                 const float* c2, float lo, float hi, int clamp_mode, float* out,
                 int B, size_t per_batch, void* stream);
 /* loss = mean_b mean_i (clamp_min(pred,lo) - target)^2, per-batch weights w[b] (NULL = 1)
- * — p_losses imagen_pytorch3D.py:2361-2364; writes clamped pred in place like the reference.
+ * — p_losses imagen_pytorch3D.py:2361-2364; the clamped prediction the reference returns is written to
+ * pred_clamped (may alias pred for the reference's in-place form, or be NULL).
  * loss_out: single float (atomic-free two-stage reduce through `partials`, >= 1024 floats).          */
-int diqt_mse_clamp_fwd(float* pred, const float* target, const float* w, float lo, int do_clamp,
-                       float* partials, float* loss_out, int B, size_t per_batch, void* stream);
+int diqt_mse_clamp_fwd(const float* pred, float* pred_clamped, const float* target, const float* w, float lo,
+                       int do_clamp, float* partials, float* loss_out, int B, size_t per_batch, void* stream);
 /* dpred = gscale * 2*(pred-target)*w[b]/(B*per_batch), zero where pred was clamped (pred <= lo)      */
 int diqt_mse_clamp_bwd(const float* pred_clamped, const float* target, const float* w, float lo,
                        int do_clamp, float gscale, float* dpred, int B, size_t per_batch, void* stream);

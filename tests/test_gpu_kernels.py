@@ -301,8 +301,7 @@ def test_diffusion_steps_loss_adam(ops):
     lr_ = ((pr.clamp(min=lo) - x0) ** 2).flatten(1).mean(1).mean()
     lr_.backward()
     pd = p.to(DEV).requires_grad_()
-    pin = pd * 1.0
-    loss, pc = ops.mse_clamp(pin, x0.to(DEV), lo=lo, do_clamp=True)
+    loss, pc = ops.mse_clamp(pd, x0.to(DEV), lo=lo, do_clamp=True)
     close(loss, lr_, what="mse loss")
     close(pc, p.clamp(min=lo), tol=1e-7, what="clamped pred")
     (loss * 0.5).backward()

@@ -1,0 +1,180 @@
+"""Patch-batch data parallelism for the IQT trainer: one process per GPU, RCCL (backend "nccl" on ROCm) over
+xGMI, gradients all-reduced in contiguous buckets of ONE flat fp32 arena, launched from autograd hooks in
+reverse-layer order so the collectives overlap the rest of backward.
+
+Replaces what the reference gets implicitly from ``accelerate.Accelerator`` -> torch DDP -> NCCL
+(trainer.py:296-301, 476-497, 1118-1123): ``split_batches=True`` sharding,
+``find_unused_parameters=True`` semantics (``mid_block`` / ``norm_cond`` never receive gradients),
+``no_sync`` on non-boundary micro-steps, rank-0-only EMA / checkpoints.
+
+xGMI is point-to-point (7 links per GPU), so few, large buckets are used: the 54 MB of config-2
+gradients go out as ~25 MB buckets (first bucket 1 MB so the first collective starts early).
+"""
+import os
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_from_env(device_type=None):
+    """Initialises torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* when WORLD_SIZE > 1.
+    Returns (world_size, rank, device)."""
+    world, rank, local = env_world()
+    use_cuda = torch.cuda.is_available() if device_type is None else device_type == "cuda"
+    device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kwargs = {}
+        if use_cuda:
+            kwargs["device_id"] = device
+        dist.init_process_group(backend="nccl" if use_cuda else "gloo", rank=rank, world_size=world, **kwargs)
+    return world, rank, device
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()
+
+
+class FlatArena:
+    """All parameters of a module as views into one flat fp32 buffer (+ a flat gradient buffer whose slices are
+    installed as ``p.grad``), so the optimiser is one kernel launch and a gradient bucket is a contiguous range."""
+
+    def __init__(self, params: List[torch.nn.Parameter], with_grad=True):
+        params = [p for p in params]
+        assert len(params) > 0
+        dev = params[0].device
+        self.params = params
+        self.offsets, off = [], 0
+        for p in params:
+            assert p.device == dev and p.dtype == torch.float32
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev) if with_grad else None
+        with torch.no_grad():
+            for p, o in zip(params, self.offsets):
+                self.flat[o:o + p.numel()].view_as(p).copy_(p.data)
+                p.data = self.flat[o:o + p.numel()].view_as(p)
+                if with_grad and p.requires_grad:
+                    p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def intact(self):
+        """False if something (e.g. ``module.to()``) re-allocated a parameter and broke the views."""
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+
+    def reinstall_grads(self):
+        for p, o in zip(self.params, self.offsets):
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o):
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+
+class BucketedGradReducer:
+    """All-reduce(mean) of an arena's gradient buffer in contiguous buckets, overlapped with backward.
+
+    Buckets are cut in REVERSE parameter order (the order backward produces gradients).  A bucket is launched
+    (async) from the post-accumulate-grad hook of the last of its *used* parameters; the set of used parameters
+    is learned in the first synchronised backward (every rank runs the same graph, so the sets agree) — the
+    equivalent of DDP's ``find_unused_parameters=True``.  ``sync=False`` (gradient-accumulation micro-steps)
+    skips communication like DDP's ``no_sync``.
+    """
+
+    def __init__(self, arena: FlatArena, bucket_cap_mb=25.0, first_bucket_mb=1.0, process_group=None):
+        self.arena, self.pg = arena, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.sync = True
+        self.used = None                    # learned set of parameter indices that receive gradients
+        self._seen, self._pending, self._handles = set(), {}, []
+        n = len(arena.params)
+        ends = [arena.offsets[i + 1] if i + 1 < n else arena.numel for i in range(n)]
+        self.buckets, cap, cur, cur_hi = [], int(first_bucket_mb * (1 << 18)), [], arena.numel
+        for i in reversed(range(n)):
+            cur.append(i)
+            if cur_hi - arena.offsets[i] >= cap or i == 0:
+                self.buckets.append((arena.offsets[i], cur_hi, tuple(cur)))
+                cur, cur_hi, cap = [], arena.offsets[i], int(bucket_cap_mb * (1 << 18))
+        self.bucket_of = {i: b for b, (_, _, idx) in enumerate(self.buckets) for i in idx}
+        self._launched = set()
+        for i, p in enumerate(arena.params):
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_param):
+            if self.world == 1 or not self.sync:
+                return
+            self._seen.add(i)
+            if self.used is None:
+                return
+            b = self.bucket_of[i]
+            left = self._pending.get(b)
+            if left is None:
+                left = set(j for j in self.buckets[b][2] if j in self.used)
+                self._pending[b] = left
+            left.discard(i)
+            if not left and b not in self._launched:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        lo, hi, _ = self.buckets[b]
+        buf = self.arena.grad[lo:hi]
+        if buf.is_cuda:
+            h = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+        else:
+            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._launched.add(b)
+        self._handles.append((h, buf))
+
+    def prepare_backward(self, sync=True):
+        self.sync = sync
+        self._seen, self._pending, self._handles, self._launched = set(), {}, [], set()
+
+    def finalize_backward(self):
+        """Call after ``loss.backward()`` of a synchronised micro-step: launches whatever is left and waits."""
+        if self.world == 1 or not self.sync:
+            return
+        for b in range(len(self.buckets)):
+            if b not in self._launched:
+                self._launch(b)
+        for h, buf in self._handles:
+            h.wait()
+            if not buf.is_cuda:
+                buf.div_(self.world)
+        if self.used is None:
+            self.used = set(self._seen)
+        self._handles = []
+
+
+def broadcast_arena(arena: FlatArena, src=0, process_group=None):
+    """Rank-0 parameters to everyone (what DDP does at construction, trainer.py:487)."""
+    if world_size() > 1:
+        dist.broadcast(arena.flat, src=src, group=process_group)
+
+
+def shard_batch(t, world, rank_):
+    """``split_batches=True`` (trainer.py:297): every rank takes its contiguous 1/world slice of a global batch."""
+    if world == 1 or not torch.is_tensor(t):
+        return t
+    b = t.shape[0]
+    assert b % world == 0, f"global batch {b} is not divisible by world size {world}"
+    per = b // world
+    return t[rank_ * per:(rank_ + 1) * per]

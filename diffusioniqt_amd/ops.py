@@ -36,6 +36,27 @@ def _chk(*ts):
             raise RuntimeError("diffusioniqt_amd ops need contiguous tensors")
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the dominant kernel (conv3d fwd/bwd-data launches) for bench.py's roofline:
+    events are recorded on the stream the kernel is launched on (torch's current stream)."""
+    def __init__(self):
+        self.records = []      # (start_event, end_event, flops, tag)
+        self.enabled = False
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for s, e, flops, tag in self.records:
+            ms, fl, n = out.get(tag, (0.0, 0.0, 0))
+            out[tag] = (ms + s.elapsed_time(e), fl + flops, n + 1)
+        return out
+
+
+TIMER = KernelTimer()
+
 _WS = {}
 
 
@@ -86,7 +107,13 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad):
     pd, ph, pw = pad
     Do, Ho, Wo = D + 2 * pd - kd + 1, H + 2 * ph - kh + 1, W + 2 * pw - kw + 1
     y = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=x5.device)
+    if TIMER.enabled:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
     _lib.call("diqt_conv3d_fwd", x5, packed, bias, residual, y, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, _stream())
+    if TIMER.enabled:
+        e.record()
+        TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_kernel"))
     return y
 
 
@@ -119,8 +146,15 @@ class _Conv3dFn(Function):
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             n = _lib.query("diqt_conv3d_bwd_weight_workspace_bytes", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw)
             ws = _workspace(n, x.device)
+            if TIMER.enabled:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
             _lib.call("diqt_conv3d_bwd_weight", x, dy, dw, db, ws, n, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw,
                       _stream())
+            if TIMER.enabled:
+                e.record()
+                Do, Ho, Wo = dy.shape[1:4]
+                TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_bwd_weight_kernel"))
         return dx, dw, db, None, (dy if ctx.has_res else None)
 
 

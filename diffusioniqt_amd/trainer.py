@@ -1,0 +1,758 @@
+"""MI355X-native counterpart of the reference's ``trainer.ImagenTrainer`` (trainer.py:236-1128).
+
+Same constructor surface, ``add_*_dataset`` / ``train_step`` / ``valid_step`` / ``update`` / ``sample`` /
+``save`` / ``load`` methods, return conventions and checkpoint dictionary keys, without ``accelerate``:
+data parallelism is ``distributed.BucketedGradReducer`` (RCCL over xGMI), the optimiser is ONE fused
+Adam(+zero_grad) kernel over a flat arena and the EMA is one lerp kernel.
+
+Semantics kept on purpose (SURVEY.md Appendix A "Trainer facts", pinned by tests/golden/trainerA_trace.npz):
+``train_step`` is one pass over the dataloader; inside ``forward`` every chunk calls ``update()``; Adam only
+steps on every ``gradient_accumulation_steps``-th micro-step of a global counter (gradients keep accumulating
+in between), while the EMA update and ``steps`` advance on every micro-step; ``sample`` uses the EMA weights.
+"""
+import copy
+import os
+from contextlib import contextmanager, nullcontext
+from functools import partial, wraps
+from math import ceil
+from collections.abc import Iterable
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.utils.data import DataLoader, random_split
+
+from . import ops
+from . import distributed as D
+from .imagen_pytorch3D import Imagen, NullUnet
+from .utils_mine import convertVolume2subVolume, merge_sub_volumes
+from .metrics import SSIM, PSNR
+from . import __version__
+
+device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+
+def exists(val):
+    return val is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+def cast_tuple(val, length=1):
+    if isinstance(val, list):
+        val = tuple(val)
+    return val if isinstance(val, tuple) else ((val,) * length)
+
+
+def cycle(dl):
+    while True:
+        for data in dl:
+            yield data
+
+
+def num_to_groups(num, divisor):
+    groups, remainder = num // divisor, num % divisor
+    arr = [divisor] * groups
+    if remainder > 0:
+        arr.append(remainder)
+    return arr
+
+
+def groupby_prefix_and_trim(prefix, d):
+    with_prefix = {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+    without = {k: v for k, v in d.items() if not k.startswith(prefix)}
+    return with_prefix, without
+
+
+def eval_decorator(fn):
+    def inner(model, *args, **kwargs):
+        was_training = model.training
+        model.eval()
+        out = fn(model, *args, **kwargs)
+        model.train(was_training)
+        return out
+    return inner
+
+
+def cast_torch_tensor(fn, cast_fp16=False):
+    """trainer.py:123-147: numpy -> torch, move tensors to the trainer's device."""
+    @wraps(fn)
+    def inner(model, *args, **kwargs):
+        dev = kwargs.pop('_device', model.device)
+        cast_device = kwargs.pop('_cast_device', True)
+        keys = list(kwargs.keys())
+        all_args = (*args, *kwargs.values())
+        split = len(all_args) - len(keys)
+        all_args = tuple(torch.from_numpy(t) if isinstance(t, np.ndarray) else t for t in all_args)
+        if cast_device:
+            all_args = tuple(t.to(dev) if isinstance(t, torch.Tensor) else t for t in all_args)
+        args, kw_values = all_args[:split], all_args[split:]
+        return fn(model, *args, **dict(zip(keys, kw_values)))
+    return inner
+
+
+def split(t, split_size=None):
+    if not exists(split_size):
+        return t
+    if isinstance(t, torch.Tensor):
+        return t.split(split_size, dim=0)
+    if isinstance(t, Iterable):
+        return [t[i * split_size:(i + 1) * split_size] for i in range(ceil(len(t) / split_size))]
+    return TypeError
+
+
+def split_args_and_kwargs(*args, split_size=None, **kwargs):
+    """trainer.py:176-197: gradient-accumulation chunks, each with its share of the batch."""
+    all_args = (*args, *kwargs.values())
+    first_tensor = next((t for t in all_args if isinstance(t, torch.Tensor)), None)
+    assert exists(first_tensor)
+    batch_size = len(first_tensor)
+    split_size = default(split_size, batch_size)
+    num_chunks = ceil(batch_size / split_size)
+    keys = list(kwargs.keys())
+    split_index = len(all_args) - len(keys)
+    split_all = [split(a, split_size=split_size) if exists(a) and isinstance(a, (torch.Tensor, Iterable)) and not isinstance(a, str)
+                 else ((a,) * num_chunks) for a in all_args]
+    for chunk_size, *chunked in zip(num_to_groups(batch_size, split_size), *split_all):
+        yield chunk_size / batch_size, (tuple(chunked[:split_index]), dict(zip(keys, chunked[split_index:])))
+
+
+def imagen_sample_in_chunks(fn):
+    @wraps(fn)
+    def inner(self, *args, max_batch_size=None, **kwargs):
+        if not exists(max_batch_size):
+            return fn(self, *args, **kwargs)
+        if self.imagen.unconditional:
+            batch_sizes = num_to_groups(kwargs.get('batch_size'), max_batch_size)
+            outputs = [fn(self, *args, **{**kwargs, 'batch_size': b}) for b in batch_sizes]
+        else:
+            outputs = [fn(self, *ca, **ck) for _, (ca, ck) in split_args_and_kwargs(*args, split_size=max_batch_size, **kwargs)]
+        if isinstance(outputs[0], torch.Tensor):
+            return torch.cat(outputs, dim=0)
+        return list(map(lambda t: torch.cat(t, dim=0), list(zip(*outputs))))
+    return inner
+
+
+def restore_parts(state_dict_target, state_dict_from):
+    """trainer.py:222-233: partial load on shape mismatch."""
+    for name, param in state_dict_from.items():
+        if name not in state_dict_target:
+            continue
+        if param.size() == state_dict_target[name].size():
+            state_dict_target[name].copy_(param)
+        else:
+            print(f"layer {name}({param.size()} different than target: {state_dict_target[name].size()}")
+    return state_dict_target
+
+
+# ----------------------------------------------------------------------------------------------
+# fused Adam over a flat arena (torch.optim.Adam semantics, trainer.py:352-359)
+# ----------------------------------------------------------------------------------------------
+class FusedAdam:
+    """Adam(lr, betas, eps, weight_decay=0) whose state lives in flat fp32 arenas.  The arena is created lazily
+    (after the model sits on its device); until then / on CPU the per-parameter state mirrors torch's so that
+    ``state_dict()`` is interchangeable with ``torch.optim.Adam``'s."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params]
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False,
+                                  maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                                  params=list(range(len(self.params))))]
+        self.arena = None
+        self.exp_avg = self.exp_avg_sq = None
+        self.step_count = 0
+        self._pending_state = None
+
+    def attach(self, arena: D.FlatArena):
+        self.arena = arena
+        self.exp_avg = torch.zeros_like(arena.flat)
+        self.exp_avg_sq = torch.zeros_like(arena.flat)
+        if self._pending_state is not None:
+            self._load_into_arena(self._pending_state)
+            self._pending_state = None
+
+    def step(self):
+        assert self.arena is not None, 'optimizer used before the trainer prepared the unet'
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0],
+                      g['betas'][1], g['eps'], g['weight_decay'], self.step_count, zero_grad=True)
+
+    def zero_grad(self, set_to_none=False):
+        if self.arena is not None:
+            self.arena.grad.zero_()
+
+    def state_dict(self):
+        state = {}
+        if self.arena is not None and self.step_count > 0:
+            for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+                n = p.numel()
+                state[i] = dict(step=torch.tensor(float(self.step_count)),
+                                exp_avg=self.exp_avg[o:o + n].view_as(p).clone(),
+                                exp_avg_sq=self.exp_avg_sq[o:o + n].view_as(p).clone())
+        groups = [{k: v for k, v in g.items()} for g in self.param_groups]
+        return dict(state=state, param_groups=groups)
+
+    def _load_into_arena(self, sd):
+        for i, st in sd.get('state', {}).items():
+            i = int(i)
+            p, o = self.arena.params[i], self.arena.offsets[i]
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            self.step_count = max(self.step_count, int(float(st['step'])))
+
+    def load_state_dict(self, sd):
+        for k in ('lr', 'betas', 'eps', 'weight_decay'):
+            if sd.get('param_groups'):
+                self.param_groups[0][k] = sd['param_groups'][0].get(k, self.param_groups[0][k])
+        if self.arena is None:
+            self._pending_state = sd
+        else:
+            self._load_into_arena(sd)
+
+
+class _NullScaler:
+    """fp32 path: the reference's GradScaler(enabled=False) (trainer.py:364) — empty state."""
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, sd):
+        pass
+
+
+class EMA(nn.Module):
+    """ema_pytorch==0.1.4 semantics restated from its published algorithm (the package is absent here: parity
+    unpinned): ``update_every=10``, copy until ``update_after_step=100``, then
+    decay = clamp(1 - (1 + epoch/inv_gamma)^-power, min_value, beta) with beta 0.9999, inv_gamma 1, power 2/3.
+    The lerp is one HIP kernel over the flat arenas when the model is on the GPU."""
+
+    def __init__(self, model, beta=0.9999, update_after_step=100, update_every=10, inv_gamma=1.0, power=2 / 3,
+                 min_value=0.0, **_):
+        super().__init__()
+        self.online_model = model
+        self.ema_model = copy.deepcopy(model)
+        self.ema_model.requires_grad_(False)
+        self.beta, self.update_after_step, self.update_every = beta, update_after_step, update_every
+        self.inv_gamma, self.power, self.min_value = inv_gamma, power, min_value
+        self.register_buffer('initted', torch.tensor([False]))
+        self.register_buffer('step', torch.tensor([0]))
+        self._arena = None
+
+    def restore_ema_model_device(self):
+        self.ema_model.to(self.initted.device)
+
+    def get_current_decay(self):
+        epoch = max(self.step.item() - self.update_after_step - 1, 0.)
+        value = 1 - (1 + epoch / self.inv_gamma) ** -self.power
+        return 0. if epoch <= 0 else min(max(value, self.min_value), self.beta)
+
+    def _flat(self):
+        """(ema_flat, online_flat): both models as flat arenas on the online model's device."""
+        on = getattr(self.online_model, '_diqt_arena', None)
+        if on is None or not on.intact():
+            on = D.FlatArena(list(self.online_model.parameters()), with_grad=False)
+            self.online_model._diqt_arena = on
+        if self._arena is None or not self._arena.intact() or self._arena.flat.device != on.flat.device:
+            self.ema_model.to(on.flat.device)
+            self._arena = D.FlatArena(list(self.ema_model.parameters()), with_grad=False)
+        return self._arena.flat, on.flat
+
+    def update(self):
+        step = self.step.item()
+        self.step += 1
+        if (step % self.update_every) != 0:
+            return
+        ema_flat, online_flat = self._flat()
+        if step <= self.update_after_step or not self.initted.item():
+            ema_flat.copy_(online_flat)                      # plain copy (no arithmetic)
+            ops.bump_weight_epoch()
+            self.initted.data.copy_(torch.tensor([True]))
+            if step <= self.update_after_step:
+                return
+        ops.ema_lerp(ema_flat, online_flat, 1. - self.get_current_decay())     # HIP kernel; raises on CPU tensors
+
+    def forward(self, *args, **kwargs):
+        return self.ema_model(*args, **kwargs)
+
+
+class _ReplicaUnet(nn.Module):
+    """What ``accelerator.prepare(unet)`` returned in the reference (a DDP wrapper exposing ``.module``)."""
+
+    def __init__(self, module, reducer):
+        super().__init__()
+        self.module = module
+        self.reducer = reducer
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+# ----------------------------------------------------------------------------------------------
+class ImagenTrainer(nn.Module):
+    locked = False
+
+    def __init__(self, configs, imagen=None, imagen_checkpoint_path=None, use_ema=True, lr=1e-4, eps=1e-8, beta1=0.9,
+                 beta2=0.99, max_grad_norm=None, group_wd_params=True, warmup_steps=None, cosine_decay_max_steps=None,
+                 only_train_unet_number=None, fp16=False, precision=None, split_batches=True,
+                 dl_tuple_output_keywords_names=('images', 'lowres_img', 'text_embeds', 'text_masks', 'cond_images'),
+                 verbose=True, split_valid_fraction=0.025, split_valid_from_train=False, split_random_seed=42,
+                 checkpoint_path=None, checkpoint_every=None, checkpoint_fs=None, fs_kwargs: dict = None,
+                 max_checkpoints_keep=20, gradient_accumulation_steps=4, **kwargs):
+        super().__init__()
+        assert not ImagenTrainer.locked, 'ImagenTrainer can only be initialized once per process - for the sake of distributed training, you will now have to create a separate script to train each unet (or a script that accepts unet number as an argument)'
+        assert exists(imagen) ^ exists(imagen_checkpoint_path), 'either imagen instance is passed into the trainer, or a checkpoint path that contains the imagen config'
+        assert exists(imagen), 'imagen_checkpoint_path (CLI configs) is dead code in the reference and not built'
+        assert not fp16 and precision in (None, 'no'), 'the MI355X path computes in fp32 (BASELINE: fp32 tolerance)'
+        assert max_grad_norm is None and warmup_steps is None and cosine_decay_max_steps is None, \
+            'grad clipping / LR schedules are off in the reference scripts (trainer.py:245-252) and not built'
+        self.configs = configs
+        ema_kwargs, kwargs = groupby_prefix_and_trim('ema_', kwargs)
+        _, kwargs = groupby_prefix_and_trim('accelerate_', kwargs)
+        from .elucidated_imagen import ElucidatedImagen
+        assert isinstance(imagen, (Imagen, ElucidatedImagen))
+        self.is_elucidated = isinstance(imagen, ElucidatedImagen)
+
+        # one process per GPU; RANK/LOCAL_RANK/WORLD_SIZE from the launcher (torchrun)
+        self.world_size, self.rank, self._device = D.init_from_env()
+        self.split_batches = split_batches
+        self.gradient_accumulation_steps = gradient_accumulation_steps
+        self._micro_step = 0
+        ImagenTrainer.locked = self.is_distributed
+
+        self.imagen = imagen
+        self.num_unets = len(self.imagen.unets)
+        self.use_ema = use_ema and self.is_main
+        self.ema_unets = nn.ModuleList([])
+        self.ema_unet_being_trained_index = -1
+        self.train_dl_iter = self.train_dl = self.valid_dl_iter = self.valid_dl = None
+        self.dl_tuple_output_keywords_names = dl_tuple_output_keywords_names
+        self.split_valid_from_train = split_valid_from_train
+        assert 0 <= split_valid_fraction <= 1, 'split valid fraction must be between 0 and 1'
+        self.split_valid_fraction, self.split_random_seed = split_valid_fraction, split_random_seed
+
+        lr, eps = cast_tuple(lr, self.num_unets), cast_tuple(eps, self.num_unets)
+        for ind, (unet, unet_lr, unet_eps) in enumerate(zip(self.imagen.unets, lr, eps)):
+            setattr(self, f'optim{ind}', FusedAdam(unet.parameters(), lr=unet_lr, eps=unet_eps, betas=(beta1, beta2), **kwargs))
+            if self.use_ema:
+                self.ema_unets.append(EMA(unet, **ema_kwargs))
+            setattr(self, f'scaler{ind}', _NullScaler())
+            setattr(self, f'scheduler{ind}', None)
+            setattr(self, f'warmup{ind}', None)
+        self.max_grad_norm = max_grad_norm
+        self.register_buffer('steps', torch.tensor([0] * self.num_unets))
+        self.verbose = verbose
+        self.imagen.to(self.device)
+        self.to(self.device)
+
+        assert not (exists(checkpoint_path) ^ exists(checkpoint_every))
+        self.checkpoint_path, self.checkpoint_every, self.max_checkpoints_keep = checkpoint_path, checkpoint_every, max_checkpoints_keep
+        self.can_checkpoint = self.is_main
+        if exists(checkpoint_path) and self.can_checkpoint:
+            os.makedirs(checkpoint_path, exist_ok=True)
+            self.load_from_checkpoint_folder()
+        self.only_train_unet_number = only_train_unet_number
+        self.prepared = False
+        self.valid_images_save = False
+
+    # ---- properties ---------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def is_distributed(self):
+        return self.world_size > 1
+
+    @property
+    def is_main(self):
+        return self.rank == 0
+
+    @property
+    def is_local_main(self):
+        return D.env_world()[2] == 0
+
+    @property
+    def unwrapped_unet(self):
+        return self.unet_being_trained.module
+
+    def print(self, msg):
+        if self.is_main and self.verbose:
+            print(msg)
+
+    def get_lr(self, unet_number):
+        self.validate_unet_number(unet_number)
+        return getattr(self, f'optim{unet_number - 1}').param_groups[0]['lr']
+
+    # ---- preparing the unet being trained (the reference's accelerator.prepare / DDP wrap) ----------
+    def prepare(self):
+        assert not self.prepared, 'The trainer is allready prepared'
+        self.validate_and_set_unet_being_trained(self.only_train_unet_number)
+        self.prepared = True
+
+    def validate_and_set_unet_being_trained(self, unet_number=None):
+        if exists(unet_number):
+            self.validate_unet_number(unet_number)
+        assert not exists(self.only_train_unet_number) or self.only_train_unet_number == unet_number, \
+            'you cannot only train on one unet at a time. you will need to save the trainer into a checkpoint, and resume training on a new unet'
+        self.only_train_unet_number = unet_number
+        self.imagen.only_train_unet_number = unet_number
+        if not exists(unet_number):
+            return
+        self.wrap_unet(unet_number)
+
+    def wrap_unet(self, unet_number):
+        if hasattr(self, 'one_unet_wrapped'):
+            return
+        unet = self.imagen.get_unet(unet_number)
+        optimizer = getattr(self, f'optim{unet_number - 1}')
+        arena = D.FlatArena(list(unet.parameters()))
+        unet._diqt_arena = arena
+        optimizer.attach(arena)
+        D.broadcast_arena(arena)                         # rank-0 weights to every replica (trainer.py:487)
+        reducer = D.BucketedGradReducer(arena) if self.is_distributed else None
+        self._arena = arena
+        self.unet_being_trained = _ReplicaUnet(unet, reducer)
+        self.one_unet_wrapped = True
+
+    def validate_unet_number(self, unet_number=None):
+        if self.num_unets == 1:
+            unet_number = default(unet_number, 1)
+        assert 0 < unet_number <= self.num_unets, f'unet number should be in between 1 and {self.num_unets}'
+        return unet_number
+
+    def num_steps_taken(self, unet_number=None):
+        if self.num_unets == 1:
+            unet_number = default(unet_number, 1)
+        return self.steps[unet_number - 1].item()
+
+    def print_untrained_unets(self):
+        flag = False
+        for ind, (steps, unet) in enumerate(zip(self.steps.tolist(), self.imagen.unets)):
+            if steps > 0 or isinstance(unet, NullUnet):
+                continue
+            self.print(f'unet {ind + 1} has not been trained')
+            flag = True
+        if flag:
+            self.print('when sampling, you can pass stop_at_unet_number to stop early in the cascade, so it does not try to generate with untrained unets')
+
+    # ---- data -----------------------------------------------------------------------------------------
+    def add_train_dataloader(self, dl=None):
+        if not exists(dl):
+            return
+        assert not exists(self.train_dl), 'training dataloader was already added'
+        assert not self.prepared, 'You need to add the dataset before preperation'
+        self.train_dl = dl
+
+    def add_valid_dataloader(self, dl):
+        if not exists(dl):
+            return
+        assert not exists(self.valid_dl), 'validation dataloader was already added'
+        assert not self.prepared, 'You need to add the dataset before preperation'
+        self.valid_dl = dl
+
+    def add_train_dataset(self, ds=None, *, batch_size, **dl_kwargs):
+        if not exists(ds):
+            return
+        assert not exists(self.train_dl), 'training dataloader was already added'
+        valid_ds = None
+        if self.split_valid_from_train:
+            train_size = int((1 - self.split_valid_fraction) * len(ds))
+            valid_size = len(ds) - train_size
+            ds, valid_ds = random_split(ds, [train_size, valid_size], generator=torch.Generator().manual_seed(self.split_random_seed))
+            self.print(f'training with dataset of {len(ds)} samples and validating with randomly splitted {len(valid_ds)} samples')
+        self.add_train_dataloader(DataLoader(ds, batch_size=batch_size, **dl_kwargs))
+        if self.split_valid_from_train:
+            self.add_valid_dataset(valid_ds, batch_size=batch_size, **dl_kwargs)
+
+    def add_valid_dataset(self, ds, *, batch_size, **dl_kwargs):
+        if not exists(ds):
+            return
+        assert not exists(self.valid_dl), 'validation dataloader was already added'
+        self.valid_batch_size = batch_size
+        self.add_valid_dataloader(DataLoader(ds, batch_size=self.valid_batch_size, **dl_kwargs))
+
+    def create_train_iter(self):
+        assert exists(self.train_dl), 'training dataloader has not been registered with the trainer yet'
+        if not exists(self.train_dl_iter):
+            self.train_dl_iter = cycle(self.train_dl)
+
+    def create_valid_iter(self):
+        assert exists(self.valid_dl), 'validation dataloader has not been registered with the trainer yet'
+        if not exists(self.valid_dl_iter):
+            self.valid_dl_iter = cycle(self.valid_dl)
+
+    # ---- steps ----------------------------------------------------------------------------------------
+    def train_step(self, unet_number=None, **kwargs):
+        self.training = True
+        if not self.prepared:
+            self.prepare()
+        self.create_train_iter()
+        return self.step_with_dl_iter(self.train_dl, unet_number=unet_number, **kwargs)
+
+    @torch.no_grad()
+    @eval_decorator
+    def valid_step(self, unet_number=None, **kwargs):
+        self.training = False
+        if not self.prepared:
+            self.prepare()
+        self.create_valid_iter()
+        context = self.use_ema_unets if kwargs.pop('use_ema_unets', False) else nullcontext
+        with context():
+            np.random.seed(42)
+            torch.manual_seed(42)
+            loss, preds, condi1, condi2, hrs, ssim, psnr = self.step_with_dl_iter(self.valid_dl, unet_number=unet_number, **kwargs)
+        return loss, preds, condi1, [hrs, condi2], ssim, psnr
+
+    def step_with_dl_iter(self, dl_iter, **kwargs):
+        """trainer.py:705-765 — one pass (``Eval.repeat`` passes when validating) over the whole dataloader."""
+        self.total_loss = 0.
+        if self.training:
+            self.repeat = 1
+        else:
+            self.repeat = self.configs['Eval']['repeat']
+            preds, condi1, condi2, hrs, ssims, psnrs = [], [], [], [], [], []
+        for r in range(self.repeat):
+            for i, data in enumerate(dl_iter):
+                hr_data, lr_data = data[0], data[1]
+                if self.split_batches and self.is_distributed and not self.configs['Train']['batch_sample']:
+                    hr_data = D.shard_batch(hr_data, self.world_size, self.rank)
+                    lr_data = D.shard_batch(lr_data, self.world_size, self.rank)
+                if self.configs['Train']['batch_sample']:
+                    new_batch = (hr_data.shape[-1] // self.configs['Train']['patch_size_sub']) ** 3
+                    c, h = hr_data.shape[1], self.configs['Train']['patch_size_sub']
+                    hr_data = convertVolume2subVolume(hr_data, target_shape=(new_batch, c, h, h, h))
+                    lr_data = convertVolume2subVolume(lr_data, target_shape=(new_batch, c, h, h, h))
+                model_input = dict(list(zip(self.dl_tuple_output_keywords_names, (hr_data, lr_data))))
+                loss, pred, x_noisy, lowres_cond_img_noisy = self.forward(**{**kwargs, **model_input})
+                if not self.training:
+                    if self.configs['Train']['batch_sample']:
+                        pred_merge, hr_merge = merge_sub_volumes(pred), merge_sub_volumes(hr_data)
+                    else:
+                        pred_merge, hr_merge = pred, hr_data
+                    if self.configs['Train']['pred_obj'] == 'x_start':
+                        ssims.append(np.asarray(SSIM(pred_merge.cpu(), hr_merge.cpu())))
+                        psnrs.append(np.asarray(PSNR(pred_merge.cpu(), hr_merge.cpu())))
+                    if r < 2:
+                        preds.append(pred.cpu().numpy())
+                        condi1.append(x_noisy.cpu().numpy())
+                        condi2.append(lowres_cond_img_noisy.cpu().numpy())
+                        hrs.append(hr_data.cpu().numpy())
+                self.total_loss += loss
+        loss = self.total_loss / (len(dl_iter) * self.repeat)
+        if self.training:
+            return loss
+        return (loss, np.concatenate(preds), np.concatenate(condi1), np.concatenate(condi2), np.concatenate(hrs),
+                np.mean(np.array(ssims)), np.mean(np.array(psnrs)))
+
+    # ---- checkpoints (trainer.py:769-945) ---------------------------------------------------------------
+    @property
+    def all_checkpoints_sorted(self):
+        import glob
+        cks = glob.glob(os.path.join(self.checkpoint_path, '*.pt'))
+        return sorted(cks, key=lambda x: int(str(x).split('.')[-2]), reverse=True)
+
+    def load_from_checkpoint_folder(self, last_total_steps=-1):
+        if last_total_steps != -1:
+            self.load(os.path.join(self.checkpoint_path, f'checkpoint.{last_total_steps}.pt'))
+            return
+        cks = self.all_checkpoints_sorted
+        if len(cks) == 0:
+            self.print(f'no checkpoints found to load from at {self.checkpoint_path}')
+            return
+        self.load(cks[0])
+
+    def save_to_checkpoint_folder(self):
+        D.barrier()
+        if not self.can_checkpoint:
+            return
+        total_steps = int(self.steps.sum().item())
+        self.save(os.path.join(self.checkpoint_path, f'checkpoint.{total_steps}.pt'))
+        if self.max_checkpoints_keep <= 0:
+            return
+        for ck in self.all_checkpoints_sorted[self.max_checkpoints_keep:]:
+            os.remove(ck)
+
+    def save(self, path, overwrite=True, without_optim_and_sched=False, **kwargs):
+        D.barrier()
+        if not self.can_checkpoint:
+            return
+        assert not (os.path.exists(path) and not overwrite)
+        self.reset_ema_unets_all_one_device()
+        save_obj = dict(model=self.imagen.state_dict(), version=__version__, steps=self.steps.cpu(), **kwargs)
+        for ind in (range(0, self.num_unets) if not without_optim_and_sched else tuple()):
+            save_obj = {**save_obj, f'scaler{ind}': getattr(self, f'scaler{ind}').state_dict(),
+                        f'optim{ind}': getattr(self, f'optim{ind}').state_dict()}
+        if self.use_ema:
+            save_obj = {**save_obj, 'ema': self.ema_unets.state_dict()}
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, 'wb') as f:
+            torch.save(save_obj, f)
+        self._rebind_after_device_moves()
+        self.print(f'checkpoint saved to {path}')
+
+    def load(self, path, only_model=False, strict=True, noop_if_not_exist=False):
+        if noop_if_not_exist and not os.path.exists(path):
+            self.print(f'trainer checkpoint not found at {str(path)}')
+            return
+        assert os.path.exists(path), f'{path} does not exist'
+        self.reset_ema_unets_all_one_device()
+        with open(path, 'rb') as f:
+            loaded_obj = torch.load(f, map_location='cpu', weights_only=False)
+        if str(loaded_obj.get('version')) != str(__version__):
+            self.print(f'loading saved imagen at version {loaded_obj.get("version")}, but current package version is {__version__}')
+        try:
+            self.imagen.load_state_dict(loaded_obj['model'], strict=strict)
+        except RuntimeError:
+            print("Failed loading state dict. Trying partial load")
+            self.imagen.load_state_dict(restore_parts(self.imagen.state_dict(), loaded_obj['model']))
+        ops.bump_weight_epoch()
+        self._rebind_after_device_moves()
+        if only_model:
+            return loaded_obj
+        self.steps.copy_(loaded_obj['steps'])
+        for ind in range(0, self.num_unets):
+            try:
+                getattr(self, f'optim{ind}').load_state_dict(loaded_obj[f'optim{ind}'])
+                getattr(self, f'scaler{ind}').load_state_dict(loaded_obj[f'scaler{ind}'])
+            except Exception:
+                self.print('could not load optimizer and scaler, possibly because you have turned on mixed precision training since the last run. resuming with new optimizer and scalers')
+        if self.use_ema:
+            assert 'ema' in loaded_obj
+            try:
+                self.ema_unets.load_state_dict(loaded_obj['ema'], strict=strict)
+            except RuntimeError:
+                print("Failed loading state dict. Trying partial load")
+                self.ema_unets.load_state_dict(restore_parts(self.ema_unets.state_dict(), loaded_obj['ema']))
+        self.print(f'checkpoint loaded from {path}')
+        return loaded_obj
+
+    def _rebind_after_device_moves(self):
+        """``state_dict()``/``load`` shuffle unets across devices like the reference; a broken arena is rebuilt."""
+        arena = getattr(self, '_arena', None)
+        if arena is not None and not arena.intact():
+            raise RuntimeError('the trained unet was moved off its flat arena; re-create the trainer')
+        if arena is not None:
+            arena.reinstall_grads()
+
+    # ---- EMA unets (trainer.py:949-1005) -----------------------------------------------------------------
+    @property
+    def unets(self):
+        return nn.ModuleList([ema.ema_model for ema in self.ema_unets])
+
+    def get_ema_unet(self, unet_number=None):
+        if not self.use_ema:
+            return
+        unet_number = self.validate_unet_number(unet_number)
+        index = unet_number - 1
+        if isinstance(self.unets, nn.ModuleList):
+            unets_list = [unet for unet in self.ema_unets]
+            delattr(self, 'ema_unets')
+            self.ema_unets = unets_list
+        if index != self.ema_unet_being_trained_index:
+            for unet_index, unet in enumerate(self.ema_unets):
+                unet.to(self.device if unet_index == index else 'cpu')
+        self.ema_unet_being_trained_index = index
+        return self.ema_unets[index]
+
+    def reset_ema_unets_all_one_device(self, device=None):
+        if not self.use_ema:
+            return
+        device = default(device, self.device)
+        self.ema_unets = nn.ModuleList([*self.ema_unets])
+        self.ema_unets.to(device)
+        self.ema_unet_being_trained_index = -1
+
+    @torch.no_grad()
+    @contextmanager
+    def use_ema_unets(self):
+        if not self.use_ema:
+            output = yield
+            return output
+        self.reset_ema_unets_all_one_device()
+        self.imagen.reset_unets_all_one_device()
+        self.unets.eval()
+        trainable_unets = self.imagen.unets
+        self.imagen.unets = self.unets
+        output = yield
+        self.imagen.unets = trainable_unets
+        for ema in self.ema_unets:
+            ema.restore_ema_model_device()
+        return output
+
+    def state_dict(self, *args, **kwargs):
+        self.reset_ema_unets_all_one_device()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.reset_ema_unets_all_one_device()
+        return super().load_state_dict(*args, **kwargs)
+
+    # ---- optimisation -----------------------------------------------------------------------------------
+    def _is_sync_step(self):
+        return (self._micro_step % self.gradient_accumulation_steps) == 0
+
+    def update(self, unet_number=None):
+        """trainer.py:1038-1081.  The optimiser really steps only when the micro-step counter hit the accumulation
+        boundary (``_sync_now``); EMA and ``steps`` advance on every call."""
+        unet_number = self.validate_unet_number(unet_number)
+        self.validate_and_set_unet_being_trained(unet_number)
+        index = unet_number - 1
+        optimizer = getattr(self, f'optim{index}')
+        if getattr(self, '_sync_now', False):
+            optimizer.step()            # fused Adam + zero_grad
+            self._sync_now = False
+        if self.use_ema:
+            self.get_ema_unet(unet_number).update()
+        self.steps += F.one_hot(torch.tensor(unet_number - 1, device=self.steps.device), num_classes=len(self.steps))
+        if not exists(self.checkpoint_path):
+            return
+        total_steps = int(self.steps.sum().item())
+        if total_steps % self.checkpoint_every:
+            return
+        self.save_to_checkpoint_folder()
+
+    @torch.no_grad()
+    @cast_torch_tensor
+    @imagen_sample_in_chunks
+    def sample(self, *args, **kwargs):
+        context = nullcontext if kwargs.pop('use_non_ema', False) else self.use_ema_unets
+        self.print_untrained_unets()
+        kwargs['use_tqdm'] = False
+        with context():
+            output = self.imagen.sample(*args, device=self.device, **kwargs)
+        return output
+
+    @partial(cast_torch_tensor, cast_fp16=True)
+    def forward(self, *args, unet_number=None, max_batch_size=None, **kwargs):
+        """trainer.py:1099-1128 -> (total_loss, pred, x_noisy, lowres)."""
+        unet_number = self.validate_unet_number(unet_number)
+        self.validate_and_set_unet_being_trained(unet_number)
+        self.max_batch_size = max_batch_size
+        assert not exists(self.only_train_unet_number) or self.only_train_unet_number == unet_number, \
+            f'you can only train unet #{self.only_train_unet_number}'
+        total_loss = 0.
+        reducer = self.unet_being_trained.reducer
+        for chunk_size_frac, (chunked_args, chunked_kwargs) in split_args_and_kwargs(*args, split_size=max_batch_size, **kwargs):
+            self._micro_step += 1
+            sync = self._is_sync_step()
+            loss, pred, x_noisy, lowres_cond_img_noisy = self.imagen(*chunked_args, unet=self.unet_being_trained,
+                                                                     unet_number=unet_number, **chunked_kwargs)
+            loss = loss * chunk_size_frac
+            if self.training:
+                # like accelerate.accumulate: the loss is divided by the accumulation steps, DDP syncs on the boundary
+                if exists(reducer):
+                    reducer.prepare_backward(sync=sync)
+                (loss / self.gradient_accumulation_steps).backward()
+                if exists(reducer):
+                    reducer.finalize_backward()
+                self._sync_now = sync
+                self.update(unet_number=unet_number)
+            total_loss += loss.item()
+        return total_loss, pred, x_noisy, lowres_cond_img_noisy

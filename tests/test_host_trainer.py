@@ -1,0 +1,118 @@
+"""Host logic of ImagenTrainer / Imagen (no GPU): chunking, accumulation cadence, loss scaling, EMA schedule and
+checkpoint layout, pinned against the trace recorded from the real reference trainer
+(tests/golden/trainerA_trace.npz, made by oracle/make_golden.py with accelerate 1.14: parity of the cadence with the
+reference's pinned accelerate 0.16 is unpinned — SURVEY.md Appendix A).  Device ops are replaced by the plain-torch
+doubles of tests/cpu_doubles.py and the U-Net by the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import iqt_oracle as O
+from tests.conftest import load_golden
+from tests.cpu_doubles import cpu_op_doubles, OracleUnet
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def make_trainer(tmp_path=None, **kw):
+    from diffusioniqt_amd.imagen_pytorch3D import Imagen, NullUnet
+    from diffusioniqt_amd.trainer import ImagenTrainer
+    gu = load_golden('unetA_tiny')
+    keys = [str(k) for k in gu['keys']]
+    shapes = [tuple(json.loads(str(s))) for s in gu['shapes']]
+    sd = O.hash_fill_state_dict({k: torch.zeros(s) for k, s in zip(keys, shapes)}, 0)
+    cfg = O.unet_config(**json.loads(str(gu['kwargs'])))
+    unet = OracleUnet(sd, cfg)
+    configs = {'Data': {'norm': 'z-score'}, 'Train': {'batch_sample': False, 'patch_size_sub': 8, 'pred_obj': 'x_start'},
+               'Eval': {'repeat': 1}}
+    imagen = Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=float(gu['min_bound']), image_sizes=(8, 8),
+                    channels=1, pred_objectives='x_start', timesteps=4, dynamic_thresholding=False,
+                    p2_loss_weight_gamma=0.0, cond_drop_prob=0.0)
+    ImagenTrainer.locked = False
+    trainer = ImagenTrainer(configs=configs, imagen=imagen, gradient_accumulation_steps=4, verbose=False, **kw)
+    return trainer, unet
+
+
+def test_trainer_cadence_losses_and_weights_match_reference_trace():
+    g = load_golden('trainerA_trace')
+    with cpu_op_doubles():
+        trainer, unet = make_trainer()
+        trainer.training = True
+        idx = unet.names.index('final_conv.weight')
+        w_prev = unet.plist[idx].detach().clone()
+        for i in range(g['hr'].shape[0]):
+            times = T(g['times'][i])
+            trainer.imagen.noise_schedulers[1].sample_random_times = lambda b, device, t=times: t.clone()
+            loss, pred, x_noisy, _ = trainer.forward(T(g['hr'][i]), lowres_img=T(g['lowres'][i]), unet_number=2,
+                                                     max_batch_size=2, noise=T(g['noise'][i]))
+            w = unet.plist[idx].detach().clone()
+            steps_ref, changed_ref = int(g['trace'][i][0]), bool(g['trace'][i][1])
+            assert int(trainer.steps[1].item()) == steps_ref
+            assert (not torch.equal(w, w_prev)) == changed_ref, f'micro-step {i}: Adam cadence differs from the reference'
+            w_prev = w
+            assert abs(loss - float(g['losses'][i])) <= 2e-5 * abs(float(g['losses'][i])), (i, loss, g['losses'][i])
+            ref_w = T(g['final_conv_w'][i])
+            assert torch.allclose(w.flatten(), ref_w, atol=2e-6, rtol=1e-4), f'weights after micro-step {i}'
+
+
+def test_checkpoint_layout_and_roundtrip(tmp_path):
+    with cpu_op_doubles():
+        trainer, unet = make_trainer()
+        trainer.training = True
+        g = load_golden('trainerA_trace')
+        for i in range(4):
+            trainer.forward(T(g['hr'][i]), lowres_img=T(g['lowres'][i]), unet_number=2, max_batch_size=2, noise=T(g['noise'][i]))
+        path = os.path.join(tmp_path, 'ck', '3dimagen.pt')
+        trainer.save(path)
+        obj = torch.load(path, map_location='cpu', weights_only=False)
+        assert {'model', 'version', 'steps', 'optim0', 'optim1', 'scaler0', 'scaler1', 'ema'} <= set(obj)
+        assert all(k.startswith('unets.') for k in obj['model'])
+        assert any(k.startswith('1.ema_model.') for k in obj['ema'])
+        assert set(obj['optim1']) == {'state', 'param_groups'} and obj['optim1']['param_groups'][0]['betas'] == (0.9, 0.99)
+        st = obj['optim1']['state'][0]
+        assert set(st) == {'step', 'exp_avg', 'exp_avg_sq'} and float(st['step']) == 1.0
+        w_saved = obj['model']['unets.1.plist.0'].clone()
+        # perturb, reload, compare
+        with torch.no_grad():
+            unet.plist[0].add_(1.0)
+        trainer.load(path)
+        assert torch.equal(unet.plist[0].detach(), w_saved)
+        assert int(trainer.steps[1]) == 4
+
+
+def test_train_step_is_one_pass_over_the_loader_and_sample_returns_three_tuple():
+    from diffusioniqt_amd.data import SyntheticPatchDataset
+    with cpu_op_doubles():
+        trainer, unet = make_trainer()
+        ds = SyntheticPatchDataset(n=6, size=8, seed=1)
+        trainer.add_train_dataset(ds, batch_size=2)
+        trainer.add_valid_dataset(SyntheticPatchDataset(n=2, size=8, seed=2), batch_size=2)
+        loss = trainer.train_step(unet_number=2, max_batch_size=2)
+        assert isinstance(loss, float) and int(trainer.steps[1]) == 3          # 3 batches -> 3 micro-steps
+        trainer.update(unet_number=2)                                           # train.py:162's extra update
+        assert int(trainer.steps[1]) == 4
+        out = trainer.valid_step(unet_number=2, max_batch_size=2)
+        assert len(out) == 6 and out[1].shape == (2, 1, 8, 8, 8) and isinstance(out[3], list)
+        lr = torch.randn(2, 1, 8, 8, 8)
+        res = trainer.sample(batch_size=2, skip_steps=None, return_all_outputs=False, return_pil_images=False,
+                             start_image_or_video=lr, start_at_unet_number=2)
+        assert len(res) == 3 and tuple(res[0].shape) == (2, 1, 8, 8, 8) and len(res[1]) == 5 and isinstance(res[1][0], np.ndarray)
+        res2 = trainer.sample(batch_size=2, return_all_unet_outputs=True, start_image_or_video=lr, start_at_unet_number=2,
+                              use_non_ema=True)
+        assert isinstance(res2[0], list)
+
+
+def test_ema_schedule_matches_published_defaults():
+    from diffusioniqt_amd.trainer import EMA
+    m = torch.nn.Linear(2, 2)
+    e = EMA(m)
+    decays = []
+    for s in (0, 100, 101, 102, 111, 1000, 10 ** 7):
+        e.step.fill_(s)
+        decays.append(e.get_current_decay())
+    assert decays[:3] == [0.0, 0.0, 0.0]
+    assert abs(decays[3] - (1 - 2 ** (-2 / 3))) < 1e-9 and abs(decays[4] - (1 - 11 ** (-2 / 3))) < 1e-9
+    assert decays[-1] == 0.9999

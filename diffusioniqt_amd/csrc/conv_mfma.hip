@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     float* halo = smem;                                  // [HV][36]
     float* wbuf = smem + (size_t)HV * LDSROW;            // [2][64][36]
     int* out_off = reinterpret_cast<int*>(wbuf + 2 * NT * LDSROW);   // [128] voxel -> output row or -1
+    int* halo_src = out_off + MTILE;                                 // [HV] halo voxel -> input voxel index or -1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -109,6 +110,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
         out_off[tid] = off;
     }
 
+    // halo voxel -> source voxel, computed once per tile (keeps the integer divisions out of the staging loops)
+    for (int hv = tid; hv < HV; hv += 256) {
+        const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+        const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+        int src = -1;
+        if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) src = ((b * g.D + iz) * g.H + iy) * g.W + ix;
+        halo_src[hv] = src;
+    }
+
     // this lane's voxel (row of the A operand) -> halo index at tap (0,0,0)
     int hidx_lane;
     {
@@ -129,11 +139,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
         // ---- stage halo chunk ----
         for (int idx = tid; idx < HV * 8; idx += 256) {
             const int hv = idx >> 3, c4 = (idx & 7) * 4;
-            const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
-            const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+            const int src = halo_src[hv];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
-                const size_t base = ((((size_t)b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin + ci0 + c4;
+            if (src >= 0) {
+                const size_t base = (size_t)src * g.Cin + ci0 + c4;
                 if (VEC4) {
                     if (ci0 + c4 < g.Cin) v = *reinterpret_cast<const float4*>(x + base);
                 } else {
@@ -237,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(const float* __
     const int HVp = g.TD * HHp * HWp;
     float* xh = smem;                                     // [HVp][32]
     float* dyt = smem + (size_t)HVp * CK;                 // [128][64]
+    int* xsrc = reinterpret_cast<int*>(dyt + MTILE * NT);  // [HVp] halo voxel -> input voxel or -1
+    int* ysrc = xsrc + HVp;                                // [128] tile voxel -> output voxel or -1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -280,15 +291,28 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(const float* __
         const int tz = mt % g.tilesD;
         const int b = mt / g.tilesD;
         const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
-        __syncthreads();
+        // index tables (one division set per voxel, not per 16-byte piece); xsrc/ysrc are only read during staging
+        for (int hv = tid; hv < HVp + MTILE; hv += 256) {
+            if (hv < HVp) {
+                const int hx = hv % HWp, hy = (hv / HWp) % HHp, hz = hv / (HWp * HHp);
+                const int iz = d0 + hz + kz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+                xsrc[hv] = (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                               ? ((b * g.D + iz) * g.H + iy) * g.W + ix : -1;
+            } else {
+                const int v = hv - HVp;
+                const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
+                const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+                ysrc[v] = (od < g.Do && oh < g.Ho && ow < g.Wo) ? ((b * g.Do + od) * g.Ho + oh) * g.Wo + ow : -1;
+            }
+        }
+        __syncthreads();   // tables ready; all MFMA reads of the previous tile's xh/dyt are done (they precede this barrier)
         // x halo plane for this kz: input depth rows d0 + td + kz - pd
         for (int idx = tid; idx < HVp * 8; idx += 256) {
             const int hv = idx >> 3, c4 = (idx & 7) * 4;
-            const int hx = hv % HWp, hy = (hv / HWp) % HHp, hz = hv / (HWp * HHp);
-            const int iz = d0 + hz + kz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+            const int src = xsrc[hv];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
-                const size_t base = ((((size_t)b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin + ci0 + c4;
+            if (src >= 0) {
+                const size_t base = (size_t)src * g.Cin + ci0 + c4;
                 if (VEC4) {
                     if (ci0 + c4 < g.Cin) v = *reinterpret_cast<const float4*>(x + base);
                 } else {
@@ -304,11 +328,10 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(const float* __
         // dY tile [128][64]
         for (int idx = tid; idx < MTILE * 16; idx += 256) {
             const int v = idx >> 4, c4 = (idx & 15) * 4;
-            const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
-            const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+            const int src = ysrc[v];
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (od < g.Do && oh < g.Ho && ow < g.Wo) {
-                const size_t base = ((((size_t)b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout + n0 + c4;
+            if (src >= 0) {
+                const size_t base = (size_t)src * g.Cout + n0 + c4;
                 const int rem = g.Cout - (n0 + c4);
                 if ((g.Cout & 3) == 0) {
                     if (rem > 0) r = *reinterpret_cast<const float4*>(dy + base);
@@ -410,12 +433,15 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
         }
     }
 }
-__global__ void colsum_stage2_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int nblk, int C) {
+    // one wave per channel, lanes over the partial blocks
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += partial[(size_t)k * C + c];
-    out[c] = s;
+    for (int k = lane; k < nblk; k += 64) s += partial[(size_t)k * C + c];
+    s = wave_sum(s);
+    if (lane == 0) out[c] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -431,7 +457,7 @@ static void choose_tile(int Do, int Ho, int Wo, int kd, int kh, int kw, int& TD,
         if (c[2] & 1) continue;   // bwd-weight pairs voxels along W
         const double tiles = (double)cdiv(Do, c[0]) * cdiv(Ho, c[1]) * cdiv(Wo, c[2]);
         const double halo = (double)(c[0] + kd - 1) * (c[1] + kh - 1) * (c[2] + kw - 1);
-        if (halo * LDSROW * 4 + 2 * NT * LDSROW * 4 + 512 > 150 * 1024) continue;
+        if (halo * (LDSROW + 1) * 4 + 2 * NT * LDSROW * 4 + 512 > 150 * 1024) continue;
         const double cost = tiles * (halo * 0.15 + 128.0 * kd * kh * kw);   // staging + MFMA work
         if (cost < best) { best = cost; TD = c[0]; TH = c[1]; TW = c[2]; }
     }
@@ -473,7 +499,7 @@ extern "C" size_t diqt_conv_packed_elems(int Cout, int Cin, int kd, int kh, int 
 extern "C" long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, int kw, int pd, int ph, int pw) {
     ConvGeom g;
     if (make_geom(g, 1, D, H, W, 4, 4, kd, kh, kw, pd, ph, pw)) return -1;
-    return (long long)(((size_t)g.HD * g.HH * g.HWd * LDSROW + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int));
+    return (long long)(((size_t)g.HD * g.HH * g.HWd * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int));
 }
 
 extern "C" int diqt_conv_pack_weight(const float* w, float* packed, int Cout, int Cin, int kd, int kh, int kw,
@@ -499,7 +525,7 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
     if (rc) return rc;
     DIQT_REQUIRE(aligned16(packed), DIQT_E_ALIGN, "conv3d_fwd: packed weights must be 16-byte aligned");
     const bool vec4 = (Cin % 4 == 0) && aligned16(x);
-    const size_t lds = ((size_t)g.HD * g.HH * g.HWd * LDSROW + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int);
+    const size_t lds = ((size_t)g.HD * g.HH * g.HWd * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int);
     DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_fwd: halo tile needs %zu B of LDS", lds);
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
     auto kern = vec4 ? conv_fwd_kernel<true> : conv_fwd_kernel<false>;
@@ -520,7 +546,8 @@ static int bw_plan(BwGeom& bg, int B, int D, int H, int W, int Cin, int Cout, in
     bg.tapGroups = cdiv(kh * kw, 2 * BW_MAXT);
     bg.MT = g.B * g.tilesD * g.tilesH * g.tilesW;
     const int gx = g.nChunks * g.nNt * g.kd * bg.tapGroups;
-    ksplit = cdiv(1024, gx);
+    // 2 workgroups fit a CU (LDS): aim at ONE full round of 512 resident workgroups, never 1.01 rounds
+    ksplit = 512 / gx;
     if (ksplit > bg.MT) ksplit = bg.MT;
     if (ksplit < 1) ksplit = 1;
     bg.tilesPerSplit = cdiv(bg.MT, ksplit);
@@ -553,7 +580,7 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     DIQT_REQUIRE(workspace_bytes >= need, DIQT_E_WORKSPACE, "conv3d_bwd_weight: workspace %zu < %zu", workspace_bytes, need);
     DIQT_REQUIRE(aligned16(workspace), DIQT_E_ALIGN, "conv3d_bwd_weight: workspace must be 16-byte aligned");
     const bool vec4 = (Cin % 4 == 0) && aligned16(x) && aligned16(dy);
-    const size_t lds = ((size_t)g.TD * g.HH * g.HWd * CK + (size_t)MTILE * NT) * sizeof(float);
+    const size_t lds = ((size_t)g.TD * g.HH * g.HWd * (CK + 1) + (size_t)MTILE * (NT + 1)) * sizeof(float);
     DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_bwd_weight: tile needs %zu B of LDS", lds);
     auto kern = vec4 ? conv_bwd_weight_kernel<true> : conv_bwd_weight_kernel<false>;
     if (lds > 64 * 1024) {
@@ -575,13 +602,13 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     if (dbias) {
         const size_t rows = (size_t)g.B * g.Do * g.Ho * g.Wo;
         unsigned nblk = (unsigned)((rows + 255) / 256);
-        if (nblk > 1024) nblk = 1024;
+        if (nblk > 512) nblk = 512;
         if (nblk < 1) nblk = 1;
         // the slabs were consumed by the reduce kernel above (same stream) -> reuse the workspace
         hipLaunchKernelGGL(colsum_stage1_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), s, dy, slabs, rows, Cout);
         rc = check_launch("colsum_stage1");
         if (rc) return rc;
-        hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(Cout, 256)), dim3(256), 0, s, slabs, dbias, (int)nblk, Cout);
+        hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(Cout, 4)), dim3(256), 0, s, slabs, dbias, (int)nblk, Cout);
         rc = check_launch("colsum_stage2");
     }
     return rc;

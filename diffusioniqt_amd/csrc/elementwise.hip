@@ -93,22 +93,27 @@ struct MomentsF {
     }
 };
 
-__global__ void gn_stats_final_kernel(const float* __restrict__ partial, float* __restrict__ mean,
-                                      float* __restrict__ rstd, int B, int C, int G, int nblk, double count,
-                                      float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * G) return;
+__global__ __launch_bounds__(64) void gn_stats_final_kernel(const float* __restrict__ partial, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int B, int C, int G, int nblk,
+                                                            double count, float eps) {
+    // one wave per (b,g): lanes stride over the nblk x Cg partial sums, fp64 combine
+    const int i = blockIdx.x;
     const int b = i / G, g = i % G, Cg = C / G;
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < nblk; ++k) {
+    for (int e = threadIdx.x; e < nblk * Cg; e += 64) {
+        const int k = e / Cg, c = g * Cg + e % Cg;
         const float* p = partial + ((size_t)b * nblk + k) * 2 * C;
-        for (int c = g * Cg; c < (g + 1) * Cg; ++c) { s += p[c]; ss += p[C + c]; }
+        s += p[c]; ss += p[C + c];
     }
-    const double m = s / count;
-    double var = ss / count - m * m;
-    if (var < 0) var = 0;
-    mean[i] = (float)m;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+    if (threadIdx.x == 0) {
+        const double m = s / count;
+        double var = ss / count - m * m;
+        if (var < 0) var = 0;
+        mean[i] = (float)m;
+        rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -179,38 +184,32 @@ struct GnBwdF {
     __device__ void scalar(size_t i, int b, int c, float (&o)[2]) const { one(x[i], dy[i], b, c, o[0], o[1]); }
 };
 
-// pass 2: reduce partials -> S[b][2][C] (in place at the head of the workspace tail), param grads, group means
-__global__ void gn_bwd_final_kernel(const float* __restrict__ partial, float* __restrict__ S, GnCoef k,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                    float* __restrict__ dscale, float* __restrict__ dshift,
-                                    float* __restrict__ m12, int B, int nblk, float inv_count) {
-    // one block; thread loops
+// pass 2a: S[b][v][c] = sum_blk partial[b][blk][v][c]  (sum_partials_kernel, one wave per output)
+// pass 2b: parameter gradients and per-(b,g) means from S (thread-parallel, loops of length B or C/G)
+__global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restrict__ S, GnCoef k,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dscale, float* __restrict__ dshift,
+                                                           float* __restrict__ m12, int B, float inv_count) {
     const int C = k.C, G = k.G, Cg = C / G;
-    for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B * C) {
         const int b = i / C, c = i % C;
-        float s1 = 0.f, s2 = 0.f;
-        for (int q = 0; q < nblk; ++q) {
-            const float* p = partial + ((size_t)b * nblk + q) * 2 * C;
-            s1 += p[c]; s2 += p[C + c];
-        }
-        S[(size_t)b * 2 * C + c] = s1;
-        S[(size_t)b * 2 * C + C + c] = s2;
+        const float s1 = S[(size_t)b * 2 * C + c], s2 = S[(size_t)b * 2 * C + C + c];
         const float ga = k.gamma ? k.gamma[c] : 1.f, be = k.beta ? k.beta[c] : 0.f;
         if (dscale) dscale[b * k.cs + c] = ga * s2 + be * s1;
         if (dshift) dshift[b * k.cs + c] = s1;
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    if (i < C) {
         float dg = 0.f, db = 0.f;
         for (int b = 0; b < B; ++b) {
-            const float sc = k.scale ? k.scale[b * k.cs + c] + 1.f : 1.f;
-            dg += sc * S[(size_t)b * 2 * C + C + c];
-            db += sc * S[(size_t)b * 2 * C + c];
+            const float sc = k.scale ? k.scale[b * k.cs + i] + 1.f : 1.f;
+            dg += sc * S[(size_t)b * 2 * C + C + i];
+            db += sc * S[(size_t)b * 2 * C + i];
         }
-        if (dgamma) dgamma[c] = dg;
-        if (dbeta) dbeta[c] = db;
+        if (dgamma) dgamma[i] = dg;
+        if (dbeta) dbeta[i] = db;
     }
-    for (int i = threadIdx.x; i < B * G; i += blockDim.x) {
+    if (i < B * G) {
         const int b = i / G, g = i % G;
         float a1 = 0.f, a2 = 0.f;
         for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
@@ -318,15 +317,16 @@ struct ChanLnDgF {
     }
     __device__ void scalar(size_t i, int, int, float (&o)[1]) const { o[0] = one(i); }
 };
-__global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int NVC,
-                                    int total, float alpha) {
-    // out[b][j] = alpha * sum_k partial[b][k][j], j in [0,NVC); total = B*NVC
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int nblk, int NVC, int total, float alpha) {
+    // out[b][j] = alpha * sum_k partial[b][k][j]; one wave per output, lanes over k
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= total) return;
-    const int b = i / NVC, j = i % NVC;
+    const int b = i / NVC, j = i % NVC, lane = threadIdx.x & 63;
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += partial[((size_t)b * nblk + k) * NVC + j];
-    out[i] = alpha * s;
+    for (int k = lane; k < nblk; k += 64) s += partial[((size_t)b * nblk + k) * NVC + j];
+    s = wave_sum(s);
+    if (lane == 0) out[i] = alpha * s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -812,7 +812,7 @@ extern "C" int diqt_groupnorm_stats(const float* x, float* mean, float* rstd, vo
     hipLaunchKernelGGL((colreduce_kernel<2, MomentsF>), dim3(nblk, B), dim3(256), 0, STREAM, f, partial, rows, C);
     int rc = check_launch("groupnorm_stats/reduce");
     if (rc) return rc;
-    hipLaunchKernelGGL(gn_stats_final_kernel, dim3((B * G + 63) / 64), dim3(64), 0, STREAM, partial, mean, rstd, B, C, G,
+    hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B * G), dim3(64), 0, STREAM, partial, mean, rstd, B, C, G,
                        nblk, (double)rows * (C / G), eps);
     return check_launch("groupnorm_stats/final");
 }
@@ -859,8 +859,12 @@ extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mea
     }
     int rc = check_launch("gn_act_bwd/reduce");
     if (rc) return rc;
-    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(1), dim3(256), 0, STREAM, partial, S, k, dgamma, dbeta, dscale, dshift,
-                       m12, B, nblk, 1.f / ((float)rows * (C / G)));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((B * 2 * C + 3) / 4), dim3(256), 0, STREAM, partial, S, nblk, 2 * C,
+                       B * 2 * C, 1.f);
+    rc = check_launch("gn_act_bwd/sum");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, STREAM, S, k, dgamma, dbeta, dscale,
+                       dshift, m12, B, 1.f / ((float)rows * (C / G)));
     rc = check_launch("gn_act_bwd/final");
     if (rc) return rc;
     const dim3 grid(grid_for(per / 4 + 1, 256, 1024), B);
@@ -895,7 +899,7 @@ extern "C" int diqt_chan_layernorm_bwd(const float* x, const float* dy, const fl
     hipLaunchKernelGGL((colreduce_kernel<1, ChanLnDgF>), dim3(nblk, 1), dim3(256), 0, STREAM, f, partial, rows, C);
     rc = check_launch("chan_layernorm_bwd/dg");
     if (rc) return rc;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, STREAM, partial, dg, nblk, C, C, 1.f);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 3) / 4), dim3(256), 0, STREAM, partial, dg, nblk, C, C, 1.f);
     return check_launch("chan_layernorm_bwd/dg-final");
 }
 
@@ -928,7 +932,7 @@ static int colreduce1(F f, float* out, float alpha, void* workspace, size_t work
     hipLaunchKernelGGL((colreduce_kernel<1, F>), dim3(nblk, B), dim3(256), 0, STREAM, f, partial, rows, C);
     int rc = check_launch(what);
     if (rc) return rc;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((B * C + 255) / 256), dim3(256), 0, STREAM, partial, out, nblk, C, B * C, alpha);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((B * C + 3) / 4), dim3(256), 0, STREAM, partial, out, nblk, C, B * C, alpha);
     return check_launch(what);
 }
 

@@ -21,6 +21,7 @@
 //   LDS and issues one MFMA per (tap, 2 voxels).  Partial slabs go to the workspace in the packed
 //   layout and are reduced in a fixed order (deterministic) by conv_reduce_dw_kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace diqt {
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     int* halo_src = out_off + MTILE;                                 // [HV] halo voxel -> input voxel index or -1
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
 
     const unsigned nwg = gridDim.x;
@@ -180,11 +181,19 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
                     const float* wcur = wbuf + (tap & 1) * (NT * LDSROW);
                     const float* ap = halo + (hidx_lane + (kz * g.HH + ky) * g.HWd + kx) * LDSROW + 4 * h;
                     const float* bp = wcur + l31 * LDSROW + 4 * h;
+                    // software-pipelined over q: the fragments of q+1 are in flight while the 8 MFMAs of q issue
+                    float4 a = *reinterpret_cast<const float4*>(ap);
+                    float4 b0 = *reinterpret_cast<const float4*>(bp);
+                    float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 a = *reinterpret_cast<const float4*>(ap + 8 * q);
-                        const float4 b0 = *reinterpret_cast<const float4*>(bp + 8 * q);
-                        const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * q);
+                        float4 an, b0n, b1n;
+                        if (q < 3) {
+                            an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+                            b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+                            b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // keep the q+1 reads ahead of q's MFMAs (hipcc sinks them otherwise)
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
@@ -193,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+                        if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
                     }
                     if (more) {
                         float* wnext = wbuf + ((tap + 1) & 1) * (NT * LDSROW);
@@ -227,12 +237,227 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// persistent forward / backward-data kernel (the default): <= 2 workgroups per CU walk the tile list of
+// "their" XCD; the halo chunk of the NEXT (tile, chunk) item is fetched global -> registers while the
+// current item's 27 x 32 MFMAs run and is written to LDS at the item boundary (async-stage split), so HBM
+// latency, workgroup launch and index math are off the MFMA critical path.  Same math, same LDS images.
+// ---------------------------------------------------------------------------------------------
+template <bool VEC4, int NR>
+__global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ wp,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ residual,
+                                                                  float* __restrict__ y, ConvGeom g, int nTiles, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HV = g.HD * g.HH * g.HWd;
+    float* halo = smem;                                  // [HV][36]
+    float* wbuf = smem + (size_t)HV * LDSROW;            // [2][64][36]
+    int* out_off = reinterpret_cast<int*>(wbuf + 2 * NT * LDSROW);   // [2][128]
+    int* halo_src = out_off + 2 * MTILE;                              // [2][HV]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int T = g.kd * g.kh * g.kw;
+
+    // tile ownership: XCD x (= blockIdx % 8 under round-robin placement; speed only) owns a contiguous range
+    const int G8 = gridDim.x / kNumXcd;                  // workgroups per XCD (grid is a multiple of 8)
+    const int xcd = blockIdx.x % kNumXcd, j = blockIdx.x / kNumXcd;
+    const int tpx = (nTiles + kNumXcd - 1) / kNumXcd;
+    const int tileEnd = min((xcd + 1) * tpx, nTiles);
+    int tile = xcd * tpx + j;
+    if (tile >= tileEnd) return;
+
+    struct TilePos { int b, d0, h0, w0, n0; };
+    auto decode = [&](int t) {
+        TilePos p;
+        p.n0 = (t % g.nNt) * NT;
+        int mt = t / g.nNt;
+        p.w0 = (mt % g.tilesW) * g.TW; mt /= g.tilesW;
+        p.h0 = (mt % g.tilesH) * g.TH; mt /= g.tilesH;
+        p.d0 = (mt % g.tilesD) * g.TD;
+        p.b = mt / g.tilesD;
+        return p;
+    };
+    auto fill_tables = [&](const TilePos& p, int slot) {
+        for (int hv = tid; hv < HV; hv += 256) {
+            const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+            const int iz = p.d0 + hz - g.pd, iy = p.h0 + hy - g.ph, ix = p.w0 + hx - g.pw;
+            int src = -1;
+            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                src = ((p.b * g.D + iz) * g.H + iy) * g.W + ix;
+            halo_src[slot * HV + hv] = src;
+        }
+        if (tid < MTILE) {
+            const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
+            const int od = p.d0 + td, oh = p.h0 + th, ow = p.w0 + tw;
+            out_off[slot * MTILE + tid] = (od < g.Do && oh < g.Ho && ow < g.Wo)
+                                              ? ((p.b * g.Do + od) * g.Ho + oh) * g.Wo + ow : -1;
+        }
+    };
+    float4 R[NR];
+    auto issue_loads = [&](int slot, int ci0) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int idx = tid + 256 * r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < HV * 8) {
+                const int hv = idx >> 3, c4 = (idx & 7) * 4;
+                const int src = halo_src[slot * HV + hv];
+                if (src >= 0 && !(ablate & 2)) {
+                    const size_t base = (size_t)src * g.Cin + ci0 + c4;
+                    if (VEC4) {
+                        if (ci0 + c4 < g.Cin) v = *reinterpret_cast<const float4*>(x + base);
+                    } else {
+                        const int rem = g.Cin - (ci0 + c4);
+                        if (rem > 0) v.x = x[base];
+                        if (rem > 1) v.y = x[base + 1];
+                        if (rem > 2) v.z = x[base + 2];
+                        if (rem > 3) v.w = x[base + 3];
+                    }
+                }
+            }
+            R[r] = v;
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int idx = tid + 256 * r;
+            if (idx < HV * 8) *reinterpret_cast<float4*>(halo + (idx >> 3) * LDSROW + (idx & 7) * 4) = R[r];
+        }
+    };
+
+    int hidx_lane;
+    {
+        const int v = wave * 32 + l31;
+        const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
+        hidx_lane = (td * g.HH + th) * g.HWd + tw;
+    }
+    const int wrow = tid >> 3, wc4 = (tid & 7) * 4;
+
+    int slot = 0;
+    TilePos pos = decode(tile);
+    fill_tables(pos, 0);
+    __syncthreads();
+    issue_loads(0, 0);
+    // stagger: the second resident set of workgroups starts half a tap late, so the two waves sharing a SIMD do not
+    // reach their barriers / LDS-read waits in lockstep (speed only)
+    if (blockIdx.x >= gridDim.x / 2)
+        for (int i = 0; i < (ablate >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+
+    while (true) {
+        const int nextTile = tile + G8;
+        const bool haveNextTile = nextTile < tileEnd;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+        for (int chunk = 0; chunk < g.nChunks; ++chunk) {
+            const bool lastChunk = chunk == g.nChunks - 1;
+            __syncthreads();          // every wave is done reading the previous item's halo and weight buffers
+            store_halo();             // waits for the prefetched registers (issued one item ago)
+            const float* wchunk = wp + ((size_t)chunk * T * g.CoutPad + pos.n0) * CK;
+            {
+                const float4 r0 = *reinterpret_cast<const float4*>(wchunk + (size_t)wrow * CK + wc4);
+                const float4 r1 = *reinterpret_cast<const float4*>(wchunk + (size_t)(wrow + 32) * CK + wc4);
+                *reinterpret_cast<float4*>(wbuf + wrow * LDSROW + wc4) = r0;
+                *reinterpret_cast<float4*>(wbuf + (wrow + 32) * LDSROW + wc4) = r1;
+            }
+            TilePos npos = pos;
+            if (lastChunk && haveNextTile) {
+                npos = decode(nextTile);
+                fill_tables(npos, slot ^ 1);
+            }
+            __syncthreads();
+            // prefetch the next item's halo chunk into registers; it lands while this item's MFMAs run
+            if (!lastChunk) issue_loads(slot, (chunk + 1) * CK);
+            else if (haveNextTile) issue_loads(slot ^ 1, 0);
+
+            int tap = 0;
+            for (int kz = 0; kz < g.kd; ++kz)
+                for (int ky = 0; ky < g.kh; ++ky)
+                    for (int kx = 0; kx < g.kw; ++kx, ++tap) {
+                        float4 r0, r1;
+                        const bool more = (tap + 1 < T);
+                        if (more && !(ablate & 8)) {
+                            const float* wt = wchunk + (size_t)(tap + 1) * g.CoutPad * CK;
+                            r0 = *reinterpret_cast<const float4*>(wt + (size_t)wrow * CK + wc4);
+                            r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
+                        }
+                        const float* wcur = wbuf + (tap & 1) * (NT * LDSROW);
+                        const float* ap = (ablate & 32) ? halo + (l31 + tap) * LDSROW + 4 * h
+                                                        : halo + (hidx_lane + (kz * g.HH + ky) * g.HWd + kx) * LDSROW + 4 * h;
+                        const float* bp = wcur + l31 * LDSROW + 4 * h;
+                        float4 a = *reinterpret_cast<const float4*>(ap);
+                        float4 b0 = *reinterpret_cast<const float4*>(bp);
+                        float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float4 an, b0n, b1n;
+                            if (q < 3 && !(ablate & 16)) {
+                                an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+                                b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+                                b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+                            if (q < 3 && !(ablate & 16)) { a = an; b0 = b0n; b1 = b1n; }
+                        }
+                        if (more && !(ablate & 1)) {
+                            float* wnext = wbuf + ((tap + 1) & 1) * (NT * LDSROW);
+                            *reinterpret_cast<float4*>(wnext + wrow * LDSROW + wc4) = r0;
+                            *reinterpret_cast<float4*>(wnext + (wrow + 32) * LDSROW + wc4) = r1;
+                            __syncthreads();
+                        }
+                    }
+            if (lastChunk && (ablate & 4)) { pos = npos; }
+            if (lastChunk && !(ablate & 4)) {
+                // epilogue of this tile (out_off[slot] stays valid: the next tile's table went to slot^1)
+                const int co0 = pos.n0 + l31, co1 = pos.n0 + 32 + l31;
+                const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
+                const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int off = out_off[slot * MTILE + wave * 32 + row];
+                    if (off < 0) continue;
+                    const size_t o = (size_t)off * g.Cout;
+                    if (co0 < g.Cout) {
+                        float v = acc0[r] + bias0;
+                        if (residual) v += residual[o + co0];
+                        y[o + co0] = v;
+                    }
+                    if (co1 < g.Cout) {
+                        float v = acc1[r] + bias1;
+                        if (residual) v += residual[o + co1];
+                        y[o + co1] = v;
+                    }
+                }
+                pos = npos;
+            }
+        }
+        if (!haveNextTile) break;
+        tile = nextTile;
+        slot ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward-weight (split-K partial slabs)
 // ---------------------------------------------------------------------------------------------
 constexpr int BW_MAXT = 5;       // taps per wave pair
 struct BwGeom {
     ConvGeom g;
     int tapGroups;               // groups of <=10 (kh,kw) taps per kd plane
+    int lTW, lTH;                // log2 of the (power-of-two) tile extents
     int tilesPerSplit, MT;       // voxel tiles per grid.y block, total voxel tiles
 };
 
@@ -250,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(const float* __
     int* ysrc = xsrc + HVp;                                // [128] tile voxel -> output voxel or -1
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int l31 = lane & 31, h = lane >> 5;
     const int coHalf = wave & 1, tapHalf = wave >> 1;
 
@@ -346,24 +571,25 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(const float* __
         }
         __syncthreads();
         if (ntap > 0) {
-            // K loop over voxel pairs; lane half h takes voxel 2s+h
+            // K loop over voxel pairs; lane half h takes voxel 2s+h.  Tile extents are powers of two, so the
+            // voxel -> halo index map is shifts/masks.  All BW_MAXT MFMAs are issued unconditionally (taps beyond
+            // ntap alias tap 0 and are discarded at the end): no branch sits between the LDS reads and the MFMAs.
             const float* ap0 = dyt + coHalf * 32 + l31;
-            for (int td = 0; td < g.TD; ++td)
-                for (int th = 0; th < g.TH; ++th) {
-                    const int vrow = (td * g.TH + th) * g.TW;
-                    const float* bprow = xh + ((td * HHp + th) * HWp) * CK + l31;
-                    for (int tw = 0; tw < g.TW; tw += 2) {
-                        const float a = ap0[(vrow + tw + h) * NT];
-                        const float* bp = bprow + (tw + h) * CK;
+            const float* bp0 = xh + l31;
+            const int mTW = g.TW - 1, mTH = g.TH - 1, sTH = bg.lTW, sTD = bg.lTW + bg.lTH;
+#pragma unroll 4
+            for (int s2 = 0; s2 < MTILE / 2; ++s2) {
+                const int v = 2 * s2 + h;
+                const int tw = v & mTW, th = (v >> sTH) & mTH, td = v >> sTD;
+                const float a = ap0[v * NT];
+                const float* bp = bp0 + ((td * HHp + th) * HWp + tw) * CK;
+                float bv[BW_MAXT];
 #pragma unroll
-                        for (int t = 0; t < BW_MAXT; ++t) {
-                            if (t < ntap) {
-                                const float bv = bp[tapoff[t]];
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
+                for (int t = 0; t < BW_MAXT; ++t) bv[t] = bp[tapoff[t]];
+#pragma unroll
+                for (int t = 0; t < BW_MAXT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
+            }
         }
     }
 
@@ -525,9 +751,34 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
     if (rc) return rc;
     DIQT_REQUIRE(aligned16(packed), DIQT_E_ALIGN, "conv3d_fwd: packed weights must be 16-byte aligned");
     const bool vec4 = (Cin % 4 == 0) && aligned16(x);
-    const size_t lds = ((size_t)g.HD * g.HH * g.HWd * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int);
-    DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_fwd: halo tile needs %zu B of LDS", lds);
+    const int HV = g.HD * g.HH * g.HWd;
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
+    // opt-in: measured equal to the one-tile-per-workgroup kernel on MI355X (118 vs 121 TFLOP/s, profiles/r01_conv_ablation.md)
+    static const bool persist_ok = [] { const char* e = getenv("DIQT_CONV_PERSIST"); return e && e[0] == '1'; }();
+    if (persist_ok && HV * 8 <= 256 * 13) {
+        const size_t plds = ((size_t)HV * (LDSROW + 2) + 2 * NT * LDSROW) * sizeof(float) + 2 * MTILE * sizeof(int);
+        if (plds <= 160 * 1024) {
+            const int nr = (HV * 8 <= 256 * 4) ? 4 : 13;
+            void (*pk)(const float*, const float*, const float*, const float*, float*, ConvGeom, int, int) =
+                nr == 4 ? (vec4 ? conv_fwd_persist_kernel<true, 4> : conv_fwd_persist_kernel<false, 4>)
+                        : (vec4 ? conv_fwd_persist_kernel<true, 13> : conv_fwd_persist_kernel<false, 13>);
+            if (plds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+                DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            }
+            // resident workgroups: 2 per CU when the LDS image allows it, else 1; always a multiple of 8 (XCDs)
+            const unsigned perCu = plds <= 80 * 1024 ? 2u : 1u;
+            unsigned grid = 256u * perCu;
+            const unsigned need = (nwg + kNumXcd - 1) / kNumXcd * kNumXcd;
+            if (grid > need) grid = need;
+            static const int ablate = [] { const char* e = getenv("DIQT_CONV_ABLATE"); return e ? atoi(e) : 0; }();   // timing-only diagnostics
+            hipLaunchKernelGGL(pk, dim3(grid), dim3(256), plds, (hipStream_t)stream, x, packed, bias, residual, y, g, (int)nwg, ablate);
+            return check_launch("conv3d_fwd(persistent)");
+        }
+    }
+    const size_t lds = ((size_t)HV * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int);
+    DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_fwd: halo tile needs %zu B of LDS", lds);
     auto kern = vec4 ? conv_fwd_kernel<true> : conv_fwd_kernel<false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -544,6 +795,9 @@ static int bw_plan(BwGeom& bg, int B, int D, int H, int W, int Cin, int Cout, in
     if (rc) return rc;
     const ConvGeom& g = bg.g;
     bg.tapGroups = cdiv(kh * kw, 2 * BW_MAXT);
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    bg.lTW = ilog2(g.TW); bg.lTH = ilog2(g.TH);
+    DIQT_REQUIRE((1 << bg.lTW) == g.TW && (1 << bg.lTH) == g.TH, DIQT_E_UNSUPPORTED, "conv3d_bwd_weight: tile not a power of two");
     bg.MT = g.B * g.tilesD * g.tilesH * g.tilesW;
     const int gx = g.nChunks * g.nNt * g.kd * bg.tapGroups;
     // 2 workgroups fit a CU (LDS): aim at ONE full round of 512 resident workgroups, never 1.01 rounds

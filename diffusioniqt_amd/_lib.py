@@ -25,21 +25,21 @@ PROTOTYPES = {
     "diqt_last_error": (c_char_p, []),
     "diqt_conv_packed_elems": (Z, [I, I, I, I, I]),
     "diqt_conv_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),
-    "diqt_conv3d_fwd": (I, [P, P, P, P, P] + [I] * 12 + [P]),
-    "diqt_conv3d_lds_bytes": (L, [I] * 9),
+    "diqt_conv3d_fwd": (I, [P, P, P, P, P] + [I] * 15 + [P]),
+    "diqt_conv3d_lds_bytes": (L, [I] * 12),
     "diqt_trilinear_up_fwd": (I, [P, P, I, I, I, I, I, I, P]),
     "diqt_trilinear_up_bwd": (I, [P, P, I, I, I, I, I, I, P]),
-    "diqt_conv3d_bwd_weight_workspace_bytes": (Z, [I] * 12),
-    "diqt_conv3d_bwd_weight": (I, [P, P, P, P, P, Z] + [I] * 12 + [P]),
-    "diqt_conv3d_direct_fwd": (I, [P, P, P, P] + [I] * 16 + [P]),
-    "diqt_conv3d_direct_bwd_data": (I, [P, P, P] + [I] * 16 + [P]),
-    "diqt_conv3d_direct_bwd_weight": (I, [P, P, P, P] + [I] * 16 + [P]),
+    "diqt_conv3d_bwd_weight_workspace_bytes": (Z, [I] * 15),
+    "diqt_conv3d_bwd_weight": (I, [P, P, P, P, P, Z] + [I] * 15 + [P]),
+    "diqt_conv3d_direct_fwd": (I, [P, P, P, P] + [I] * 19 + [P]),
+    "diqt_conv3d_direct_bwd_data": (I, [P, P, P] + [I] * 19 + [P]),
+    "diqt_conv3d_direct_bwd_weight": (I, [P, P, P, P] + [I] * 19 + [P]),
     "diqt_reduce_workspace_bytes": (Z, [I, I]),
     "diqt_groupnorm_stats": (I, [P, P, P, P, Z, I, I, I, I, F, P]),
     "diqt_gn_act_fwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "diqt_gn_act_bwd": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
-    "diqt_chan_layernorm_fwd": (I, [P, P, P, P, P, I, I, F, P]),
-    "diqt_chan_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, P]),
+    "diqt_chan_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "diqt_chan_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, P]),
     "diqt_act_fwd": (I, [P, P, Z, I, P]),
     "diqt_act_bwd": (I, [P, P, P, Z, I, P]),
     "diqt_learned_sinu_fwd": (I, [P, P, P, I, I, P]),
@@ -65,6 +65,12 @@ PROTOTYPES = {
     "diqt_ema_lerp": (I, [P, P, Z, F, P]),
     "diqt_softmax_fwd": (I, [P, P, Z, I, I, F, P]),
     "diqt_softmax_bwd": (I, [P, P, P, Z, I, I, F, P]),
+    "diqt_space_to_depth_nd": (I, [P, P] + [I] * 8 + [P]),
+    "diqt_depth_to_space_nd": (I, [P, P] + [I] * 8 + [P]),
+    "diqt_transpose_mid": (I, [P, P, I, I, I, I, P]),
+    "diqt_nearest_resize": (I, [P, P] + [I] * 8 + [P]),
+    "diqt_attn_softmax_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "diqt_attn_softmax_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "diqt_bgemm": (I, [P, P, P, I, I, I, I, I, I, L, L, L, I, I, I, F, F, P]),
 }
 

@@ -117,13 +117,14 @@ __global__ __launch_bounds__(256) void direct_bwd_weight_kernel(const float* __r
 }
 
 static int dgeom(DGeom& g, int B, int D, int H, int W, int Cin, int Cout, int groups, int kd, int kh, int kw, int sd,
-                 int sh, int sw, int pd, int ph, int pw) {
+                 int sh, int sw, int pd, int ph, int pw, int epd, int eph, int epw) {
     DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && groups > 0, DIQT_E_SHAPE, "conv3d_direct: bad extent");
     DIQT_REQUIRE(Cin % groups == 0 && Cout % groups == 0, DIQT_E_SHAPE, "conv3d_direct: channels not divisible by groups");
     DIQT_REQUIRE(kd > 0 && kh > 0 && kw > 0 && sd > 0 && sh > 0 && sw > 0 && pd >= 0 && ph >= 0 && pw >= 0, DIQT_E_SHAPE,
                  "conv3d_direct: bad filter/stride/pad");
     g = DGeom{B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw,
-              (D + 2 * pd - kd) / sd + 1, (H + 2 * ph - kh) / sh + 1, (W + 2 * pw - kw) / sw + 1};
+              (D + 2 * pd + epd - kd) / sd + 1, (H + 2 * ph + eph - kh) / sh + 1, (W + 2 * pw + epw - kw) / sw + 1};
+    DIQT_REQUIRE(pd + epd >= 0 && ph + eph >= 0 && pw + epw >= 0, DIQT_E_SHAPE, "conv3d_direct: negative high-side pad");
     DIQT_REQUIRE(g.Do > 0 && g.Ho > 0 && g.Wo > 0, DIQT_E_SHAPE, "conv3d_direct: empty output");
     return DIQT_OK;
 }
@@ -132,10 +133,10 @@ static int dgeom(DGeom& g, int B, int D, int H, int W, int Cin, int Cout, int gr
 using namespace diqt;
 extern "C" int diqt_conv3d_direct_fwd(const float* x, const float* w, const float* bias, float* y, int B, int D, int H,
                                       int W, int Cin, int Cout, int groups, int kd, int kh, int kw, int sd, int sh,
-                                      int sw, int pd, int ph, int pw, void* stream) {
+                                      int sw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
     DIQT_REQUIRE(x && w && y, DIQT_E_ALIGN, "conv3d_direct_fwd: null pointer");
     DGeom g;
-    int rc = dgeom(g, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw);
+    int rc = dgeom(g, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw, epd, eph, epw);
     if (rc) return rc;
     const size_t total = (size_t)g.B * g.Do * g.Ho * g.Wo * g.Cout;
     hipLaunchKernelGGL(direct_fwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, g);
@@ -143,10 +144,10 @@ extern "C" int diqt_conv3d_direct_fwd(const float* x, const float* w, const floa
 }
 extern "C" int diqt_conv3d_direct_bwd_data(const float* dy, const float* w, float* dx, int B, int D, int H, int W,
                                            int Cin, int Cout, int groups, int kd, int kh, int kw, int sd, int sh,
-                                           int sw, int pd, int ph, int pw, void* stream) {
+                                           int sw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
     DIQT_REQUIRE(dy && w && dx, DIQT_E_ALIGN, "conv3d_direct_bwd_data: null pointer");
     DGeom g;
-    int rc = dgeom(g, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw);
+    int rc = dgeom(g, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw, epd, eph, epw);
     if (rc) return rc;
     const size_t total = (size_t)g.B * g.D * g.H * g.W * g.Cin;
     hipLaunchKernelGGL(direct_bwd_data_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream, dy, w, dx, g);
@@ -154,10 +155,10 @@ extern "C" int diqt_conv3d_direct_bwd_data(const float* dy, const float* w, floa
 }
 extern "C" int diqt_conv3d_direct_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int D,
                                              int H, int W, int Cin, int Cout, int groups, int kd, int kh, int kw,
-                                             int sd, int sh, int sw, int pd, int ph, int pw, void* stream) {
+                                             int sd, int sh, int sw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
     DIQT_REQUIRE(x && dy && dw, DIQT_E_ALIGN, "conv3d_direct_bwd_weight: null pointer");
     DGeom g;
-    int rc = dgeom(g, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw);
+    int rc = dgeom(g, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw, epd, eph, epw);
     if (rc) return rc;
     const size_t nW = (size_t)Cout * (Cin / groups) * kd * kh * kw;
     hipStream_t s = (hipStream_t)stream;

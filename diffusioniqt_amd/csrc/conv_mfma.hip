@@ -690,17 +690,18 @@ static void choose_tile(int Do, int Ho, int Wo, int kd, int kh, int kw, int& TD,
 }
 
 static int make_geom(ConvGeom& g, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
-                     int pd, int ph, int pw) {
+                     int pd, int ph, int pw, int epd = 0, int eph = 0, int epw = 0) {
     DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DIQT_E_SHAPE, "conv3d: non-positive extent");
     DIQT_REQUIRE(kd > 0 && kh > 0 && kw > 0 && pd >= 0 && ph >= 0 && pw >= 0, DIQT_E_SHAPE, "conv3d: bad filter/pad");
-    if (kd == 1 && kh == 1 && kw == 1 && pd == 0 && ph == 0 && pw == 0) {   // 1x1x1: flatten all voxels into W
+    DIQT_REQUIRE(pd + epd >= 0 && ph + eph >= 0 && pw + epw >= 0, DIQT_E_SHAPE, "conv3d: negative high-side pad");
+    if (kd == 1 && kh == 1 && kw == 1 && pd == 0 && ph == 0 && pw == 0 && epd == 0 && eph == 0 && epw == 0) {   // 1x1x1: flatten all voxels into W
         const long long rows = (long long)B * D * H * W;
         DIQT_REQUIRE(rows < (1ll << 31), DIQT_E_SHAPE, "conv3d: too many rows");
         B = 1; D = 1; H = 1; W = (int)rows;
     }
     g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
     g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw;
-    g.Do = D + 2 * pd - kd + 1; g.Ho = H + 2 * ph - kh + 1; g.Wo = W + 2 * pw - kw + 1;
+    g.Do = D + 2 * pd + epd - kd + 1; g.Ho = H + 2 * ph + eph - kh + 1; g.Wo = W + 2 * pw + epw - kw + 1;
     DIQT_REQUIRE(g.Do > 0 && g.Ho > 0 && g.Wo > 0, DIQT_E_SHAPE, "conv3d: empty output");
     g.TD = 2; g.TH = 8; g.TW = 8;
     choose_tile(g.Do, g.Ho, g.Wo, kd, kh, kw, g.TD, g.TH, g.TW);
@@ -722,9 +723,10 @@ extern "C" size_t diqt_conv_packed_elems(int Cout, int Cin, int kd, int kh, int 
     return (size_t)cdiv(Cin, CK) * kd * kh * kw * (cdiv(Cout, NT) * NT) * CK;
 }
 
-extern "C" long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, int kw, int pd, int ph, int pw) {
+extern "C" long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, int kw, int pd, int ph, int pw,
+                                           int epd, int eph, int epw) {
     ConvGeom g;
-    if (make_geom(g, 1, D, H, W, 4, 4, kd, kh, kw, pd, ph, pw)) return -1;
+    if (make_geom(g, 1, D, H, W, 4, 4, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return -1;
     return (long long)(((size_t)g.HD * g.HH * g.HWd * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int));
 }
 
@@ -744,10 +746,10 @@ extern "C" int diqt_conv_pack_weight(const float* w, float* packed, int Cout, in
 
 extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
                                float* y, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
-                               int pd, int ph, int pw, void* stream) {
+                               int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
     DIQT_REQUIRE(x && packed && y, DIQT_E_ALIGN, "conv3d_fwd: null pointer");
     ConvGeom g;
-    int rc = make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw);
+    int rc = make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
     if (rc) return rc;
     DIQT_REQUIRE(aligned16(packed), DIQT_E_ALIGN, "conv3d_fwd: packed weights must be 16-byte aligned");
     const bool vec4 = (Cin % 4 == 0) && aligned16(x);
@@ -790,8 +792,8 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
 }
 
 static int bw_plan(BwGeom& bg, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
-                   int ph, int pw, int& ksplit) {
-    int rc = make_geom(bg.g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw);
+                   int ph, int pw, int epd, int eph, int epw, int& ksplit) {
+    int rc = make_geom(bg.g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
     if (rc) return rc;
     const ConvGeom& g = bg.g;
     bg.tapGroups = cdiv(kh * kw, 2 * BW_MAXT);
@@ -810,10 +812,11 @@ static int bw_plan(BwGeom& bg, int B, int D, int H, int W, int Cin, int Cout, in
 }
 
 extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd,
-                                                         int kh, int kw, int pd, int ph, int pw) {
+                                                         int kh, int kw, int pd, int ph, int pw, int epd, int eph,
+                                                         int epw) {
     BwGeom bg;
     int ksplit;
-    if (bw_plan(bg, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, ksplit)) return 0;
+    if (bw_plan(bg, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, ksplit)) return 0;
     const size_t slab = (size_t)bg.g.nChunks * kd * kh * kw * bg.g.CoutPad * CK * sizeof(float);
     const size_t colsum = (size_t)1024 * Cout * sizeof(float);
     const size_t need = (size_t)ksplit * slab;
@@ -822,15 +825,15 @@ extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, in
 
 extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, void* workspace,
                                       size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout, int kd,
-                                      int kh, int kw, int pd, int ph, int pw, void* stream) {
+                                      int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
     DIQT_REQUIRE(x && dy && dw && workspace, DIQT_E_ALIGN, "conv3d_bwd_weight: null pointer");
     BwGeom bg;
     int ksplit;
-    int rc = bw_plan(bg, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, ksplit);
+    int rc = bw_plan(bg, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, ksplit);
     if (rc) return rc;
     const ConvGeom& g = bg.g;
     const int T = kd * kh * kw;
-    const size_t need = diqt_conv3d_bwd_weight_workspace_bytes(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw);
+    const size_t need = diqt_conv3d_bwd_weight_workspace_bytes(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
     DIQT_REQUIRE(workspace_bytes >= need, DIQT_E_WORKSPACE, "conv3d_bwd_weight: workspace %zu < %zu", workspace_bytes, need);
     DIQT_REQUIRE(aligned16(workspace), DIQT_E_ALIGN, "conv3d_bwd_weight: workspace must be 16-byte aligned");
     const bool vec4 = (Cin % 4 == 0) && aligned16(x) && aligned16(dy);

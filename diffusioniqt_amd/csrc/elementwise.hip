@@ -265,8 +265,9 @@ __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // one wave per row; C <= 64*16
 __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                          float* __restrict__ y, float* __restrict__ mean,
-                                                          float* __restrict__ rstd, int rows, int C, float eps) {
+                                                          const float* __restrict__ bb, float* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                          int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb) {
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const float* __restric
         float v = 0.f;
         for (int c = lane; c < C; c += 64) { const float d = xr[c] - m; v += d * d; }
         const float rs = rsqrtf(wave_sum(v) / C + eps);
-        for (int c = lane; c < C; c += 64) y[(size_t)r * C + c] = (xr[c] - m) * rs * g[c];
+        for (int c = lane; c < C; c += 64) y[(size_t)r * C + c] = (xr[c] - m) * rs * g[c] + (bb ? bb[c] : 0.f);
         if (lane == 0) { if (mean) mean[r] = m; if (rstd) rstd[r] = rs; }
     }
 }
@@ -759,6 +760,103 @@ __global__ __launch_bounds__(256) void softmax_col_bwd_kernel(const float* __res
 }
 
 
+// generic (sd,sh,sw) in {1,2}^3 pixel (un)shuffle; iterates the fine ("space") side, c fastest
+__global__ __launch_bounds__(256) void shuffle_nd_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int D,
+                                                         int H, int W, int C, int sd, int sh, int sw, int toSpace) {
+    const int S = sd * sh * sw;
+    const size_t total = (size_t)B * S * D * H * W * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int w2 = (int)(r % (sw * W)); r /= sw * W;
+        const int h2 = (int)(r % (sh * H)); r /= sh * H;
+        const int d2 = (int)(r % (sd * D));
+        const int b = (int)(r / (sd * D));
+        const int s = ((d2 % sd) * sh + (h2 % sh)) * sw + (w2 % sw);
+        const size_t j = ((((size_t)b * D + d2 / sd) * H + h2 / sh) * W + w2 / sw) * ((size_t)S * C) + (size_t)c * S + s;
+        if (toSpace) dst[i] = src[j]; else dst[j] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_mid_kernel(const float* __restrict__ x, float* __restrict__ y, int A, int M,
+                                                            int N, int C) {
+    const size_t total = (size_t)A * M * N * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int m = (int)(r % M); r /= M;       // output index order: [A][N][M][C]
+        const int n = (int)(r % N);
+        const int a = (int)(r / N);
+        y[i] = x[(((size_t)a * M + m) * N + n) * C + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void nearest_resize_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int D,
+                                                             int H, int W, int C, int Do, int Ho, int Wo) {
+    const size_t total = (size_t)B * Do * Ho * Wo * C;
+    const float fd = (float)D / Do, fh = (float)H / Ho, fw = (float)W / Wo;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int od = (int)(r % Do);
+        const int b = (int)(r / Do);
+        const int id = min((int)floorf(od * fd), D - 1), ih = min((int)floorf(oh * fh), H - 1), iw = min((int)floorf(ow * fw), W - 1);
+        y[i] = x[((((size_t)b * D + id) * H + ih) * W + iw) * C + c];
+    }
+}
+
+// multi-query attention soft-max: one wave per (g, i, head) row of length M = n_extra + n_self
+__global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(const float* __restrict__ sim, const float* __restrict__ rel,
+                                                               const float* __restrict__ null_bias, float* __restrict__ p,
+                                                               size_t rows, int n, int h, int E, int ns, int causal) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, M = E + ns;
+    for (size_t r = blockIdx.x * (size_t)wpb + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * wpb) {
+        const int hh = (int)(r % h), i = (int)((r / h) % n);
+        const float* sr = sim + r * M;
+        float* pr = p + r * M;
+        auto score = [&](int j) -> float {
+            float s = sr[j];
+            if (j >= E) {
+                const int jj = j - E;
+                if (causal && jj > i) return -INFINITY;
+                if (rel) s += rel[(size_t)(i - jj + ns - 1) * h + hh];
+            } else if (j == E - 1 && null_bias) s += null_bias[hh];
+            return s;
+        };
+        float mx = -INFINITY;
+        for (int j = lane; j < M; j += 64) mx = fmaxf(mx, score(j));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int j = lane; j < M; j += 64) sum += __expf(score(j) - mx);
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int j = lane; j < M; j += 64) pr[j] = __expf(score(j) - mx) * inv;
+    }
+}
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                               float* __restrict__ dsim, float* __restrict__ drel,
+                                                               float* __restrict__ dnull, size_t rows, int n, int h, int E,
+                                                               int ns, int causal) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, M = E + ns;
+    for (size_t r = blockIdx.x * (size_t)wpb + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * wpb) {
+        const int hh = (int)(r % h), i = (int)((r / h) % n);
+        float s = 0.f;
+        for (int j = lane; j < M; j += 64) s += p[r * M + j] * dp[r * M + j];
+        s = wave_sum(s);
+        for (int j = lane; j < M; j += 64) {
+            const float d = p[r * M + j] * (dp[r * M + j] - s);      // zero where masked (p == 0)
+            dsim[r * M + j] = d;
+            if (j >= E) {
+                const int jj = j - E;
+                if (drel && !(causal && jj > i)) atomicAdd(drel + (size_t)(i - jj + ns - 1) * h + hh, d);
+            } else if (j == E - 1 && dnull) atomicAdd(dnull + hh, d);
+        }
+    }
+}
+
 __global__ void learned_sinu_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w, float* __restrict__ out,
                                         int B, int half) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -873,17 +971,17 @@ extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mea
     return check_launch("gn_act_bwd/dx");
 }
 
-extern "C" int diqt_chan_layernorm_fwd(const float* x, const float* g, float* y, float* mean, float* rstd, int rows,
-                                       int C, float eps, void* stream) {
+extern "C" int diqt_chan_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean,
+                                       float* rstd, int rows, int C, float eps, void* stream) {
     DIQT_REQUIRE(x && g && y, DIQT_E_ALIGN, "chan_layernorm_fwd: null pointer");
     DIQT_REQUIRE(rows > 0 && C > 0, DIQT_E_SHAPE, "chan_layernorm_fwd: bad shape");
-    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3(grid_for((size_t)rows, 4, 4096)), dim3(256), 0, STREAM, x, g, y, mean, rstd,
+    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3(grid_for((size_t)rows, 4, 4096)), dim3(256), 0, STREAM, x, g, b, y, mean, rstd,
                        rows, C, eps);
     return check_launch("chan_layernorm_fwd");
 }
 
 extern "C" int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean,
-                                       const float* rstd, float* dx, float* dg, void* workspace,
+                                       const float* rstd, float* dx, float* dg, float* db, void* workspace,
                                        size_t workspace_bytes, int rows, int C, void* stream) {
     DIQT_REQUIRE(x && dy && g && mean && rstd && dx, DIQT_E_ALIGN, "chan_layernorm_bwd: null pointer");
     DIQT_REQUIRE(rows > 0 && C > 0, DIQT_E_SHAPE, "chan_layernorm_bwd: bad shape");
@@ -900,7 +998,13 @@ extern "C" int diqt_chan_layernorm_bwd(const float* x, const float* dy, const fl
     rc = check_launch("chan_layernorm_bwd/dg");
     if (rc) return rc;
     hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 3) / 4), dim3(256), 0, STREAM, partial, dg, nblk, C, C, 1.f);
-    return check_launch("chan_layernorm_bwd/dg-final");
+    rc = check_launch("chan_layernorm_bwd/dg-final");
+    if (rc || !db) return rc;
+    hipLaunchKernelGGL((colreduce_kernel<1, IdentF>), dim3(nblk, 1), dim3(256), 0, STREAM, IdentF{dy}, partial, rows, C);
+    rc = check_launch("chan_layernorm_bwd/db");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 3) / 4), dim3(256), 0, STREAM, partial, db, nblk, C, C, 1.f);
+    return check_launch("chan_layernorm_bwd/db-final");
 }
 
 extern "C" int diqt_act_fwd(const float* x, float* y, size_t n, int act, void* stream) {
@@ -1149,4 +1253,56 @@ extern "C" int diqt_trilinear_up_bwd(const float* dy, float* dx, int B, int D, i
     const size_t total = (size_t)B * D * H * W * C * scale * scale * scale;
     hipLaunchKernelGGL(trilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, dy, dx, B, D, H, W, C, scale, 1);
     return check_launch("trilinear_up_bwd");
+}
+
+static int shuffle_nd(const float* x, float* y, int B, int D, int H, int W, int C, int sd, int sh, int sw, int toSpace,
+                      void* stream, const char* what) {
+    DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "%s: null pointer", what);
+    DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, DIQT_E_SHAPE, "%s: bad shape", what);
+    DIQT_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), DIQT_E_UNSUPPORTED, "%s: factors must be 1 or 2", what);
+    const size_t total = (size_t)B * sd * sh * sw * D * H * W * C;
+    hipLaunchKernelGGL(shuffle_nd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, x, y, B, D, H, W, C, sd, sh, sw, toSpace);
+    return check_launch(what);
+}
+extern "C" int diqt_space_to_depth_nd(const float* x, float* y, int B, int D, int H, int W, int C, int sd, int sh, int sw,
+                                      void* stream) {
+    return shuffle_nd(x, y, B, D, H, W, C, sd, sh, sw, 0, stream, "space_to_depth_nd");
+}
+extern "C" int diqt_depth_to_space_nd(const float* x, float* y, int B, int D, int H, int W, int C, int sd, int sh, int sw,
+                                      void* stream) {
+    return shuffle_nd(x, y, B, D, H, W, C, sd, sh, sw, 1, stream, "depth_to_space_nd");
+}
+extern "C" int diqt_transpose_mid(const float* x, float* y, int A, int M, int N, int C, void* stream) {
+    DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "transpose_mid: null pointer");
+    DIQT_REQUIRE(A > 0 && M > 0 && N > 0 && C > 0, DIQT_E_SHAPE, "transpose_mid: bad shape");
+    hipLaunchKernelGGL(transpose_mid_kernel, dim3(grid_for((size_t)A * M * N * C, 256)), dim3(256), 0, STREAM, x, y, A, M, N, C);
+    return check_launch("transpose_mid");
+}
+extern "C" int diqt_nearest_resize(const float* x, float* y, int B, int D, int H, int W, int C, int Do, int Ho, int Wo,
+                                   void* stream) {
+    DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "nearest_resize: null pointer");
+    DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && Do > 0 && Ho > 0 && Wo > 0, DIQT_E_SHAPE, "nearest_resize: bad shape");
+    hipLaunchKernelGGL(nearest_resize_kernel, dim3(grid_for((size_t)B * Do * Ho * Wo * C, 256)), dim3(256), 0, STREAM, x, y, B,
+                       D, H, W, C, Do, Ho, Wo);
+    return check_launch("nearest_resize");
+}
+extern "C" int diqt_attn_softmax_fwd(const float* sim, const float* rel, const float* null_bias, float* p, int G, int n,
+                                     int h, int n_extra, int n_self, int causal, void* stream) {
+    DIQT_REQUIRE(sim && p, DIQT_E_ALIGN, "attn_softmax_fwd: null pointer");
+    DIQT_REQUIRE(G > 0 && n > 0 && h > 0 && n_extra >= 0 && n_self >= 0 && n_extra + n_self > 0, DIQT_E_SHAPE, "attn_softmax_fwd: bad shape");
+    DIQT_REQUIRE(!(causal || rel) || n_self == n, DIQT_E_SHAPE, "attn_softmax_fwd: causal / relative bias need n_self == n");
+    DIQT_REQUIRE(!null_bias || n_extra >= 1, DIQT_E_SHAPE, "attn_softmax_fwd: null bias without a null key");
+    const size_t rows = (size_t)G * n * h;
+    hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3(grid_for(rows, 4, 16384)), dim3(256), 0, STREAM, sim, rel, null_bias, p, rows,
+                       n, h, n_extra, n_self, causal);
+    return check_launch("attn_softmax_fwd");
+}
+extern "C" int diqt_attn_softmax_bwd(const float* p, const float* dp, float* dsim, float* drel, float* dnull_bias, int G,
+                                     int n, int h, int n_extra, int n_self, int causal, void* stream) {
+    DIQT_REQUIRE(p && dp && dsim, DIQT_E_ALIGN, "attn_softmax_bwd: null pointer");
+    DIQT_REQUIRE(G > 0 && n > 0 && h > 0 && n_extra >= 0 && n_self >= 0 && n_extra + n_self > 0, DIQT_E_SHAPE, "attn_softmax_bwd: bad shape");
+    const size_t rows = (size_t)G * n * h;
+    hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3(grid_for(rows, 4, 16384)), dim3(256), 0, STREAM, p, dp, dsim, drel, dnull_bias,
+                       rows, n, h, n_extra, n_self, causal);
+    return check_launch("attn_softmax_bwd");
 }

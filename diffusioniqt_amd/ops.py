@@ -101,16 +101,18 @@ def _packed(weight5, mode):
     return packed
 
 
-def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad):
+def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0)):
     B, D, H, W, Cin = x5.shape
     kd, kh, kw = k
     pd, ph, pw = pad
-    Do, Ho, Wo = D + 2 * pd - kd + 1, H + 2 * ph - kh + 1, W + 2 * pw - kw + 1
+    epd, eph, epw = epad
+    Do, Ho, Wo = D + 2 * pd + epd - kd + 1, H + 2 * ph + eph - kh + 1, W + 2 * pw + epw - kw + 1
     y = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=x5.device)
     if TIMER.enabled:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-    _lib.call("diqt_conv3d_fwd", x5, packed, bias, residual, y, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, _stream())
+    _lib.call("diqt_conv3d_fwd", x5, packed, bias, residual, y, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw,
+              _stream())
     if TIMER.enabled:
         e.record()
         TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_kernel"))
@@ -119,13 +121,14 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad):
 
 class _Conv3dFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, residual):
+    def forward(ctx, x, weight, bias, pad, residual, epad=(0, 0, 0)):
         _chk(x, weight, bias, residual)
         Cout, Cin, kd, kh, kw = weight.shape
         assert x.dim() == 5 and x.shape[-1] == Cin, f"conv3d: x {tuple(x.shape)} vs weight {tuple(weight.shape)}"
-        y = _conv_fwd_raw(x, _packed(weight, 0), bias, residual, Cout, (kd, kh, kw), pad)
+        y = _conv_fwd_raw(x, _packed(weight, 0), bias, residual, Cout, (kd, kh, kw), pad, epad)
         ctx.save_for_backward(x, weight)
         ctx.pad = pad
+        ctx.epad = epad
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         return y
@@ -136,61 +139,65 @@ class _Conv3dFn(Function):
         dy = dy.contiguous()
         Cout, Cin, kd, kh, kw = weight.shape
         pd, ph, pw = ctx.pad
+        epd, eph, epw = ctx.epad
         B, D, H, W, _ = x.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
+            # dX = conv(dY, flipped W): low pad' = k-1-pad_lo, high pad' = k-1-pad_hi  ->  epad' = -epad
             dx = _conv_fwd_raw(dy, _packed(weight, 1), None, None, Cin, (kd, kh, kw),
-                               (kd - 1 - pd, kh - 1 - ph, kw - 1 - pw))
+                               (kd - 1 - pd, kh - 1 - ph, kw - 1 - pw), (-epd, -eph, -epw))
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            n = _lib.query("diqt_conv3d_bwd_weight_workspace_bytes", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw)
+            n = _lib.query("diqt_conv3d_bwd_weight_workspace_bytes", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
             ws = _workspace(n, x.device)
             if TIMER.enabled:
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
             _lib.call("diqt_conv3d_bwd_weight", x, dy, dw, db, ws, n, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw,
-                      _stream())
+                      epd, eph, epw, _stream())
             if TIMER.enabled:
                 e.record()
                 Do, Ho, Wo = dy.shape[1:4]
                 TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_bwd_weight_kernel"))
-        return dx, dw, db, None, (dy if ctx.has_res else None)
+        return dx, dw, db, None, (dy if ctx.has_res else None), None
 
 
-def conv3d(x, weight, bias=None, padding=(0, 0, 0), residual=None):
+def conv3d(x, weight, bias=None, padding=(0, 0, 0), residual=None, extra_pad=(0, 0, 0)):
     """Stride-1 conv on channels-last x[B,D,H,W,Cin] with an OIDHW weight (MFMA implicit GEMM).
     Filters whose halo tile cannot fit the 160 KiB LDS (e.g. 15^3 cross-embed taps) take the direct kernel."""
     if isinstance(padding, int):
         padding = (padding,) * 3
     padding = tuple(int(p) for p in padding)
+    extra_pad = tuple(int(p) for p in extra_pad)
     _, D, H, W, _ = x.shape
     kd, kh, kw = weight.shape[2:]
-    if _lib.query("diqt_conv3d_lds_bytes", D, H, W, kd, kh, kw, *padding) > 160 * 1024:
-        y = _ConvDirectFn.apply(x, weight, bias, (1, 1, 1), padding, 1)
+    if _lib.query("diqt_conv3d_lds_bytes", D, H, W, kd, kh, kw, *padding, *extra_pad) > 160 * 1024:
+        y = _ConvDirectFn.apply(x, weight, bias, (1, 1, 1), padding, 1, extra_pad)
         return y if residual is None else add(y, residual)
-    return _Conv3dFn.apply(x, weight, bias, padding, residual)
+    return _Conv3dFn.apply(x, weight, bias, padding, residual, extra_pad)
 
 
 def linear(x, weight, bias=None):
     """x[..., Cin] @ weight[Cout, Cin]^T + bias through the same MFMA kernel (1x1x1 conv over rows)."""
     Cout, Cin = weight.shape
     lead = x.shape[:-1]
-    y = _Conv3dFn.apply(x.reshape(1, 1, 1, -1, Cin), weight.view(Cout, Cin, 1, 1, 1), bias, (0, 0, 0), None)
+    y = _Conv3dFn.apply(x.reshape(1, 1, 1, -1, Cin), weight.view(Cout, Cin, 1, 1, 1), bias, (0, 0, 0), None, (0, 0, 0))
     return y.reshape(*lead, Cout)
 
 
 class _ConvDirectFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, groups):
+    def forward(ctx, x, weight, bias, stride, pad, groups, epad=(0, 0, 0)):
         _chk(x, weight, bias)
         B, D, H, W, Cin = x.shape
         Cout, _, kd, kh, kw = weight.shape
         sd, sh, sw = stride
         pd, ph, pw = pad
-        Do, Ho, Wo = (D + 2 * pd - kd) // sd + 1, (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        epd, eph, epw = epad
+        Do, Ho, Wo = (D + 2 * pd + epd - kd) // sd + 1, (H + 2 * ph + eph - kh) // sh + 1, (W + 2 * pw + epw - kw) // sw + 1
         y = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-        ctx.geom = (B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw)
+        ctx.geom = (B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw, epd, eph, epw)
         _lib.call("diqt_conv3d_direct_fwd", x, weight, bias, y, *ctx.geom, _stream())
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -208,12 +215,12 @@ class _ConvDirectFn(Function):
             dw = torch.empty_like(weight)
             db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if ctx.has_bias else None
             _lib.call("diqt_conv3d_direct_bwd_weight", x, dy, dw, db, *ctx.geom, _stream())
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv3d_direct(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), groups=1):
+def conv3d_direct(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), groups=1, extra_pad=(0, 0, 0)):
     t3 = lambda v: (v,) * 3 if isinstance(v, int) else tuple(v)
-    return _ConvDirectFn.apply(x, weight, bias, t3(stride), t3(padding), int(groups))
+    return _ConvDirectFn.apply(x, weight, bias, t3(stride), t3(padding), int(groups), t3(extra_pad))
 
 
 # --------------------------------------------------------------------------------------------
@@ -295,15 +302,16 @@ def mish(x):
 
 class _ChanLayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, g, eps):
-        _chk(x, g)
+    def forward(ctx, x, g, b, eps):
+        _chk(x, g, b)
         C = x.shape[-1]
         rows = x.numel() // C
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        _lib.call("diqt_chan_layernorm_fwd", x, g, y, mean, rstd, rows, C, float(eps), _stream())
+        _lib.call("diqt_chan_layernorm_fwd", x, g, b, y, mean, rstd, rows, C, float(eps), _stream())
         ctx.save_for_backward(x, g, mean, rstd)
+        ctx.has_bias = b is not None
         return y
 
     @staticmethod
@@ -313,14 +321,16 @@ class _ChanLayerNormFn(Function):
         rows = x.numel() // C
         dx = torch.empty_like(x)
         dg = torch.empty_like(g)
+        db = torch.empty_like(g) if ctx.has_bias else None
         ws, n = _reduce_ws(1, C, x.device)
-        _lib.call("diqt_chan_layernorm_bwd", x, dy.contiguous(), g, mean, rstd, dx, dg, ws, n, rows, C, _stream())
-        return dx, dg, None
+        _lib.call("diqt_chan_layernorm_bwd", x, dy.contiguous(), g, mean, rstd, dx, dg, db, ws, n, rows, C, _stream())
+        return dx, dg, db, None
 
 
-def chan_layernorm(x, g, eps=1e-5):
-    """LayerNorm over the channel (last) axis, gain only; g is any tensor with C elements."""
-    return _ChanLayerNormFn.apply(x, g.reshape(-1), eps).view_as(x)
+def chan_layernorm(x, g, eps=1e-5, bias=None):
+    """LayerNorm over the channel (last) axis; g (and the optional bias) are any tensors with C elements."""
+    y = _ChanLayerNormFn.apply(x.contiguous(), g.reshape(-1), bias.reshape(-1) if bias is not None else None, eps)
+    return y.view(x.shape)
 
 
 # --------------------------------------------------------------------------------------------
@@ -606,21 +616,22 @@ def softmax(x, dim, scale=1.0):
     return _SoftmaxFn.apply(x, outer, x.shape[dim], inner, scale)
 
 
-def _bgemm_strided(A, Bm, C, g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha):
-    _lib.call("diqt_bgemm", A, Bm, C, g, M, N, K, int(tA), int(tB), sA, sB, sC, lda, ldb, ldc, float(alpha), 0.0,
-              _stream())
+def _bgemm_strided(A, Bm, C, g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha, oA=0, oB=0, oC=0):
+    _lib.call("diqt_bgemm", A.data_ptr() + 4 * oA, Bm.data_ptr() + 4 * oB, C.data_ptr() + 4 * oC, g, M, N, K, int(tA), int(tB),
+              sA, sB, sC, lda, ldb, ldc, float(alpha), 0.0, _stream())
 
 
 class _BmmStridedFn(Function):
-    """C[g] = alpha * op(A[g]) op(B[g]) with explicit batch strides / leading dimensions, so attention heads
-    are addressed inside channels-last [tokens, heads*dim] tensors without transposing copies.
-    spec = (g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha, out_shape)."""
+    """C[g] = alpha * op(A[g]) op(B[g]) with explicit batch strides / leading dimensions / element offsets, so attention
+    heads (and the k|v halves of a fused projection) are addressed inside channels-last tensors without copies.
+    spec = (g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha, out_shape[, offA, offB])."""
     @staticmethod
     def forward(ctx, A, Bm, spec):
         _chk(A, Bm)
-        g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha, out_shape = spec
+        g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha, out_shape = spec[:14]
+        oA, oB = (spec[14], spec[15]) if len(spec) > 14 else (0, 0)
         C = torch.empty(out_shape, dtype=torch.float32, device=A.device)
-        _bgemm_strided(A, Bm, C, g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha)
+        _bgemm_strided(A, Bm, C, g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha, oA, oB)
         ctx.save_for_backward(A, Bm)
         ctx.spec = spec
         return C
@@ -628,21 +639,25 @@ class _BmmStridedFn(Function):
     @staticmethod
     def backward(ctx, dC):
         A, Bm = ctx.saved_tensors
-        g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha, _ = ctx.spec
+        spec = ctx.spec
+        g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha, _ = spec[:14]
+        oA, oB = (spec[14], spec[15]) if len(spec) > 14 else (0, 0)
         dC = dC.contiguous()
         dA = dB = None
+        # operands addressed through offsets / interleaved strides cover only part of their tensor: zero-fill then
+        partial_A = oA != 0 or len(spec) > 14
         if ctx.needs_input_grad[0]:
-            dA = torch.empty_like(A)
+            dA = torch.zeros_like(A) if partial_A else torch.empty_like(A)
             if not tA:   # dA[M,K] = a * dC[M,N] op(B)^T
-                _bgemm_strided(dC, Bm, dA, g, M, K, N, False, not tB, sC, ldc, sB, ldb, sA, lda, alpha)
+                _bgemm_strided(dC, Bm, dA, g, M, K, N, False, not tB, sC, ldc, sB, ldb, sA, lda, alpha, 0, oB, oA)
             else:        # A stored [K,M]: dA[K,M] = a * op(B)[K,N] dC^T[N,M]
-                _bgemm_strided(Bm, dC, dA, g, K, M, N, tB, True, sB, ldb, sC, ldc, sA, lda, alpha)
+                _bgemm_strided(Bm, dC, dA, g, K, M, N, tB, True, sB, ldb, sC, ldc, sA, lda, alpha, oB, 0, oA)
         if ctx.needs_input_grad[1]:
-            dB = torch.empty_like(Bm)
+            dB = torch.zeros_like(Bm) if partial_A else torch.empty_like(Bm)
             if not tB:   # dB[K,N] = a * op(A)^T[K,M] dC[M,N]
-                _bgemm_strided(A, dC, dB, g, K, N, M, not tA, False, sA, lda, sC, ldc, sB, ldb, alpha)
+                _bgemm_strided(A, dC, dB, g, K, N, M, not tA, False, sA, lda, sC, ldc, sB, ldb, alpha, oA, 0, oB)
             else:        # B stored [N,K]: dB[N,K] = a * dC^T[N,M] op(A)[M,K]
-                _bgemm_strided(dC, A, dB, g, N, K, M, True, tA, sC, ldc, sA, lda, sB, ldb, alpha)
+                _bgemm_strided(dC, A, dB, g, N, K, M, True, tA, sC, ldc, sA, lda, sB, ldb, alpha, 0, oA, oB)
         return dA, dB, None
 
 
@@ -691,6 +706,149 @@ class _BmmFn(Function):
 
 def bmm(A, Bm, transA=False, transB=False, alpha=1.0):
     return _BmmFn.apply(A.contiguous(), Bm.contiguous(), bool(transA), bool(transB), float(alpha))
+
+
+class _ShuffleNdFn(Function):
+    @staticmethod
+    def forward(ctx, x, factors, to_space):
+        _chk(x)
+        sd, sh, sw = factors
+        S = sd * sh * sw
+        if to_space:
+            B, D, H, W, CS = x.shape
+            C = CS // S
+            y = torch.empty((B, D * sd, H * sh, W * sw, C), dtype=torch.float32, device=x.device)
+            _lib.call("diqt_depth_to_space_nd", x, y, B, D, H, W, C, sd, sh, sw, _stream())
+        else:
+            B, D2, H2, W2, C = x.shape
+            D, H, W = D2 // sd, H2 // sh, W2 // sw
+            y = torch.empty((B, D, H, W, C * S), dtype=torch.float32, device=x.device)
+            _lib.call("diqt_space_to_depth_nd", x, y, B, D, H, W, C, sd, sh, sw, _stream())
+        ctx.cfg = (factors, to_space)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        factors, to_space = ctx.cfg
+        return _ShuffleNdFn.apply(dy.contiguous(), factors, not to_space), None, None
+
+
+def space_to_depth_nd(x, factors):
+    """'b (d sd) (h sh) (w sw) c -> b d h w (c sd sh sw)' for factors in {1,2}."""
+    return _ShuffleNdFn.apply(x.contiguous(), tuple(factors), False)
+
+
+def depth_to_space_nd(x, factors):
+    return _ShuffleNdFn.apply(x.contiguous(), tuple(factors), True)
+
+
+class _TransposeMidFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        A, M, N, C = x.shape
+        y = torch.empty((A, N, M, C), dtype=torch.float32, device=x.device)
+        _lib.call("diqt_transpose_mid", x, y, A, M, N, C, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _TransposeMidFn.apply(dy.contiguous())
+
+
+def transpose_mid(x):
+    """[A, M, N, C] -> [A, N, M, C]."""
+    return _TransposeMidFn.apply(x.contiguous())
+
+
+def nearest_resize(x, size):
+    """F.interpolate(mode='nearest') of a channels-last volume to (Do, Ho, Wo); data preparation, no autograd."""
+    _chk(x)
+    B, D, H, W, C = x.shape
+    Do, Ho, Wo = size
+    y = torch.empty((B, Do, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    _lib.call("diqt_nearest_resize", x, y, B, D, H, W, C, Do, Ho, Wo, _stream())
+    return y
+
+
+class _AttnSoftmaxFn(Function):
+    @staticmethod
+    def forward(ctx, sim, rel, null_bias, n, h, n_extra, n_self, causal):
+        _chk(sim, rel, null_bias)
+        G = sim.numel() // (n * h * (n_extra + n_self))
+        p = torch.empty_like(sim)
+        _lib.call("diqt_attn_softmax_fwd", sim, rel, null_bias, p, G, n, h, n_extra, n_self, int(causal), _stream())
+        ctx.save_for_backward(p)
+        ctx.cfg = (G, n, h, n_extra, n_self, int(causal), rel is not None, null_bias is not None)
+        ctx.shapes = (rel.shape if rel is not None else None, null_bias.shape if null_bias is not None else None)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        G, n, h, n_extra, n_self, causal, has_rel, has_null = ctx.cfg
+        dsim = torch.empty_like(p)
+        drel = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=p.device) if has_rel else None
+        dnull = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=p.device) if has_null else None
+        _lib.call("diqt_attn_softmax_bwd", p, dp.contiguous(), dsim, drel, dnull, G, n, h, n_extra, n_self, causal, _stream())
+        return dsim, drel, dnull, None, None, None, None, None
+
+
+def attn_softmax(sim, rel, null_bias, n, h, n_extra, n_self, causal):
+    """softmax over keys of sim[G, n, h, n_extra + n_self] with T5-style relative bias table rel[2n-1, h] on the self
+    keys, null_bias[h] on the null key (last extra key) and an optional causal mask (imagen_video.py:490-518)."""
+    return _AttnSoftmaxFn.apply(sim.contiguous(), rel, null_bias, n, h, n_extra, n_self, bool(causal))
+
+
+class _GateResidualFn(Function):
+    """y = h * gate[b, c] + res  (GlobalContext gating + residual, imagen_video.py:768-770)."""
+    @staticmethod
+    def forward(ctx, h, gate, res):
+        _chk(h, gate, res)
+        B, C = h.shape[0], h.shape[-1]
+        rows = h.numel() // (B * C)
+        y = torch.empty_like(h)
+        _lib.call("diqt_gate_residual_fwd", h, gate, res, None, 0.0, y, B, rows, C, _stream())
+        ctx.save_for_backward(h, gate)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, gate = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, C = h.shape[0], h.shape[-1]
+        rows = h.numel() // (B * C)
+        s = _stream()
+        dgate = torch.empty_like(gate)
+        ws, n = _reduce_ws(B, C, h.device)
+        _lib.call("diqt_gate_residual_bwd", h, dy, dgate, ws, n, B, rows, C, s)
+        dh = torch.empty_like(h)
+        _lib.call("diqt_gate_residual_fwd", dy, gate, None, None, 0.0, dh, B, rows, C, s)
+        return dh, dgate, (dy if ctx.has_res else None)
+
+
+def gate_residual(h, gate, res=None):
+    return _GateResidualFn.apply(h.contiguous(), gate.contiguous(), res)
+
+
+class _ScaleFn(Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        _chk(x)
+        out = torch.empty_like(x)
+        c0 = torch.full((1,), float(alpha), dtype=torch.float32, device=x.device)
+        _lib.call("diqt_axpby3", x, None, None, c0, None, None, 0.0, 0.0, 0, out, 1, x.numel(), _stream())
+        ctx.alpha = float(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return _ScaleFn.apply(d.contiguous(), ctx.alpha), None
+
+
+def scale(x, alpha):
+    return x if alpha == 1.0 else _ScaleFn.apply(x.contiguous(), alpha)
 
 
 # --------------------------------------------------------------------------------------------

@@ -742,8 +742,10 @@ class ImagenTrainer(nn.Module):
         for chunk_size_frac, (chunked_args, chunked_kwargs) in split_args_and_kwargs(*args, split_size=max_batch_size, **kwargs):
             self._micro_step += 1
             sync = self._is_sync_step()
-            loss, pred, x_noisy, lowres_cond_img_noisy = self.imagen(*chunked_args, unet=self.unet_being_trained,
-                                                                     unet_number=unet_number, **chunked_kwargs)
+            out = self.imagen(*chunked_args, unet=self.unet_being_trained, unet_number=unet_number, **chunked_kwargs)
+            # Imagen.forward returns (loss, pred, x_noisy, lowres); ElucidatedImagen.forward a scalar loss (the reference
+            # trainer crashes on the latter, trainer.py:1119 — driving EDM is a superset feature here)
+            loss, pred, x_noisy, lowres_cond_img_noisy = out if isinstance(out, tuple) else (out, None, None, None)
             loss = loss * chunk_size_frac
             if self.training:
                 # like accelerate.accumulate: the loss is divided by the accumulation steps, DDP syncs on the boundary

@@ -52,7 +52,9 @@ const char* diqt_last_error(void);
  * Replaces nn.Conv3d / nn.Linear / nn.Conv1d at: Block.project imagen_pytorch3D.py:551-553,566;
  * init_conv :1289-1291,1589; 1x1 convs :467,495,597,1388,1477; Linear :588,622-624,1310,1315;
  * pseudo-3D convs imagen_video.py:352-406,529-543.
- * Output extent per axis: O = I + 2*pad - k + 1.
+ * Output extent per axis: O = I + 2*pad + epad - k + 1, where pad is the low-side (and, with epad = 0, the
+ * high-side) zero padding and `epad` is EXTRA high-side padding (may be negative): the causal temporal
+ * convolutions of imagen_video.py:399-402 / :1351-1352 are pad = k-1, epad = -(k-1).
  * ---------------------------------------------------------------------------------------------- */
 
 /* number of floats in the packed-weight buffer for a (Cout,Cin,kd,kh,kw) filter */
@@ -68,19 +70,21 @@ int diqt_conv_pack_weight(const float* w_oidhw, float* packed, int Cout, int Cin
  * If `residual` != NULL it is added in the epilogue (same shape as y).                              */
 int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
                     float* y, int B, int D, int H, int W, int Cin, int Cout,
-                    int kd, int kh, int kw, int pd, int ph, int pw, void* stream);
+                    int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
 
 /* LDS bytes the MFMA kernel needs for this geometry (> 160 KiB: use diqt_conv3d_direct_*); < 0 on bad shape */
-long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, int kw, int pd, int ph, int pw);
+long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, int kw, int pd, int ph, int pw,
+                                int epd, int eph, int epw);
 
 /* dW[Cout][Cin][kd][kh][kw] (OIDHW, overwritten) and dbias[Cout] (may be NULL) from x and dY.
  * Deterministic: split-K partial slabs in `workspace` are reduced in a fixed order.                  */
 size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout,
-                                              int kd, int kh, int kw, int pd, int ph, int pw);
+                                              int kd, int kh, int kw, int pd, int ph, int pw,
+                                              int epd, int eph, int epw);
 int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw_oidhw, float* dbias,
                            void* workspace, size_t workspace_bytes,
                            int B, int D, int H, int W, int Cin, int Cout,
-                           int kd, int kh, int kw, int pd, int ph, int pw, void* stream);
+                           int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
 
 /* Direct (non-MFMA) grouped / strided convolution for the FLOP-trivial shapes: depthwise 3^3 and
  * patchify k=s=p convs of the attention blocks (imagen_pytorch3D.py:858-869, 913-924, 960-976),
@@ -88,15 +92,15 @@ int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw_oidhw, flo
 int diqt_conv3d_direct_fwd(const float* x, const float* w, const float* bias, float* y,
                            int B, int D, int H, int W, int Cin, int Cout, int groups,
                            int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
-                           void* stream);
+                           int epd, int eph, int epw, void* stream);
 int diqt_conv3d_direct_bwd_data(const float* dy, const float* w, float* dx,
                                 int B, int D, int H, int W, int Cin, int Cout, int groups,
                                 int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
-                                void* stream);
+                                int epd, int eph, int epw, void* stream);
 int diqt_conv3d_direct_bwd_weight(const float* x, const float* dy, float* dw, float* dbias,
                                   int B, int D, int H, int W, int Cin, int Cout, int groups,
                                   int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
-                                  void* stream);
+                                  int epd, int eph, int epw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm + (scale+1)*x+shift + activation  — Block.forward imagen_pytorch3D.py:555-562,
@@ -122,14 +126,15 @@ int diqt_gn_act_bwd(const float* x, const float* dy, const float* mean, const fl
                     void* workspace, size_t workspace_bytes,
                     int B, int rows_per_batch, int C, int G, int act, void* stream);
 
-/* Per-position LayerNorm over the channel axis, gain only, biased variance
- * (ChanLayerNorm imagen_pytorch3D.py:361-382; LayerNorm imagen_video.py:172-200).                    */
-int diqt_chan_layernorm_fwd(const float* x, const float* g, float* y, float* mean, float* rstd,
+/* Per-position LayerNorm over the channel axis, biased variance; gain `g` and optional bias `b` (NULL for the
+ * gain-only ChanLayerNorm imagen_pytorch3D.py:361-382 / LayerNorm imagen_video.py:172-200; non-NULL for
+ * nn.LayerNorm at imagen_video.py:444,1306).                                                           */
+int diqt_chan_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,
                             int rows, int C, float eps, void* stream);
-/* dg[C] is reduced through `workspace` (diqt_reduce_workspace_bytes(1, C)) */
+/* dg[C], db[C] (db may be NULL) are reduced through `workspace` (diqt_reduce_workspace_bytes(1, C)) */
 int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean,
-                            const float* rstd, float* dx, float* dg, void* workspace, size_t workspace_bytes,
-                            int rows, int C, void* stream);
+                            const float* rstd, float* dx, float* dg, float* db, void* workspace,
+                            size_t workspace_bytes, int rows, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise activations (n floats) — nn.Mish / SiLU / GELU / ReLU / Sigmoid call sites above.
@@ -174,6 +179,14 @@ int diqt_add_channel_broadcast(float* x, const float* v, float alpha, int B, int
 int diqt_space_to_depth2(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
 /* exact inverse (x[B][D][H][W][C*8] -> y[B][2D][2H][2W][C]); also PixelShuffle3D(2) forward */
 int diqt_depth_to_space2(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
+/* generic factor-(sd,sh,sw) version, each factor 1 or 2 (2-D per-frame shuffles of imagen_video.py:564-600:
+ * Rearrange 'b c f (h p1) (w p2) -> b (c p1 p2) f h w' and nn.PixelShuffle(2)); D,H,W are the coarse extents */
+int diqt_space_to_depth_nd(const float* x, float* y, int B, int D, int H, int W, int C, int sd, int sh, int sw, void* stream);
+int diqt_depth_to_space_nd(const float* x, float* y, int B, int D, int H, int W, int C, int sd, int sh, int sw, void* stream);
+/* x[A][M][N][C] -> y[A][N][M][C]  ('b c f h w' <-> '(b h w) f c' token views, imagen_video.py:1354) */
+int diqt_transpose_mid(const float* x, float* y, int A, int M, int N, int C, void* stream);
+/* F.interpolate(mode='nearest') on channels-last volumes (resize_video_to imagen_video.py:137-158) */
+int diqt_nearest_resize(const float* x, float* y, int B, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream);
 /* y[rows][Ca+Cb] = cat(a[rows][Ca], b[rows][Cb]) ; and the inverse split */
 int diqt_concat_channels(const float* a, int Ca, const float* b, int Cb, float* y, size_t rows, void* stream);
 int diqt_split_channels(const float* y, float* a, int Ca, float* b, int Cb, size_t rows, void* stream);
@@ -231,6 +244,15 @@ int diqt_ema_lerp(float* ema, const float* param, size_t n, float one_minus_deca
 int diqt_softmax_fwd(const float* x, float* y, size_t outer, int n, int inner, float scale, void* stream);
 int diqt_softmax_bwd(const float* y, const float* dy, float* dx, size_t outer, int n, int inner, float scale,
                      void* stream);
+/* Multi-query attention probabilities (imagen_video.Attention :490-518): sim[G][n][h][M] holds scores of n queries x h
+ * heads against M = n_extra + n_self keys ordered [context..., null, self...]; adds rel[(i-j+n_self-1)][h] (T5-style
+ * DynamicPositionBias table, may be NULL) on self keys and null_bias[h] (may be NULL) on the null key (the last extra
+ * key), masks self keys j > i when causal, and soft-maxes over M in place layout.  bwd also accumulates drel / dnull
+ * (zeroed by the caller; float atomics).                                                                         */
+int diqt_attn_softmax_fwd(const float* sim, const float* rel, const float* null_bias, float* p,
+                          int G, int n, int h, int n_extra, int n_self, int causal, void* stream);
+int diqt_attn_softmax_bwd(const float* p, const float* dp, float* dsim, float* drel, float* dnull_bias,
+                          int G, int n, int h, int n_extra, int n_self, int causal, void* stream);
 /* batched fp32 MFMA GEMM: C[g] = alpha * op(A[g]) * op(B[g]) (+ beta*C[g]); row-major, strides in floats */
 int diqt_bgemm(const float* A, const float* Bm, float* C, int batch, int M, int N, int K,
                int transA, int transB, long long strideA, long long strideB, long long strideC,

@@ -21,6 +21,7 @@
 //   LDS and issues one MFMA per (tap, 2 voxels).  Partial slabs go to the workspace in the packed
 //   layout and are reduced in a fixed order (deterministic) by conv_reduce_dw_kernel.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace diqt {
@@ -40,6 +41,7 @@ struct ConvGeom {
     int tilesD, tilesH, tilesW;
     int nNt, nChunks, CoutPad;
     int HD, HH, HWd;            // halo extents
+    unsigned long long* dbg;    // diagnostic cycle stamps (NULL in production)
 };
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -131,30 +133,45 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    unsigned long long stamps[8];
+    int nst = 0;
+#define DIQT_STAMP() do { if (g.dbg && nst < 8) stamps[nst++] = __builtin_readcyclecounter(); } while (0)
+    DIQT_STAMP();
 
     const int wrow = tid >> 3, wc4 = (tid & 7) * 4;      // weight staging: rows wrow, wrow+32
 
     for (int chunk = 0; chunk < g.nChunks; ++chunk) {
         const int ci0 = chunk * CK;
         __syncthreads();   // all reads of the previous chunk's halo and of both weight buffers are done
-        // ---- stage halo chunk ----
-        for (int idx = tid; idx < HV * 8; idx += 256) {
-            const int hv = idx >> 3, c4 = (idx & 7) * 4;
-            const int src = halo_src[hv];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src >= 0) {
-                const size_t base = (size_t)src * g.Cin + ci0 + c4;
+        // ---- stage halo chunk: loads are UNCONDITIONAL (clamped address, zero-selected afterwards) and issued in batches
+        //      of 8 before any LDS store, so a batch costs one memory round trip instead of eight serialized ones ----
+        for (int base = 0; base < HV * 8; base += 256 * 8) {
+            float4 v[8];
+            bool ok[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int hv = (idx < HV * 8) ? (idx >> 3) : 0, c4 = (idx & 7) * 4;
+                const int src = halo_src[hv];
+                ok[u] = idx < HV * 8 && src >= 0 && ci0 + c4 < g.Cin;
+                const size_t off = ok[u] ? (size_t)src * g.Cin + ci0 + c4 : 0;
                 if (VEC4) {
-                    if (ci0 + c4 < g.Cin) v = *reinterpret_cast<const float4*>(x + base);
+                    v[u] = *reinterpret_cast<const float4*>(x + off);
                 } else {
-                    const int rem = g.Cin - (ci0 + c4);
-                    if (rem > 0) v.x = x[base];
-                    if (rem > 1) v.y = x[base + 1];
-                    if (rem > 2) v.z = x[base + 2];
-                    if (rem > 3) v.w = x[base + 3];
+                    const int rem = ok[u] ? g.Cin - (ci0 + c4) : 0;
+                    v[u].x = x[off];
+                    v[u].y = rem > 1 ? x[off + 1] : 0.f;
+                    v[u].z = rem > 2 ? x[off + 2] : 0.f;
+                    v[u].w = rem > 3 ? x[off + 3] : 0.f;
                 }
             }
-            *reinterpret_cast<float4*>(halo + hv * LDSROW + c4) = v;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                if (idx < HV * 8)
+                    *reinterpret_cast<float4*>(halo + (idx >> 3) * LDSROW + (idx & 7) * 4) =
+                        ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         // ---- weights of tap 0 ----
         const float* wchunk = wp + ((size_t)chunk * T * g.CoutPad + n0) * CK;
@@ -165,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
             *reinterpret_cast<float4*>(wbuf + (wrow + 32) * LDSROW + wc4) = r1;
         }
         __syncthreads();
+        DIQT_STAMP();
 
         int tap = 0;
         for (int kz = 0; kz < g.kd; ++kz)
@@ -211,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
                     }
                     __syncthreads();
                 }
+        DIQT_STAMP();
     }
 
     // ---- epilogue: D[row=voxel][col=co]; row = (r&3) + 8*(r>>2) + 4*h ----
@@ -234,6 +253,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
             y[o + co1] = v;
         }
     }
+    DIQT_STAMP();
+    if (g.dbg && tid == 0)
+        for (int q = 0; q < 8; ++q) g.dbg[(size_t)blockIdx.x * 8 + q] = q < nst ? stamps[q] : 0ull;
+#undef DIQT_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
 // current item's 27 x 32 MFMAs run and is written to LDS at the item boundary (async-stage split), so HBM
 // latency, workgroup launch and index math are off the MFMA critical path.  Same math, same LDS images.
 // ---------------------------------------------------------------------------------------------
-template <bool VEC4, int NR>
+template <bool VEC4, int NR, int KD, int KH, int KW>
 __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ wp,
                                                                   const float* __restrict__ bias,
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int T = g.kd * g.kh * g.kw;
+    constexpr int T = KD * KH * KW;      // the tap loop is fully unrolled: register-array indices must be static
 
     // tile ownership: XCD x (= blockIdx % 8 under round-robin placement; speed only) owns a contiguous range
     const int G8 = gridDim.x / kNumXcd;                  // workgroups per XCD (grid is a multiple of 8)
@@ -296,35 +319,38 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
         }
     };
     float4 R[NR];
+    unsigned okmask = 0;
+    // one 16-byte piece of the next item's halo chunk (piece r of thread tid covers halo element tid + 256 r)
+    auto load_piece = [&](int r, int slot, int ci0) -> float4 {
+        const int idx = tid + 256 * r;
+        const int hv = (idx < HV * 8) ? (idx >> 3) : 0, c4 = (idx & 7) * 4;
+        const int src = halo_src[slot * HV + hv];
+        const bool ok = idx < HV * 8 && src >= 0 && ci0 + c4 < g.Cin && !(ablate & 2);
+        const size_t off = ok ? (size_t)src * g.Cin + ci0 + c4 : 0;     // unconditional load from a clamped address
+        float4 v;
+        if (VEC4) {
+            v = *reinterpret_cast<const float4*>(x + off);
+        } else {
+            const int rem = ok ? g.Cin - (ci0 + c4) : 0;
+            v.x = x[off];
+            v.y = rem > 1 ? x[off + 1] : 0.f;
+            v.z = rem > 2 ? x[off + 2] : 0.f;
+            v.w = rem > 3 ? x[off + 3] : 0.f;
+        }
+        if (ok) okmask |= (1u << r); else okmask &= ~(1u << r);     // the zero-select happens at LDS-store time: using v here
+        return v;                                                     // would make the wave wait for the load immediately
+    };
     auto issue_loads = [&](int slot, int ci0) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int idx = tid + 256 * r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < HV * 8) {
-                const int hv = idx >> 3, c4 = (idx & 7) * 4;
-                const int src = halo_src[slot * HV + hv];
-                if (src >= 0 && !(ablate & 2)) {
-                    const size_t base = (size_t)src * g.Cin + ci0 + c4;
-                    if (VEC4) {
-                        if (ci0 + c4 < g.Cin) v = *reinterpret_cast<const float4*>(x + base);
-                    } else {
-                        const int rem = g.Cin - (ci0 + c4);
-                        if (rem > 0) v.x = x[base];
-                        if (rem > 1) v.y = x[base + 1];
-                        if (rem > 2) v.z = x[base + 2];
-                        if (rem > 3) v.w = x[base + 3];
-                    }
-                }
-            }
-            R[r] = v;
-        }
+        for (int r = 0; r < NR; ++r) R[r] = load_piece(r, slot, ci0);
     };
     auto store_halo = [&]() {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int idx = tid + 256 * r;
-            if (idx < HV * 8) *reinterpret_cast<float4*>(halo + (idx >> 3) * LDSROW + (idx & 7) * 4) = R[r];
+            if (idx < HV * 8)
+                *reinterpret_cast<float4*>(halo + (idx >> 3) * LDSROW + (idx & 7) * 4) =
+                    (okmask >> r) & 1u ? R[r] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -336,6 +362,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
     }
     const int wrow = tid >> 3, wc4 = (tid & 7) * 4;
 
+    long long tsum[4] = {0, 0, 0, 0};      // diagnostic: [wait at item start, staging, tap loop, epilogue]
+    long long tprev = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
+#define DIQT_ACC(i) do { if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tsum[i] += tn - tprev; tprev = tn; } } while (0)
     int slot = 0;
     TilePos pos = decode(tile);
     fill_tables(pos, 0);
@@ -343,8 +372,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
     issue_loads(0, 0);
     // stagger: the second resident set of workgroups starts half a tap late, so the two waves sharing a SIMD do not
     // reach their barriers / LDS-read waits in lockstep (speed only)
-    if (blockIdx.x >= gridDim.x / 2)
-        for (int i = 0; i < (ablate >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+    {   // experiment: de-phase workgroups by a placement-independent pseudo-random start delay of up to (ablate>>8) K-cycles
+        unsigned hsh = blockIdx.x * 2654435761u; hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+        const int nsl = (ablate >> 8) ? (int)(hsh % (unsigned)(ablate >> 8)) : 0;
+        for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(16);
+    }
 
     while (true) {
         const int nextTile = tile + G8;
@@ -356,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
         for (int chunk = 0; chunk < g.nChunks; ++chunk) {
             const bool lastChunk = chunk == g.nChunks - 1;
             __syncthreads();          // every wave is done reading the previous item's halo and weight buffers
+            DIQT_ACC(0);
             store_halo();             // waits for the prefetched registers (issued one item ago)
             const float* wchunk = wp + ((size_t)chunk * T * g.CoutPad + pos.n0) * CK;
             {
@@ -370,20 +403,30 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
                 fill_tables(npos, slot ^ 1);
             }
             __syncthreads();
-            // prefetch the next item's halo chunk into registers; it lands while this item's MFMAs run
-            if (!lastChunk) issue_loads(slot, (chunk + 1) * CK);
-            else if (haveNextTile) issue_loads(slot ^ 1, 0);
+            DIQT_ACC(1);
+            // the next item's halo chunk is prefetched into registers ONE PIECE PER TAP, each piece issued right after
+            // that tap's weight-panel loads: vmcnt retires in order, so the end-of-tap wait for the weight panel then
+            // leaves the (younger) halo piece in flight instead of stalling on a whole-chunk burst
+            const bool havePrefetch = !lastChunk || haveNextTile;
+            const int pslot = lastChunk ? (slot ^ 1) : slot;
+            const int pci0 = lastChunk ? 0 : (chunk + 1) * CK;
+            constexpr int ppt = (NR + T - 1) / T;              // pieces per tap
 
-            int tap = 0;
-            for (int kz = 0; kz < g.kd; ++kz)
-                for (int ky = 0; ky < g.kh; ++ky)
-                    for (int kx = 0; kx < g.kw; ++kx, ++tap) {
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                    {
+                        const int kx = tap % KW, ky = (tap / KW) % KH, kz = tap / (KW * KH);
                         float4 r0, r1;
                         const bool more = (tap + 1 < T);
                         if (more && !(ablate & 8)) {
                             const float* wt = wchunk + (size_t)(tap + 1) * g.CoutPad * CK;
                             r0 = *reinterpret_cast<const float4*>(wt + (size_t)wrow * CK + wc4);
                             r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
+                        }
+                        if (havePrefetch) {
+#pragma unroll
+                            for (int r = 0; r < NR; ++r)
+                                if (r >= tap * ppt && r < (tap + 1) * ppt) R[r] = load_piece(r, pslot, pci0);
                         }
                         const float* wcur = wbuf + (tap & 1) * (NT * LDSROW);
                         const float* ap = (ablate & 32) ? halo + (l31 + tap) * LDSROW + 4 * h
@@ -418,6 +461,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
                             __syncthreads();
                         }
                     }
+            }
+            DIQT_ACC(2);
             if (lastChunk && (ablate & 4)) { pos = npos; }
             if (lastChunk && !(ablate & 4)) {
                 // epilogue of this tile (out_off[slot] stays valid: the next tile's table went to slot^1)
@@ -442,12 +487,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
                     }
                 }
                 pos = npos;
+                DIQT_ACC(3);
             }
         }
         if (!haveNextTile) break;
         tile = nextTile;
         slot ^= 1;
     }
+    if (g.dbg && tid == 0)
+        for (int q = 0; q < 4; ++q) g.dbg[(size_t)blockIdx.x * 8 + q] = (unsigned long long)tsum[q];
+#undef DIQT_ACC
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -610,6 +659,230 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward-weight, version 2 (default): a workgroup owns  COB co x 32 ci x TG taps  and walks its split-K range of
+// voxel tiles.  SPLIT_CO = false (filters with >= 4 taps): COB = 32 and the 4 waves split the taps (7/7/7/6 for 3x3x3:
+// balanced to 96 %), all sharing the full halo tile;  SPLIT_CO = true (1x1x1 and other tiny filters): COB = 128 and
+// the waves split the output channels.  The NEXT tile's X halo and dY tile are fetched global -> registers while the
+// current tile's MFMAs run and are written to LDS at the tile boundary, so HBM/Infinity-Cache latency is off the
+// critical path and each element of a tile is staged once per workgroup.
+// ---------------------------------------------------------------------------------------------
+struct BwGeom2 {
+    ConvGeom g;
+    int tapGroups, coBlocks;     // grid.x = nChunks * coBlocks * tapGroups
+    int tilesPerSplit, MT;
+    int lTW, lTH;
+};
+
+template <bool VEC4, int NRX, int NRY, int MAXT, bool SPLIT_CO, int NTHR>
+__global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ dy,
+                                                                  float* __restrict__ slabs, BwGeom2 bg) {
+    const ConvGeom& g = bg.g;
+    constexpr int COB = SPLIT_CO ? 128 : 32;
+    constexpr int NWAVE = NTHR / 64;
+    // SPLIT_CO = false: SIMD q (waves q and q+4) owns taps [q*MAXT, (q+1)*MAXT); its two waves take alternate k-steps
+    // of every tile and write separate split-K slabs, so all 8 waves run the same code with MAXT accumulators
+    constexpr int TG = SPLIT_CO ? MAXT : 4 * MAXT;
+    constexpr int KPAR = SPLIT_CO ? 1 : NWAVE / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HV = g.HD * g.HH * g.HWd;
+    float* xh = smem;                                        // [HV][32]
+    float* dyt = smem + (size_t)HV * CK;                     // [128][COB]
+    int* xsrc = reinterpret_cast<int*>(dyt + MTILE * COB);   // [2][HV]
+    int* ysrc = xsrc + 2 * HV;                               // [2][128]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int T = g.kd * g.kh * g.kw;
+
+    int bx = blockIdx.x;
+    const int tg = bx % bg.tapGroups; bx /= bg.tapGroups;
+    const int cb = bx % bg.coBlocks;
+    const int chunk = bx / bg.coBlocks;
+    const int ci0 = chunk * CK, n0 = cb * COB;
+    const int co_off = SPLIT_CO ? 32 * wave : 0;
+    const int kpar = SPLIT_CO ? 0 : wave >> 2;
+    const int tapBase = tg * TG + (SPLIT_CO ? 0 : (wave & 3) * MAXT);
+    int ntap = min(T, (tg + 1) * TG) - tapBase;
+    ntap = ntap < 0 ? 0 : (ntap > MAXT ? MAXT : ntap);
+    if (SPLIT_CO && n0 + co_off >= g.CoutPad) ntap = 0;
+
+    int tapoff[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int tp = tapBase + t;
+        const int kx = tp % g.kw, ky = (tp / g.kw) % g.kh, kz = tp / (g.kw * g.kh);
+        tapoff[t] = (t < ntap) ? ((kz * g.HH + ky) * g.HWd + kx) * CK : 0;
+    }
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int mtBegin = blockIdx.y * bg.tilesPerSplit;
+    const int mtEnd = min(mtBegin + bg.tilesPerSplit, bg.MT);
+
+    auto fill_tables = [&](int mt0, int slot) {
+        int mt = mt0;
+        const int tx = mt % g.tilesW; mt /= g.tilesW;
+        const int ty = mt % g.tilesH; mt /= g.tilesH;
+        const int tz = mt % g.tilesD;
+        const int b = mt / g.tilesD;
+        const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
+        for (int hv = tid; hv < HV + MTILE; hv += NTHR) {
+            if (hv < HV) {
+                const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+                const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+                xsrc[slot * HV + hv] = (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                                           ? ((b * g.D + iz) * g.H + iy) * g.W + ix : -1;
+            } else {
+                const int v = hv - HV;
+                const int tw = v & (g.TW - 1), th = (v >> bg.lTW) & (g.TH - 1), td = v >> (bg.lTW + bg.lTH);
+                const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+                ysrc[slot * MTILE + v] = (od < g.Do && oh < g.Ho && ow < g.Wo) ? ((b * g.Do + od) * g.Ho + oh) * g.Wo + ow : -1;
+            }
+        }
+    };
+    float4 RX[NRX], RY[NRY];
+    unsigned okx = 0, oky = 0;
+    // all loads are unconditional (clamped address) so hipcc emits them back to back; invalid pieces are zero-selected
+    auto issue_loads = [&](int slot) {
+#pragma unroll
+        for (int r = 0; r < NRX; ++r) {
+            const int idx = tid + NTHR * r;
+            const int hv = (idx < HV * 8) ? (idx >> 3) : 0, c4 = (idx & 7) * 4;
+            const int src = xsrc[slot * HV + hv];
+            const bool ok = idx < HV * 8 && src >= 0 && ci0 + c4 < g.Cin;
+            const size_t off = ok ? (size_t)src * g.Cin + ci0 + c4 : 0;
+            float4 v;
+            if (VEC4) {
+                v = *reinterpret_cast<const float4*>(x + off);
+            } else {
+                const int rem = ok ? g.Cin - (ci0 + c4) : 0;
+                v.x = x[off];
+                v.y = rem > 1 ? x[off + 1] : 0.f;
+                v.z = rem > 2 ? x[off + 2] : 0.f;
+                v.w = rem > 3 ? x[off + 3] : 0.f;
+            }
+            RX[r] = v;                                   // zero-select deferred to store_tiles (see okx)
+            if (ok) okx |= (1u << r); else okx &= ~(1u << r);
+        }
+#pragma unroll
+        for (int r = 0; r < NRY; ++r) {
+            const int idx = tid + NTHR * r;                   // idx < 128 * COB / 4 always (NRY = 128*COB/1024)
+            const int v = idx / (COB / 4), c4 = (idx % (COB / 4)) * 4;
+            const int src = ysrc[slot * MTILE + v];
+            const int rem0 = g.Cout - (n0 + c4);
+            const bool ok = src >= 0 && rem0 > 0;
+            const size_t off = ok ? (size_t)src * g.Cout + n0 + c4 : 0;
+            float4 q;
+            if ((g.Cout & 3) == 0) {
+                q = *reinterpret_cast<const float4*>(dy + off);
+            } else {
+                const int rem = ok ? rem0 : 0;
+                q.x = dy[off];
+                q.y = rem > 1 ? dy[off + 1] : 0.f;
+                q.z = rem > 2 ? dy[off + 2] : 0.f;
+                q.w = rem > 3 ? dy[off + 3] : 0.f;
+            }
+            RY[r] = q;
+            if (ok) oky |= (1u << r); else oky &= ~(1u << r);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int r = 0; r < NRX; ++r) {
+            const int idx = tid + NTHR * r;
+            if (idx < HV * 8)
+                *reinterpret_cast<float4*>(xh + (idx >> 3) * CK + (idx & 7) * 4) = (okx >> r) & 1u ? RX[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < NRY; ++r) {
+            const int idx = tid + NTHR * r;
+            *reinterpret_cast<float4*>(dyt + (idx / (COB / 4)) * COB + (idx % (COB / 4)) * 4) =
+                (oky >> r) & 1u ? RY[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    if (mtBegin < mtEnd) {
+        fill_tables(mtBegin, 0);
+        __syncthreads();
+        issue_loads(0);
+    }
+    long long tsum[5] = {0, 0, 0, 0, 0};
+    long long tprev = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
+#define DIQT_ACC(i) do { if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tsum[i] += tn - tprev; tprev = tn; } } while (0)
+    int slot = 0;
+    const int mTW = g.TW - 1, mTH = g.TH - 1, sTH = bg.lTW, sTD = bg.lTW + bg.lTH;
+    for (int mt0 = mtBegin; mt0 < mtEnd; ++mt0) {
+        const bool haveNext = mt0 + 1 < mtEnd;
+        __syncthreads();                 // all MFMA-phase reads of the previous tile are done
+        DIQT_ACC(0);
+        store_tiles();                   // waits for the registers prefetched one tile ago
+        DIQT_ACC(1);
+        if (haveNext) fill_tables(mt0 + 1, slot ^ 1);
+        __syncthreads();
+        DIQT_ACC(2);
+        if (haveNext) issue_loads(slot ^ 1);
+        DIQT_ACC(3);
+        if (ntap > 0) {
+            // voxel v = 2*s2 + h: bit 0 of v lies in exactly one of the (td, th, tw) bit-fields, so the halo offset of v is
+            // offset(2*s2) [wave-uniform, scalar ALU] + offset(h) [per lane, hoisted]
+            const int hoff = ((((h >> sTD) * g.HH + ((h >> sTH) & mTH)) * g.HWd) + (h & mTW)) * CK;
+            const float* ap0 = dyt + co_off + l31 + h * COB;
+            const float* bp0 = xh + l31 + hoff;
+            auto soff = [&](int s2) {
+                const int v = 2 * s2;
+                return ((((v >> sTD) * g.HH + ((v >> sTH) & mTH)) * g.HWd) + (v & mTW)) * CK;
+            };
+            // software pipeline: the LDS reads of step s+1 are issued behind the first MFMA of step s, so the other
+            // MAXT-1 MFMAs cover their latency (hipcc otherwise serialises read -> wait -> MFMA through one register)
+            auto rd = [&](int s2, float& a, float (&b)[MAXT]) {
+                a = ap0[2 * s2 * COB];
+                const float* bp = bp0 + soff(s2);
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) b[t] = bp[tapoff[t]];
+            };
+            auto mm = [&](float a, const float (&b)[MAXT]) {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MAXT + 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MAXT - 1, 0);
+            };
+            float a0, b0[MAXT], a1, b1[MAXT];          // ping-pong operand registers (MTILE/2/KPAR steps: even)
+            rd(kpar, a0, b0);
+            for (int s2 = kpar; s2 < MTILE / 2; s2 += 2 * KPAR) {
+                rd(s2 + KPAR, a1, b1);
+                mm(a0, b0);
+                rd(s2 + 2 * KPAR < MTILE / 2 ? s2 + 2 * KPAR : kpar, a0, b0);      // the last step re-reads the first (unused)
+                mm(a1, b1);
+            }
+        }
+        DIQT_ACC(4);
+        slot ^= 1;
+    }
+    if (g.dbg && lane == 0)       // one record per wave: 5 phase sums + SIMD id (HW_REG_HW_ID bits 5:4)
+        for (int q = 0; q < 6; ++q)
+            g.dbg[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NWAVE + wave) * 8 + q] =
+                q < 5 ? (unsigned long long)tsum[q] : (unsigned long long)((__builtin_amdgcn_s_getreg((6 - 1) << 11 | 0 << 6 | 4) >> 4) & 3);
+#undef DIQT_ACC
+
+    float* slab = slabs + ((size_t)blockIdx.y * KPAR + kpar) * g.nChunks * T * g.CoutPad * CK;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t < ntap) {
+            const int tap = tapBase + t;
+            float* dst = slab + (((size_t)chunk * T + tap) * g.CoutPad + n0 + co_off) * CK + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * CK] = acc[t][r];
+        }
+    }
+}
+
 // dW[co][ci][tap] = sum_ks slab[ks][ci/32][tap][co][ci%32]
 __global__ void conv_reduce_dw_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                       int Cout, int Cin, int T, int CoutPad, int nChunks, int ksplit) {
@@ -699,6 +972,7 @@ static int make_geom(ConvGeom& g, int B, int D, int H, int W, int Cin, int Cout,
         DIQT_REQUIRE(rows < (1ll << 31), DIQT_E_SHAPE, "conv3d: too many rows");
         B = 1; D = 1; H = 1; W = (int)rows;
     }
+    g.dbg = nullptr;
     g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
     g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw;
     g.Do = D + 2 * pd + epd - kd + 1; g.Ho = H + 2 * ph + eph - kh + 1; g.Wo = W + 2 * pw + epw - kw + 1;
@@ -717,6 +991,18 @@ static int make_geom(ConvGeom& g, int B, int D, int H, int W, int Cin, int Cout,
 }  // namespace diqt
 
 using namespace diqt;
+
+static unsigned long long* g_dbg_ptr = nullptr;   // diagnostic cycle-stamp buffer of the last DIQT_CONV_DBG=1 launch
+static unsigned g_dbg_n = 0;
+
+// diagnostic only (not part of include/diqt.h): copies the cycle stamps of the last DIQT_CONV_DBG=1 launch to the host
+extern "C" int diqt_debug_conv_stamps(unsigned long long* host_out, unsigned max_wg) {
+    if (!g_dbg_ptr || !g_dbg_n) return 0;
+    const unsigned n = g_dbg_n < max_wg ? g_dbg_n : max_wg;
+    hipDeviceSynchronize();
+    hipMemcpy(host_out, g_dbg_ptr, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    return (int)n;
+}
 
 extern "C" size_t diqt_conv_packed_elems(int Cout, int Cin, int kd, int kh, int kw) {
     if (Cout <= 0 || Cin <= 0 || kd <= 0 || kh <= 0 || kw <= 0) return 0;
@@ -757,13 +1043,13 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
     // opt-in: measured equal to the one-tile-per-workgroup kernel on MI355X (118 vs 121 TFLOP/s, profiles/r01_conv_ablation.md)
     static const bool persist_ok = [] { const char* e = getenv("DIQT_CONV_PERSIST"); return e && e[0] == '1'; }();
-    if (persist_ok && HV * 8 <= 256 * 13) {
+    const bool k333 = kd == 3 && kh == 3 && kw == 3, k133 = kd == 1 && kh == 3 && kw == 3;
+    if (persist_ok && HV * 8 <= 256 * 13 && (k333 || k133)) {
         const size_t plds = ((size_t)HV * (LDSROW + 2) + 2 * NT * LDSROW) * sizeof(float) + 2 * MTILE * sizeof(int);
         if (plds <= 160 * 1024) {
-            const int nr = (HV * 8 <= 256 * 4) ? 4 : 13;
             void (*pk)(const float*, const float*, const float*, const float*, float*, ConvGeom, int, int) =
-                nr == 4 ? (vec4 ? conv_fwd_persist_kernel<true, 4> : conv_fwd_persist_kernel<false, 4>)
-                        : (vec4 ? conv_fwd_persist_kernel<true, 13> : conv_fwd_persist_kernel<false, 13>);
+                k333 ? (vec4 ? conv_fwd_persist_kernel<true, 13, 3, 3, 3> : conv_fwd_persist_kernel<false, 13, 3, 3, 3>)
+                     : (vec4 ? conv_fwd_persist_kernel<true, 13, 1, 3, 3> : conv_fwd_persist_kernel<false, 13, 1, 3, 3>);
             if (plds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
@@ -775,6 +1061,12 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
             const unsigned need = (nwg + kNumXcd - 1) / kNumXcd * kNumXcd;
             if (grid > need) grid = need;
             static const int ablate = [] { const char* e = getenv("DIQT_CONV_ABLATE"); return e ? atoi(e) : 0; }();   // timing-only diagnostics
+            static unsigned long long* pdbg = nullptr;
+            static const bool pdbg_on = [] { const char* e = getenv("DIQT_CONV_DBG"); return e && e[0] == '1'; }();
+            if (pdbg_on) {
+                if (!pdbg) hipMalloc(&pdbg, (size_t)65536 * 8 * sizeof(unsigned long long));
+                g.dbg = pdbg; g_dbg_ptr = pdbg; g_dbg_n = grid;
+            }
             hipLaunchKernelGGL(pk, dim3(grid), dim3(256), plds, (hipStream_t)stream, x, packed, bias, residual, y, g, (int)nwg, ablate);
             return check_launch("conv3d_fwd(persistent)");
         }
@@ -782,6 +1074,13 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
     const size_t lds = ((size_t)HV * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int);
     DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_fwd: halo tile needs %zu B of LDS", lds);
     auto kern = vec4 ? conv_fwd_kernel<true> : conv_fwd_kernel<false>;
+    static unsigned long long* dbg_buf = nullptr;
+    static const bool dbg_on = [] { const char* e = getenv("DIQT_CONV_DBG"); return e && e[0] == '1'; }();
+    if (dbg_on) {     // diagnostic build path only: cycle stamps per workgroup, read back with diqt_debug_conv_stamps()
+        if (!dbg_buf) hipMalloc(&dbg_buf, (size_t)65536 * 8 * sizeof(unsigned long long));
+        if (nwg <= 65536) g.dbg = dbg_buf;
+        g_dbg_ptr = dbg_buf; g_dbg_n = nwg <= 65536 ? nwg : 0;
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -811,12 +1110,45 @@ static int bw_plan(BwGeom& bg, int B, int D, int H, int W, int Cin, int Cout, in
     return DIQT_OK;
 }
 
+constexpr int BW2_MAXT_A = 7, BW2_MAXT_B = 3;   // A: 4 SIMDs x 7 taps per group, 2 k-interleaved waves per SIMD
+constexpr int BW2_KPAR_A = 2;                   // slabs written per workgroup in mode A
+// version-2 plan; returns false when the shape needs the generic (version-1) kernel
+static bool bw2_plan(const ConvGeom& g, BwGeom2& b2, bool& splitCo, int& ksplit, size_t& lds) {
+    static const bool off = [] { const char* e = getenv("DIQT_BWDW_V1"); return e && e[0] == '1'; }();
+    if (off) return false;
+    const int T = g.kd * g.kh * g.kw, HV = g.HD * g.HH * g.HWd;
+    splitCo = T <= BW2_MAXT_B;
+    if (splitCo ? (HV * 8 > 256 * 4) : (HV * 8 > 512 * 7)) return false;
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    b2.g = g;
+    b2.lTW = ilog2(g.TW); b2.lTH = ilog2(g.TH);
+    if ((1 << b2.lTW) != g.TW || (1 << b2.lTH) != g.TH) return false;
+    const int COB = splitCo ? 128 : 32, TG = splitCo ? BW2_MAXT_B : 4 * BW2_MAXT_A;
+    b2.tapGroups = cdiv(T, TG);
+    b2.coBlocks = cdiv(g.CoutPad, COB);
+    b2.MT = g.B * g.tilesD * g.tilesH * g.tilesW;
+    const int gx = g.nChunks * b2.coBlocks * b2.tapGroups;
+    static const int wgs = [] { const char* e = getenv("DIQT_BWDW_WGS"); return e ? atoi(e) : 256; }();
+    ksplit = wgs / gx;      // ONE workgroup per CU: the kernel needs >256 VGPRs to keep its LDS reads batched ahead of the MFMAs
+    if (ksplit > b2.MT) ksplit = b2.MT;
+    if (ksplit < 1) ksplit = 1;
+    b2.tilesPerSplit = cdiv(b2.MT, ksplit);
+    ksplit = cdiv(b2.MT, b2.tilesPerSplit);
+    lds = ((size_t)HV * CK + (size_t)MTILE * COB) * sizeof(float) + (2 * (size_t)HV + 2 * MTILE) * sizeof(int);
+    return lds <= 160 * 1024;
+}
+
 extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd,
                                                          int kh, int kw, int pd, int ph, int pw, int epd, int eph,
                                                          int epw) {
     BwGeom bg;
     int ksplit;
     if (bw_plan(bg, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, ksplit)) return 0;
+    BwGeom2 b2;
+    bool splitCo;
+    int ks2 = 0;
+    size_t lds2;
+    if (bw2_plan(bg.g, b2, splitCo, ks2, lds2) && ks2 * (splitCo ? 1 : BW2_KPAR_A) > ksplit) ksplit = ks2 * (splitCo ? 1 : BW2_KPAR_A);
     const size_t slab = (size_t)bg.g.nChunks * kd * kh * kw * bg.g.CoutPad * CK * sizeof(float);
     const size_t colsum = (size_t)1024 * Cout * sizeof(float);
     const size_t need = (size_t)ksplit * slab;
@@ -847,9 +1179,32 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     }
     hipStream_t s = (hipStream_t)stream;
     float* slabs = static_cast<float*>(workspace);
-    const dim3 grid(g.nChunks * g.nNt * g.kd * bg.tapGroups, ksplit);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, dy, slabs, bg);
-    rc = check_launch("conv3d_bwd_weight");
+    BwGeom2 b2;
+    bool splitCo = false;
+    int ks2 = 0;
+    size_t lds2 = 0;
+    if (bw2_plan(g, b2, splitCo, ks2, lds2)) {
+        void (*k2)(const float*, const float*, float*, BwGeom2) =
+            splitCo ? (vec4 ? conv_bwd_weight2_kernel<true, 4, 16, BW2_MAXT_B, true, 256> : conv_bwd_weight2_kernel<false, 4, 16, BW2_MAXT_B, true, 256>)
+                    : (vec4 ? conv_bwd_weight2_kernel<true, 7, 2, BW2_MAXT_A, false, 512> : conv_bwd_weight2_kernel<false, 7, 2, BW2_MAXT_A, false, 512>);
+        if (lds2 > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_bwd_weight: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        ksplit = ks2 * (splitCo ? 1 : BW2_KPAR_A);
+        static unsigned long long* bdbg = nullptr;
+        static const bool bdbg_on = [] { const char* e = getenv("DIQT_CONV_DBG"); return e && e[0] == '1'; }();
+        if (bdbg_on) {
+            if (!bdbg) hipMalloc(&bdbg, (size_t)65536 * 8 * sizeof(unsigned long long));
+            b2.g.dbg = bdbg; g_dbg_ptr = bdbg; g_dbg_n = g.nChunks * b2.coBlocks * b2.tapGroups * ks2 * (splitCo ? 4 : 8);
+        }
+        hipLaunchKernelGGL(k2, dim3(g.nChunks * b2.coBlocks * b2.tapGroups, ks2), dim3(splitCo ? 256 : 512), lds2, s, x, dy, slabs, b2);
+        rc = check_launch("conv3d_bwd_weight(v2)");
+    } else {
+        const dim3 grid(g.nChunks * g.nNt * g.kd * bg.tapGroups, ksplit);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, dy, slabs, bg);
+        rc = check_launch("conv3d_bwd_weight");
+    }
     if (rc) return rc;
     const size_t total = (size_t)Cout * Cin * T;
     hipLaunchKernelGGL(conv_reduce_dw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, slabs, dw, Cout, Cin, T,

@@ -46,3 +46,45 @@ if mode in ("bwdw", "both"):
         y.backward(dy, retain_graph=True, inputs=[w, bias])
     ms = timeit(bw, iters)
     print(f"conv bwd-weight(+bias): {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
+
+if os.environ.get("DIQT_CONV_DBG") == "1" and mode == "bwdw":
+    import ctypes
+    import numpy as np
+    lib = _lib.load()
+    for _ in range(20):
+        bw()
+    torch.cuda.synchronize()
+    buf = np.zeros((65536, 8), dtype=np.uint64)
+    n = lib.diqt_debug_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p), 65536)
+    st = buf[:n, :6].astype(np.int64).reshape(-1, 8, 6)
+    names = ["barrier wait", "store regs->LDS", "tables+barrier", "issue loads", "MFMA k-loop"]
+    print("per-wave medians (cycles per workgroup, 32 tiles):  " + "  ".join(names) + "  | SIMD")
+    for wv in range(8):
+        print(f"  wave {wv}: " + "  ".join(f"{np.median(st[:, wv, i]):12.0f}" for i in range(5)) + f"  | {np.bincount(st[:, wv, 5], minlength=4)}")
+    sys.exit(0)
+if os.environ.get("DIQT_CONV_DBG") == "1":
+    import ctypes
+    import numpy as np
+    lib = _lib.load()
+    with torch.no_grad():
+        for _ in range(50):
+            ops.conv3d(x, w, bias, (1, 1, 1))
+    torch.cuda.synchronize()
+    buf = np.zeros((65536, 8), dtype=np.uint64)
+    n = lib.diqt_debug_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p), 65536)
+    st = buf[:n].astype(np.int64)
+    if os.environ.get("DIQT_CONV_PERSIST") == "1":
+        tot = st[:, :4].sum(axis=1)
+        for i, nm in enumerate(["wait at item start", "store halo+W0+tables", "tap loops", "epilogues"]):
+            print(f"  {nm:22s} median {np.median(st[:, i]):10.0f} cycles = {100 * np.median(st[:, i] / tot):5.1f} % of workgroup life")
+        print(f"  workgroup life median {np.median(tot):.0f} cycles, {n} persistent workgroups")
+        sys.exit(0)
+    d = np.diff(st[:, :6], axis=1)
+    names = ["tables+stage chunk0", "taps chunk0", "stage chunk1", "taps chunk1", "epilogue"]
+    print(f"stamps from {n} workgroups (cycles of the constant-rate counter, median / p90):")
+    for i, nm in enumerate(names):
+        print(f"  {nm:22s} {np.median(d[:, i]):10.0f} {np.percentile(d[:, i], 90):10.0f}")
+    tot = st[:, 5] - st[:, 0]
+    print(f"  {'workgroup lifetime':22s} {np.median(tot):10.0f} {np.percentile(tot, 90):10.0f}")
+    span = st[:, 5].max() - st[:, 0].min()
+    print(f"  kernel span {span} ticks; sum of lifetimes / (512 slots) = {tot.sum() / 512:.0f}")

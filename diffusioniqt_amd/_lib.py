@@ -72,6 +72,9 @@ PROTOTYPES = {
     "diqt_attn_softmax_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "diqt_attn_softmax_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "diqt_bgemm": (I, [P, P, P, I, I, I, I, I, I, L, L, L, I, I, I, F, F, P]),
+    "diqt_linear_small_workspace_bytes": (Z, [I, I, I]),
+    "diqt_linear_small_fwd": (I, [P, P, P, P, I, I, I, P]),
+    "diqt_linear_small_bwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, P]),
 }
 
 _lib = None

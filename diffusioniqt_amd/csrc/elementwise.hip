@@ -29,10 +29,25 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, float* __restrict__
         for (int v = 0; v < NV; ++v)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[v][j] = 0.f;
+        F fl = f;
+        fl.prep(b, cq * 4);          // per-thread loop invariants (a thread keeps its channel quad)
         if (rr < rpar) {
-            for (int r = r0 + rr; r < r1; r += rpar) {
+            int r = r0 + rr;
+            // 4 independent 16-byte loads in flight per lane (the reduction is latency-bound otherwise)
+            for (; r + 3 * rpar < r1; r += 4 * rpar) {
+                float o[4][NV][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fl.vec4(((size_t)b * rows + r + u * rpar) * C + cq * 4, b, cq * 4, o[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[v][j] += o[u][v][j];
+            }
+            for (; r < r1; r += rpar) {
                 float o[NV][4];
-                f.vec4(((size_t)b * rows + r) * C + cq * 4, b, cq * 4, o);
+                fl.vec4(((size_t)b * rows + r) * C + cq * 4, b, cq * 4, o);
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -82,6 +97,7 @@ static inline int red_nblk(int rows) {
 // ---------------------------------------------------------------------------------------------
 struct MomentsF {
     const float* x;
+    __device__ void prep(int, int) {}
     __device__ void vec4(size_t i, int, int, float (&o)[2][4]) const {
         const float4 v = *reinterpret_cast<const float4*>(x + i);
         o[0][0] = v.x; o[0][1] = v.y; o[0][2] = v.z; o[0][3] = v.w;
@@ -140,15 +156,19 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
     const float* xb = x + (size_t)b * per;
     float* yb = y + (size_t)b * per;
     if (VEC) {
-        const size_t n4 = per >> 2;
-        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-            const int c = (int)((i * 4) % C);
+        // the host sizes the grid so that (gridDim.x * 1024) % C == 0: a thread keeps its 4 channels for the whole
+        // loop and the per-(b,c) coefficients live in registers
+        const size_t n4 = per >> 2, i0 = blockIdx.x * (size_t)256 + threadIdx.x;
+        const int c = (int)((i0 * 4) % C);
+        float A[4], Bc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k.get(b, c + j, A[j], Bc[j]);
+        for (size_t i = i0; i < n4; i += (size_t)gridDim.x * 256) {
             float4 v = *reinterpret_cast<const float4*>(xb + i * 4);
-            float A, Bc;
-            k.get(b, c, A, Bc);     v.x = act_fwd(A * v.x + Bc, act);
-            k.get(b, c + 1, A, Bc); v.y = act_fwd(A * v.y + Bc, act);
-            k.get(b, c + 2, A, Bc); v.z = act_fwd(A * v.z + Bc, act);
-            k.get(b, c + 3, A, Bc); v.w = act_fwd(A * v.w + Bc, act);
+            v.x = act_fwd(A[0] * v.x + Bc[0], act);
+            v.y = act_fwd(A[1] * v.y + Bc[1], act);
+            v.z = act_fwd(A[2] * v.z + Bc[2], act);
+            v.w = act_fwd(A[3] * v.w + Bc[3], act);
             *reinterpret_cast<float4*>(yb + i * 4) = v;
         }
     } else {
@@ -173,13 +193,27 @@ struct GnBwdF {
         const float dz = dyv * act_grad(A * xv + Bc, act);
         s1 = dz; s2 = dz * xhat;
     }
-    __device__ void vec4(size_t i, int b, int c, float (&o)[2][4]) const {
+    float cA[4], cB[4], cm[4], cr[4];      // filled by prep() on the device
+    __device__ void prep(int b, int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            k.get(b, c + j, cA[j], cB[j]);
+            const int g = (c + j) / (k.C / k.G);
+            cm[j] = k.mean[b * k.G + g]; cr[j] = k.rstd[b * k.G + g];
+        }
+    }
+    __device__ __forceinline__ void onej(float xv, float dyv, int j, float& s1, float& s2) const {
+        const float xhat = (xv - cm[j]) * cr[j];
+        const float dz = dyv * act_grad(cA[j] * xv + cB[j], act);
+        s1 = dz; s2 = dz * xhat;
+    }
+    __device__ void vec4(size_t i, int, int, float (&o)[2][4]) const {
         const float4 xv = *reinterpret_cast<const float4*>(x + i);
         const float4 dv = *reinterpret_cast<const float4*>(dy + i);
-        one(xv.x, dv.x, b, c, o[0][0], o[1][0]);
-        one(xv.y, dv.y, b, c + 1, o[0][1], o[1][1]);
-        one(xv.z, dv.z, b, c + 2, o[0][2], o[1][2]);
-        one(xv.w, dv.w, b, c + 3, o[0][3], o[1][3]);
+        onej(xv.x, dv.x, 0, o[0][0], o[1][0]);
+        onej(xv.y, dv.y, 1, o[0][1], o[1][1]);
+        onej(xv.z, dv.z, 2, o[0][2], o[1][2]);
+        onej(xv.w, dv.w, 3, o[0][3], o[1][3]);
     }
     __device__ void scalar(size_t i, int b, int c, float (&o)[2]) const { one(x[i], dy[i], b, c, o[0], o[1]); }
 };
@@ -244,14 +278,28 @@ __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restr
         return A * dz - r * (m12[2 * (b * G + g)] + xhat * m12[2 * (b * G + g) + 1]);
     };
     if (VEC) {
-        const size_t n4 = per >> 2;
-        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-            const int c = (int)((i * 4) % C);
+        // grid sized so a thread keeps its 4 channels (see gn_act_fwd_kernel): coefficients hoisted into registers
+        const size_t n4 = per >> 2, i0 = blockIdx.x * (size_t)256 + threadIdx.x;
+        const int c = (int)((i0 * 4) % C);
+        float A[4], Bc[4], r[4], m[4], m1[4], m2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            k.get(b, c + j, A[j], Bc[j]);
+            const int g = (c + j) / Cg;
+            r[j] = k.rstd[b * G + g]; m[j] = k.mean[b * G + g];
+            m1[j] = m12[2 * (b * G + g)]; m2[j] = m12[2 * (b * G + g) + 1];
+        }
+        auto onej = [&](float xv, float dyv, int j) -> float {
+            const float xhat = (xv - m[j]) * r[j];
+            const float dz = dyv * act_grad(A[j] * xv + Bc[j], act);
+            return A[j] * dz - r[j] * (m1[j] + xhat * m2[j]);
+        };
+        for (size_t i = i0; i < n4; i += (size_t)gridDim.x * 256) {
             const float4 xv = *reinterpret_cast<const float4*>(xb + i * 4);
             const float4 dv = *reinterpret_cast<const float4*>(dyb + i * 4);
             float4 o;
-            o.x = one(xv.x, dv.x, c); o.y = one(xv.y, dv.y, c + 1);
-            o.z = one(xv.z, dv.z, c + 2); o.w = one(xv.w, dv.w, c + 3);
+            o.x = onej(xv.x, dv.x, 0); o.y = onej(xv.y, dv.y, 1);
+            o.z = onej(xv.z, dv.z, 2); o.w = onej(xv.w, dv.w, 3);
             *reinterpret_cast<float4*>(dxb + i * 4) = o;
         }
     } else {
@@ -313,6 +361,7 @@ struct ChanLnDgF {
         const size_t r = i / C;
         return dy[i] * (x[i] - mean[r]) * rstd[r];
     }
+    __device__ void prep(int, int) {}
     __device__ void vec4(size_t i, int, int, float (&o)[1][4]) const {
         o[0][0] = one(i); o[0][1] = one(i + 1); o[0][2] = one(i + 2); o[0][3] = one(i + 3);
     }
@@ -372,6 +421,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 struct IdentF {
     const float* x;
+    __device__ void prep(int, int) {}
     __device__ void vec4(size_t i, int, int, float (&o)[1][4]) const {
         const float4 v = *reinterpret_cast<const float4*>(x + i);
         o[0][0] = v.x; o[0][1] = v.y; o[0][2] = v.z; o[0][3] = v.w;
@@ -380,6 +430,7 @@ struct IdentF {
 };
 struct ProdF {
     const float *a, *b;
+    __device__ void prep(int, int) {}
     __device__ void vec4(size_t i, int, int, float (&o)[1][4]) const {
         const float4 u = *reinterpret_cast<const float4*>(a + i);
         const float4 v = *reinterpret_cast<const float4*>(b + i);
@@ -880,6 +931,83 @@ __global__ void learned_sinu_bwd_kernel(const float* __restrict__ t, const float
     dw[j] = s;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// skinny linear layers (time-conditioning MLPs: M = batch rows <= 64).  The MFMA conv kernel spends ~28 us
+// of pipeline fill on these; here one wave owns one output column and streams its weight row once.
+// ---------------------------------------------------------------------------------------------
+constexpr int LS_MB = 8;      // rows per register block
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int M, int K, int N) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* w = W + (size_t)n * K;
+    for (int m0 = 0; m0 < M; m0 += LS_MB) {
+        float acc[LS_MB];
+#pragma unroll
+        for (int j = 0; j < LS_MB; ++j) acc[j] = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float wv = w[k];
+#pragma unroll
+            for (int j = 0; j < LS_MB; ++j)
+                if (m0 + j < M) acc[j] += x[(size_t)(m0 + j) * K + k] * wv;
+        }
+#pragma unroll
+        for (int j = 0; j < LS_MB; ++j) {
+            const float s = wave_sum(acc[j]);
+            if (lane == 0 && m0 + j < M) y[(size_t)(m0 + j) * N + n] = s + (bias ? bias[n] : 0.f);
+        }
+    }
+}
+
+// dW[n][k] = sum_m dy[m][n] x[m][k];  db[n] = sum_m dy[m][n]
+__global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ dw, float* __restrict__ db,
+                                                              int M, int K, int N) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i >= (size_t)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    float s = 0.f, sb = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float d = dy[(size_t)m * N + n];
+        s += d * x[(size_t)m * K + k];
+        sb += d;
+    }
+    dw[i] = s;
+    if (db && k == 0) db[n] = sb;
+}
+
+// dX partials: part[slice][m][k] = sum_{n in slice} dy[m][n] W[n][k]   (grid: (ceil(K/256), slices), M <= 64)
+__global__ __launch_bounds__(256) void linear_small_dx_part_kernel(const float* __restrict__ W, const float* __restrict__ dy,
+                                                                   float* __restrict__ part, int M, int K, int N, int nPer) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = blockIdx.y * nPer, n1 = min(N, n0 + nPer);
+    for (int m0 = 0; m0 < M; m0 += LS_MB) {
+        float acc[LS_MB];
+#pragma unroll
+        for (int j = 0; j < LS_MB; ++j) acc[j] = 0.f;
+        if (k < K)
+            for (int n = n0; n < n1; ++n) {
+                const float wv = W[(size_t)n * K + k];
+#pragma unroll
+                for (int j = 0; j < LS_MB; ++j)
+                    if (m0 + j < M) acc[j] += dy[(size_t)(m0 + j) * N + n] * wv;      // wave-uniform address: scalar load
+            }
+        if (k < K)
+#pragma unroll
+            for (int j = 0; j < LS_MB; ++j)
+                if (m0 + j < M) part[((size_t)blockIdx.y * M + m0 + j) * K + k] = acc[j];
+    }
+}
+__global__ __launch_bounds__(256) void linear_small_dx_sum_kernel(const float* __restrict__ part, float* __restrict__ dx,
+                                                                  int MK, int slices) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= MK) return;
+    float s = 0.f;
+    for (int q = 0; q < slices; ++q) s += part[(size_t)q * MK + i];
+    dx[i] = s;
+}
 }  // namespace diqt
 
 using namespace diqt;
@@ -915,6 +1043,15 @@ extern "C" int diqt_groupnorm_stats(const float* x, float* mean, float* rstd, vo
     return check_launch("groupnorm_stats/final");
 }
 
+// grid.x for the vectorised GN apply kernels: a multiple of C / gcd(C, 1024) so every thread's channel quad is loop-invariant
+static unsigned gn_grid(size_t per, int C) {
+    int a = C, b = 1024;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const unsigned m = (unsigned)(C / a);
+    unsigned n = grid_for(per / 4 + 1, 256, 2048);
+    return (n + m - 1) / m * m;
+}
+
 extern "C" int diqt_gn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, const float* scale, const float* shift, int cond_stride, float* y,
                                int B, int rows, int C, int G, int act, void* stream) {
@@ -924,7 +1061,7 @@ extern "C" int diqt_gn_act_fwd(const float* x, const float* mean, const float* r
     DIQT_REQUIRE(!scale || cond_stride >= C, DIQT_E_SHAPE, "gn_act_fwd: cond_stride < C");
     GnCoef k{mean, rstd, gamma, beta, scale, shift, C, G, cond_stride};
     const size_t per = (size_t)rows * C;
-    const dim3 grid(grid_for(per / 4 + 1, 256, 1024), B);
+    const dim3 grid(gn_grid(per, C), B);
     if (vec_ok(x, y, nullptr, per, C))
         hipLaunchKernelGGL(gn_act_fwd_kernel<true>, grid, dim3(256), 0, STREAM, x, y, k, rows, act);
     else
@@ -965,7 +1102,7 @@ extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mea
                        dshift, m12, B, 1.f / ((float)rows * (C / G)));
     rc = check_launch("gn_act_bwd/final");
     if (rc) return rc;
-    const dim3 grid(grid_for(per / 4 + 1, 256, 1024), B);
+    const dim3 grid(gn_grid(per, C), B);
     if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
     else hipLaunchKernelGGL(gn_act_bwd_dx_kernel<false>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
     return check_launch("gn_act_bwd/dx");
@@ -1305,4 +1442,44 @@ extern "C" int diqt_attn_softmax_bwd(const float* p, const float* dp, float* dsi
     hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3(grid_for(rows, 4, 16384)), dim3(256), 0, STREAM, p, dp, dsim, drel, dnull_bias,
                        rows, n, h, n_extra, n_self, causal);
     return check_launch("attn_softmax_bwd");
+}
+
+static int ls_slices(int N) { int s = (N + 15) / 16; return s > 64 ? 64 : (s < 1 ? 1 : s); }
+
+extern "C" size_t diqt_linear_small_workspace_bytes(int M, int K, int N) {
+    return (size_t)ls_slices(N) * M * K * sizeof(float);
+}
+
+extern "C" int diqt_linear_small_fwd(const float* x, const float* W, const float* bias, float* y, int M, int K, int N,
+                                     void* stream) {
+    DIQT_REQUIRE(x && W && y, DIQT_E_ALIGN, "linear_small_fwd: null pointer");
+    DIQT_REQUIRE(M > 0 && M <= 64 && K > 0 && N > 0, DIQT_E_SHAPE, "linear_small_fwd: needs 0 < M <= 64 (got %d)", M);
+    hipLaunchKernelGGL(linear_small_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, STREAM, x, W, bias, y, M, K, N);
+    return check_launch("linear_small_fwd");
+}
+
+extern "C" int diqt_linear_small_bwd(const float* x, const float* W, const float* dy, float* dx, float* dw, float* db,
+                                     void* workspace, size_t workspace_bytes, int M, int K, int N, void* stream) {
+    DIQT_REQUIRE(x && W && dy, DIQT_E_ALIGN, "linear_small_bwd: null pointer");
+    DIQT_REQUIRE(M > 0 && M <= 64 && K > 0 && N > 0, DIQT_E_SHAPE, "linear_small_bwd: needs 0 < M <= 64 (got %d)", M);
+    int rc = DIQT_OK;
+    if (dw) {
+        hipLaunchKernelGGL(linear_small_dw_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, STREAM, x, dy, dw,
+                           db, M, K, N);
+        rc = check_launch("linear_small_bwd/dw");
+        if (rc) return rc;
+    }
+    if (dx) {
+        const int slices = ls_slices(N), nPer = (N + slices - 1) / slices;
+        DIQT_REQUIRE(workspace && workspace_bytes >= diqt_linear_small_workspace_bytes(M, K, N), DIQT_E_WORKSPACE,
+                     "linear_small_bwd: workspace too small");
+        float* part = static_cast<float*>(workspace);
+        hipLaunchKernelGGL(linear_small_dx_part_kernel, dim3((K + 255) / 256, slices), dim3(256), 0, STREAM, W, dy, part, M, K,
+                           N, nPer);
+        rc = check_launch("linear_small_bwd/dx_part");
+        if (rc) return rc;
+        hipLaunchKernelGGL(linear_small_dx_sum_kernel, dim3((M * K + 255) / 256), dim3(256), 0, STREAM, part, dx, M * K, slices);
+        rc = check_launch("linear_small_bwd/dx_sum");
+    }
+    return rc;
 }

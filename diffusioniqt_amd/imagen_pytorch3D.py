@@ -332,6 +332,20 @@ class SE3D(nn.Module):
         return ops.se_gate_residual(x, self.fc[0].weight, self.fc[2].weight, residual)
 
 
+class TimeCond:
+    """The time embedding handed to every ResnetBlock of one U-Net evaluation.  Each block's time_mlp starts with the
+    same Mish(t) (imagen_pytorch3D.py:575-578), so it is evaluated once here and shared."""
+    __slots__ = ("t", "_act")
+
+    def __init__(self, t):
+        self.t, self._act = t, None
+
+    def mish(self):
+        if self._act is None:
+            self._act = ops.mish(self.t)
+        return self._act
+
+
 class ResnetBlock(nn.Module):
     """imagen_pytorch3D.py:568-614."""
 
@@ -347,8 +361,8 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x, time_emb=None):
         scale_shift = None
-        if exists(self.time_mlp) and exists(time_emb):
-            scale_shift = self.time_mlp(time_emb)            # [B, 2C]: scale | shift
+        if exists(self.time_mlp) and exists(time_emb):      # [B, 2C]: scale | shift
+            scale_shift = self.time_mlp[1](time_emb.mish()) if isinstance(time_emb, TimeCond) else self.time_mlp(time_emb)
         h = self.block1(x)
         res = self.res_conv(x)
         if isinstance(self.se, SE3D):
@@ -742,7 +756,7 @@ class Unet(nn.Module):
             x = boundary_pad(x)
         x = self.init_conv(x)
 
-        t = self.to_time_cond(self.to_time_hiddens(time.float().contiguous()))
+        t = TimeCond(self.to_time_cond(self.to_time_hiddens(time.float().contiguous())))
 
         hiddens = []
         last = len(self.downs)

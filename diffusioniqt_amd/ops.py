@@ -40,7 +40,7 @@ class KernelTimer:
     """Optional HIP-event timing of the dominant kernel (conv3d fwd/bwd-data launches) for bench.py's roofline:
     events are recorded on the stream the kernel is launched on (torch's current stream)."""
     def __init__(self):
-        self.records = []      # (start_event, end_event, flops, tag)
+        self.records = []      # (start_event, end_event, flops, tag, shape)
         self.enabled = False
 
     def reset(self):
@@ -49,9 +49,18 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for s, e, flops, tag in self.records:
+        for s, e, flops, tag, _ in self.records:
             ms, fl, n = out.get(tag, (0.0, 0.0, 0))
             out[tag] = (ms + s.elapsed_time(e), fl + flops, n + 1)
+        return out
+
+    def by_shape(self):
+        """{(tag, shape): (ms, flops, launches)} -- tools/shape_profile.py"""
+        torch.cuda.synchronize()
+        out = {}
+        for s, e, flops, tag, shape in self.records:
+            ms, fl, n = out.get((tag, shape), (0.0, 0.0, 0))
+            out[(tag, shape)] = (ms + s.elapsed_time(e), fl + flops, n + 1)
         return out
 
 
@@ -115,7 +124,8 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0)):
               _stream())
     if TIMER.enabled:
         e.record()
-        TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_kernel"))
+        TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_kernel",
+                              (B, D, H, W, Cin, Cout, kd, kh, kw)))
     return y
 
 
@@ -159,7 +169,8 @@ class _Conv3dFn(Function):
             if TIMER.enabled:
                 e.record()
                 Do, Ho, Wo = dy.shape[1:4]
-                TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_bwd_weight_kernel"))
+                TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_bwd_weight_kernel",
+                                      (B, D, H, W, Cin, Cout, kd, kh, kw)))
         return dx, dw, db, None, (dy if ctx.has_res else None), None
 
 
@@ -178,10 +189,42 @@ def conv3d(x, weight, bias=None, padding=(0, 0, 0), residual=None, extra_pad=(0,
     return _Conv3dFn.apply(x, weight, bias, padding, residual, extra_pad)
 
 
+class _LinearSmallFn(Function):
+    """nn.Linear over <= 64 rows (time-conditioning MLPs): one wave per output column, no MFMA pipeline fill."""
+    @staticmethod
+    def forward(ctx, x2, weight, bias):
+        _chk(x2, weight, bias)
+        M, K = x2.shape
+        N = weight.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+        _lib.call("diqt_linear_small_fwd", x2, weight, bias, y, M, K, N, _stream())
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x2.shape
+        N = weight.shape[0]
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dx = torch.empty_like(x2) if need_dx else None
+        dw = torch.empty_like(weight) if need_dw else None
+        db = torch.empty(N, dtype=torch.float32, device=x2.device) if (need_dw and ctx.has_bias) else None
+        n = _lib.query("diqt_linear_small_workspace_bytes", M, K, N)
+        ws = _workspace(n, x2.device)
+        _lib.call("diqt_linear_small_bwd", x2, weight, dy, dx, dw, db, ws, n, M, K, N, _stream())
+        return dx, dw, db
+
+
 def linear(x, weight, bias=None):
-    """x[..., Cin] @ weight[Cout, Cin]^T + bias through the same MFMA kernel (1x1x1 conv over rows)."""
+    """x[..., Cin] @ weight[Cout, Cin]^T + bias: skinny kernel for <= 64 rows, otherwise the MFMA kernel (1x1x1 conv)."""
     Cout, Cin = weight.shape
     lead = x.shape[:-1]
+    rows = x.numel() // Cin
+    if 0 < rows <= 64:
+        return _LinearSmallFn.apply(x.reshape(rows, Cin).contiguous(), weight.contiguous(), bias).reshape(*lead, Cout)
     y = _Conv3dFn.apply(x.reshape(1, 1, 1, -1, Cin), weight.view(Cout, Cin, 1, 1, 1), bias, (0, 0, 0), None, (0, 0, 0))
     return y.reshape(*lead, Cout)
 

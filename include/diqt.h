@@ -142,6 +142,15 @@ int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, con
 int diqt_act_fwd(const float* x, float* y, size_t n, int act, void* stream);
 int diqt_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, void* stream);
 
+/* Skinny nn.Linear for the time-conditioning MLPs (imagen_pytorch3D.py:589-606 to_time_hiddens / to_time_cond /
+ * to_time_tokens, :554-557 ResnetBlock.time_mlp; imagen_video.py:1226-1262): y[M][N] = x[M][K] W[N][K]^T + bias,
+ * 0 < M <= 64 (batch rows).  W is the nn.Linear [out][in] layout.  bias may be NULL.                    */
+int diqt_linear_small_fwd(const float* x, const float* W, const float* bias, float* y, int M, int K, int N, void* stream);
+/* dx[M][K], dw[N][K], db[N] (each may be NULL; db needs dw).  dx goes through `workspace`.             */
+size_t diqt_linear_small_workspace_bytes(int M, int K, int N);
+int diqt_linear_small_bwd(const float* x, const float* W, const float* dy, float* dx, float* dw, float* db,
+                          void* workspace, size_t workspace_bytes, int M, int K, int N, void* stream);
+
 /* LearnedSinusoidalPosEmb (imagen_pytorch3D.py:518-533): out[b] = [t, sin(2 pi t w), cos(2 pi t w)] */
 int diqt_learned_sinu_fwd(const float* t, const float* w, float* out, int B, int half, void* stream);
 /* dw[half] (overwritten) from dout[B][2*half+1] */

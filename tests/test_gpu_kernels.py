@@ -96,6 +96,29 @@ def test_conv3d_residual_epilogue_and_linear(ops):
     close(xld.grad, wl.sum(0)[None, :].expand(3, 17), what="linear dx")
 
 
+@pytest.mark.parametrize("M,K,N,bias", [(8, 256, 128, True), (1, 17, 256, True), (64, 100, 33, False), (65, 64, 48, True),
+                                         (16, 1024, 256, True)])
+def test_linear_skinny_and_mfma_paths(ops, M, K, N, bias):
+    """nn.Linear call sites (time MLPs: <= 64 rows take diqt_linear_small_*, more rows the MFMA kernel)."""
+    g = torch.Generator().manual_seed(M * 1000 + K)
+    x = torch.randn(M, K, generator=g).double()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).double()
+    b = torch.randn(N, generator=g).double() if bias else None
+    up = torch.randn(M, N, generator=g).double()
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    F.linear(xr, wr, br).backward(up)
+    xd, wd = x.float().to(DEV).requires_grad_(), w.float().to(DEV).requires_grad_()
+    bd = b.float().to(DEV).requires_grad_() if bias else None
+    y = ops.linear(xd, wd, bd)
+    close(y, F.linear(x, w, b), what="linear fwd")
+    y.backward(up.float().to(DEV))
+    close(xd.grad, xr.grad, what="linear dx")
+    close(wd.grad, wr.grad, what="linear dw")
+    if bias:
+        close(bd.grad, br.grad, what="linear db")
+
+
 @pytest.mark.parametrize("groups,stride,k,pad,Cin,Cout", [(16, 1, 3, 1, 16, 16), (8, 4, 4, 0, 8, 8), (1, 2, 2, 0, 4, 6),
                                                             (12, 1, (3, 1, 1), (1, 0, 0), 12, 12)])
 def test_conv3d_direct(ops, groups, stride, k, pad, Cin, Cout):

@@ -677,7 +677,8 @@ struct BwGeom2 {
 template <bool VEC4, int NRX, int NRY, int MAXT, bool SPLIT_CO, int NTHR>
 __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ dy,
-                                                                  float* __restrict__ slabs, BwGeom2 bg) {
+                                                                  float* __restrict__ slabs,
+                                                                  float* __restrict__ bias_part, BwGeom2 bg) {
     const ConvGeom& g = bg.g;
     constexpr int COB = SPLIT_CO ? 128 : 32;
     constexpr int NWAVE = NTHR / 64;
@@ -748,6 +749,10 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
     };
     float4 RX[NRX], RY[NRY];
     unsigned okx = 0, oky = 0;
+    // bias gradient rides along: the workgroups of (chunk 0, tap group 0) see every dY element of their co-block once;
+    // a thread always stages the same channel quad (NTHR % (COB/4) == 0), so it keeps one float4 of column sums
+    const bool doBias = bias_part != nullptr && chunk == 0 && tg == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     // all loads are unconditional (clamped address) so hipcc emits them back to back; invalid pieces are zero-selected
     auto issue_loads = [&](int slot) {
 #pragma unroll
@@ -802,8 +807,9 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
 #pragma unroll
         for (int r = 0; r < NRY; ++r) {
             const int idx = tid + NTHR * r;
-            *reinterpret_cast<float4*>(dyt + (idx / (COB / 4)) * COB + (idx % (COB / 4)) * 4) =
-                (oky >> r) & 1u ? RY[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 q = (oky >> r) & 1u ? RY[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(dyt + (idx / (COB / 4)) * COB + (idx % (COB / 4)) * 4) = q;
+            if (doBias) { bsum.x += q.x; bsum.y += q.y; bsum.z += q.z; bsum.w += q.w; }
         }
     };
 
@@ -871,6 +877,18 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
                 q < 5 ? (unsigned long long)tsum[q] : (unsigned long long)((__builtin_amdgcn_s_getreg((6 - 1) << 11 | 0 << 6 | 4) >> 4) & 3);
 #undef DIQT_ACC
 
+    if (doBias) {                        // block-uniform
+        __syncthreads();
+        float4* sb = reinterpret_cast<float4*>(smem);
+        sb[tid] = bsum;
+        __syncthreads();
+        if (tid < COB && n0 + tid < g.CoutPad) {
+            float sacc = 0.f;
+            for (int t = tid >> 2; t < NTHR; t += COB / 4) sacc += reinterpret_cast<const float*>(&sb[t])[tid & 3];
+            bias_part[(size_t)blockIdx.y * g.CoutPad + n0 + tid] = sacc;
+        }
+    }
+
     float* slab = slabs + ((size_t)blockIdx.y * KPAR + kpar) * g.nChunks * T * g.CoutPad * CK;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
@@ -883,9 +901,10 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
     }
 }
 
-// dW[co][ci][tap] = sum_ks slab[ks][ci/32][tap][co][ci%32]
+// dW[co][ci][tap] = sum_ks slab[ks][ci/32][tap][co][ci%32];  optionally dbias[c] = sum_y bias_part[y][c]
 __global__ void conv_reduce_dw_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                      int Cout, int Cin, int T, int CoutPad, int nChunks, int ksplit) {
+                                      int Cout, int Cin, int T, int CoutPad, int nChunks, int ksplit,
+                                      const float* __restrict__ bias_part, float* __restrict__ dbias, int biasParts) {
     const size_t total = (size_t)Cout * Cin * T;
     const size_t slabElems = (size_t)nChunks * T * CoutPad * CK;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
@@ -895,11 +914,23 @@ __global__ void conv_reduce_dw_kernel(const float* __restrict__ slabs, float* __
         size_t r = i / Cin;
         const int co = (int)(r % Cout);
         const int tap = (int)(r / Cout);
-        const size_t src = (((size_t)(ci / CK) * T + tap) * CoutPad + co) * CK + (ci % CK);
+        const float* src = slabs + (((size_t)(ci / CK) * T + tap) * CoutPad + co) * CK + (ci % CK);
         float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += slabs[(size_t)k * slabElems + src];
+        int k = 0;
+        for (; k + 4 <= ksplit; k += 4) {          // 4 independent loads in flight, summation order unchanged
+            const float a0 = src[(size_t)k * slabElems], a1 = src[(size_t)(k + 1) * slabElems];
+            const float a2 = src[(size_t)(k + 2) * slabElems], a3 = src[(size_t)(k + 3) * slabElems];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; k < ksplit; ++k) s += src[(size_t)k * slabElems];
         dw[((size_t)co * Cin + ci) * T + tap] = s;
     }
+    if (dbias)
+        for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < (size_t)Cout; c += (size_t)gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int y = 0; y < biasParts; ++y) s += bias_part[(size_t)y * CoutPad + c];
+            dbias[c] = s;
+        }
 }
 
 // column sums: out[c] = sum_rows x[row][c]; stage 1 -> partial[block][C], stage 2 -> out
@@ -1151,7 +1182,7 @@ extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, in
     if (bw2_plan(bg.g, b2, splitCo, ks2, lds2) && ks2 * (splitCo ? 1 : BW2_KPAR_A) > ksplit) ksplit = ks2 * (splitCo ? 1 : BW2_KPAR_A);
     const size_t slab = (size_t)bg.g.nChunks * kd * kh * kw * bg.g.CoutPad * CK * sizeof(float);
     const size_t colsum = (size_t)1024 * Cout * sizeof(float);
-    const size_t need = (size_t)ksplit * slab;
+    const size_t need = (size_t)ksplit * slab + (size_t)ksplit * bg.g.CoutPad * sizeof(float);   // + bias partials (v2)
     return need > colsum ? need : colsum;
 }
 
@@ -1183,8 +1214,10 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     bool splitCo = false;
     int ks2 = 0;
     size_t lds2 = 0;
+    float* bias_part = nullptr;      // v2 kernel: per-split-K bias-gradient partials behind the slabs
+    int bias_parts = 0;
     if (bw2_plan(g, b2, splitCo, ks2, lds2)) {
-        void (*k2)(const float*, const float*, float*, BwGeom2) =
+        void (*k2)(const float*, const float*, float*, float*, BwGeom2) =
             splitCo ? (vec4 ? conv_bwd_weight2_kernel<true, 4, 16, BW2_MAXT_B, true, 256> : conv_bwd_weight2_kernel<false, 4, 16, BW2_MAXT_B, true, 256>)
                     : (vec4 ? conv_bwd_weight2_kernel<true, 7, 2, BW2_MAXT_A, false, 512> : conv_bwd_weight2_kernel<false, 7, 2, BW2_MAXT_A, false, 512>);
         if (lds2 > 64 * 1024) {
@@ -1198,7 +1231,9 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
             if (!bdbg) hipMalloc(&bdbg, (size_t)65536 * 8 * sizeof(unsigned long long));
             b2.g.dbg = bdbg; g_dbg_ptr = bdbg; g_dbg_n = g.nChunks * b2.coBlocks * b2.tapGroups * ks2 * (splitCo ? 4 : 8);
         }
-        hipLaunchKernelGGL(k2, dim3(g.nChunks * b2.coBlocks * b2.tapGroups, ks2), dim3(splitCo ? 256 : 512), lds2, s, x, dy, slabs, b2);
+        if (dbias) { bias_part = slabs + (size_t)ksplit * g.nChunks * T * g.CoutPad * CK; bias_parts = ks2; }
+        hipLaunchKernelGGL(k2, dim3(g.nChunks * b2.coBlocks * b2.tapGroups, ks2), dim3(splitCo ? 256 : 512), lds2, s, x, dy, slabs,
+                           bias_part, b2);
         rc = check_launch("conv3d_bwd_weight(v2)");
     } else {
         const dim3 grid(g.nChunks * g.nNt * g.kd * bg.tapGroups, ksplit);
@@ -1208,10 +1243,10 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     if (rc) return rc;
     const size_t total = (size_t)Cout * Cin * T;
     hipLaunchKernelGGL(conv_reduce_dw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, slabs, dw, Cout, Cin, T,
-                       g.CoutPad, g.nChunks, ksplit);
+                       g.CoutPad, g.nChunks, ksplit, bias_part, bias_part ? dbias : nullptr, bias_parts);
     rc = check_launch("conv_reduce_dw");
     if (rc) return rc;
-    if (dbias) {
+    if (dbias && !bias_part) {
         const size_t rows = (size_t)g.B * g.Do * g.Ho * g.Wo;
         unsigned nblk = (unsigned)((rows + 255) / 256);
         if (nblk > 512) nblk = 512;

@@ -163,7 +163,22 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
         float A[4], Bc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) k.get(b, c + j, A[j], Bc[j]);
-        for (size_t i = i0; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t st = (size_t)gridDim.x * 256;
+        size_t i = i0;
+        for (; i + 3 * st < n4; i += 4 * st) {          // 4 loads in flight
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xb + (i + u * st) * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u].x = act_fwd(A[0] * v[u].x + Bc[0], act);
+                v[u].y = act_fwd(A[1] * v[u].y + Bc[1], act);
+                v[u].z = act_fwd(A[2] * v[u].z + Bc[2], act);
+                v[u].w = act_fwd(A[3] * v[u].w + Bc[3], act);
+                *reinterpret_cast<float4*>(yb + (i + u * st) * 4) = v[u];
+            }
+        }
+        for (; i < n4; i += st) {
             float4 v = *reinterpret_cast<const float4*>(xb + i * 4);
             v.x = act_fwd(A[0] * v.x + Bc[0], act);
             v.y = act_fwd(A[1] * v.y + Bc[1], act);
@@ -294,7 +309,24 @@ __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restr
             const float dz = dyv * act_grad(A[j] * xv + Bc[j], act);
             return A[j] * dz - r[j] * (m1[j] + xhat * m2[j]);
         };
-        for (size_t i = i0; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t st = (size_t)gridDim.x * 256;
+        size_t i = i0;
+        for (; i + st < n4; i += 2 * st) {              // 4 loads in flight
+            float4 xv[2], dv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                xv[u] = *reinterpret_cast<const float4*>(xb + (i + u * st) * 4);
+                dv[u] = *reinterpret_cast<const float4*>(dyb + (i + u * st) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float4 o;
+                o.x = onej(xv[u].x, dv[u].x, 0); o.y = onej(xv[u].y, dv[u].y, 1);
+                o.z = onej(xv[u].z, dv[u].z, 2); o.w = onej(xv[u].w, dv[u].w, 3);
+                *reinterpret_cast<float4*>(dxb + (i + u * st) * 4) = o;
+            }
+        }
+        for (; i < n4; i += st) {
             const float4 xv = *reinterpret_cast<const float4*>(xb + i * 4);
             const float4 dv = *reinterpret_cast<const float4*>(dyb + i * 4);
             float4 o;
@@ -1044,11 +1076,14 @@ extern "C" int diqt_groupnorm_stats(const float* x, float* mean, float* rstd, vo
 }
 
 // grid.x for the vectorised GN apply kernels: a multiple of C / gcd(C, 1024) so every thread's channel quad is loop-invariant
-static unsigned gn_grid(size_t per, int C) {
+static unsigned gn_grid(size_t per, int C, int B) {
     int a = C, b = 1024;
     while (b) { const int t = a % b; a = b; b = t; }
     const unsigned m = (unsigned)(C / a);
-    unsigned n = grid_for(per / 4 + 1, 256, 2048);
+    // one resident round of workgroups (256 CUs x 8 blocks) shared by the B batch slices: long-lived threads amortise
+    // the coefficient prologue and keep several 16-byte loads in flight each
+    unsigned want = (2048u + (unsigned)B - 1) / (unsigned)B;
+    unsigned n = grid_for(per / 4 + 1, 256, want < 1 ? 1 : want);
     return (n + m - 1) / m * m;
 }
 
@@ -1061,7 +1096,7 @@ extern "C" int diqt_gn_act_fwd(const float* x, const float* mean, const float* r
     DIQT_REQUIRE(!scale || cond_stride >= C, DIQT_E_SHAPE, "gn_act_fwd: cond_stride < C");
     GnCoef k{mean, rstd, gamma, beta, scale, shift, C, G, cond_stride};
     const size_t per = (size_t)rows * C;
-    const dim3 grid(gn_grid(per, C), B);
+    const dim3 grid(gn_grid(per, C, B), B);
     if (vec_ok(x, y, nullptr, per, C))
         hipLaunchKernelGGL(gn_act_fwd_kernel<true>, grid, dim3(256), 0, STREAM, x, y, k, rows, act);
     else
@@ -1102,7 +1137,7 @@ extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mea
                        dshift, m12, B, 1.f / ((float)rows * (C / G)));
     rc = check_launch("gn_act_bwd/final");
     if (rc) return rc;
-    const dim3 grid(gn_grid(per, C), B);
+    const dim3 grid(gn_grid(per, C, B), B);
     if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
     else hipLaunchKernelGGL(gn_act_bwd_dx_kernel<false>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
     return check_launch("gn_act_bwd/dx");

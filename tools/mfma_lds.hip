@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters) {
                 for (int t = 0; t < NT; ++t) bv[t] = bn[t];
             }
         }
-    } else {
+    } else if (VAR == 3) {
         const float* ap = lds + l31 * 36 + 4 * h;
         const float* bp = lds + 8192 + l31 * 36 + 4 * h;
         for (int it = 0; it < iters * 14; ++it) {     // 14 "taps" x 32 MFMA ~ same MFMA count as 64 x 7
@@ -85,6 +85,69 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters) {
             }
         }
     }
+    if (VAR >= 4 && VAR <= 7) {
+        // conv-fwd tap structure: per "tap" 4 q-groups x 8 MFMA; fragments of q+1 prefetched inside the tap, but the
+        // first group of each tap is read cold (VAR 4); + a workgroup barrier per tap (VAR 5); + a weight-panel
+        // ds_write_b128 pair before the barrier (VAR 6); VAR 7 = VAR 4 with a per-tap moving address (VALU add)
+        const float* ap = lds + l31 * 36 + 4 * h;
+        const float* bp = lds + 8192 + l31 * 36 + 4 * h;
+        float4 wv = make_float4(1e-3f * lane, 0.f, 1.f, 2.f);
+        for (int it = 0; it < iters * 14; ++it) {
+            const float* at = ap + ((VAR == 7) ? (it % 27) * 36 : 0);
+            float4 a = *(const float4*)at, b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 32 * 36);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 an, b0n, b1n;
+                if (q < 3) { an = *(const float4*)(at + 8 * (q + 1)); b0n = *(const float4*)(bp + 8 * (q + 1)); b1n = *(const float4*)(bp + 32 * 36 + 8 * (q + 1)); }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+                if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
+            }
+            if (VAR == 6) {
+                *(float4*)(lds + 12288 + threadIdx.x * 4) = wv;
+                *(float4*)(lds + 12288 + 1024 + threadIdx.x * 4) = wv;
+            }
+            if (VAR == 5 || VAR == 6) __syncthreads();
+        }
+    }
+    if (VAR == 8) {
+        // weights global -> VGPR (fragment-major panels: [tap][r 0..7][lane][4], 8 KB per tap, 54 taps cycling through
+        // a 442 KB L2-resident buffer), prefetched one tap ahead; A fragments from LDS; no barrier, no weight LDS traffic
+        const float* ap = lds + l31 * 36 + 4 * h;
+        const float4* wg = reinterpret_cast<const float4*>(out + (1 << 20));       // scratch region of the out buffer
+        float4 w[8], wn[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r] = wg[r * 64 + lane];
+        for (int it = 0; it < iters * 14; ++it) {
+            const int tn = (it + 1) % 54;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) wn[r] = wg[(tn * 8 + r) * 64 + lane];
+            const float* at = ap + (it % 27) * 36;
+            float4 a = *(const float4*)at;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 an;
+                if (q < 3) an = *(const float4*)(at + 8 * (q + 1));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[2 * q].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[2 * q + 1].x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[2 * q].y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[2 * q + 1].y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[2 * q].z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[2 * q + 1].z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[2 * q].w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[2 * q + 1].w, acc[1], 0, 0, 0);
+                if (q < 3) a = an;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) w[r] = wn[r];
+        }
+    }
     float s = 0.f;
     for (int t = 0; t < NT; ++t) for (int j = 0; j < 16; ++j) s += acc[t][j];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -97,12 +160,12 @@ template <int VAR> void run(const char* name, float* out, int wgs) {
         hipLaunchKernelGGL(k<VAR>, dim3(wgs), dim3(256), 65536, 0, out, iters);
         hipEventRecord(e); hipEventSynchronize(e);
         float ms; hipEventElapsedTime(&ms, s, e);
-        const double nm = VAR == 3 ? (double)iters * 14 * 32 : (double)iters * 64 * NT;
+        const double nm = VAR >= 3 ? (double)iters * 14 * 32 : (double)iters * 64 * NT;
         if (rep == 5) printf("%-44s %d WG/CU: %.3f ms  %.1f TFLOP/s\n", name, wgs / 256, ms, wgs * 4 * nm * 4096.0 / ms / 1e9);
     }
 }
 int main(int argc, char** argv) {
-    float* out; hipMalloc(&out, 4096 * 256 * 4);
+    float* out; hipMalloc(&out, (4096 * 256 + (1 << 20)) * 4 + (1 << 21)); hipMemset(out, 0, (4096 * 256 + (1 << 20)) * 4 + (1 << 21));
     int rnd = argc > 1 ? atoi(argv[1]) : 0;
     hipMemcpyToSymbol(HIP_SYMBOL(g_random), &rnd, sizeof(int));
     printf("operands: %s\n", rnd ? "random full-range" : "smooth small");
@@ -111,6 +174,11 @@ int main(int argc, char** argv) {
         run<1>("LDS b32 x8 -> 7 MFMA (compiler order)", out, w);
         run<2>("LDS b32 x8 prefetched one step ahead", out, w);
         run<3>("LDS b128 x3 / 8 MFMA prefetched (fwd style)", out, w);
+        run<4>("  + cold first group per tap", out, w);
+        run<7>("  + cold first group, moving address", out, w);
+        run<5>("  + cold first group + barrier per tap", out, w);
+        run<6>("  + cold group + W ds_write + barrier per tap", out, w);
+        run<8>("A from LDS, W global->VGPR prefetched, no barrier", out, w);
     }
     return 0;
 }

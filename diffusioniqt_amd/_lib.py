@@ -26,6 +26,8 @@ PROTOTYPES = {
     "diqt_conv_packed_elems": (Z, [I, I, I, I, I]),
     "diqt_conv_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),
     "diqt_conv3d_fwd": (I, [P, P, P, P, P] + [I] * 15 + [P]),
+    "diqt_conv3d_fwd_workspace_bytes": (Z, [I] * 15),
+    "diqt_conv3d_fwd_ws": (I, [P, P, P, P, P, P, Z] + [I] * 15 + [P]),
     "diqt_conv3d_lds_bytes": (L, [I] * 12),
     "diqt_trilinear_up_fwd": (I, [P, P, I, I, I, I, I, I, P]),
     "diqt_trilinear_up_bwd": (I, [P, P, I, I, I, I, I, I, P]),

@@ -41,6 +41,8 @@ struct ConvGeom {
     int tilesD, tilesH, tilesW;
     int nNt, nChunks, CoutPad;
     int HD, HH, HWd;            // halo extents
+    int chunksPerSplit;         // forward split-K over input-channel chunks (grid.y slices; == nChunks when unsplit)
+    unsigned long long slabStride;   // floats between the split-K output slabs
     unsigned long long* dbg;    // diagnostic cycle stamps (NULL in production)
 };
 
@@ -140,7 +142,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
 
     const int wrow = tid >> 3, wc4 = (tid & 7) * 4;      // weight staging: rows wrow, wrow+32
 
-    for (int chunk = 0; chunk < g.nChunks; ++chunk) {
+    // split-K (small spatial extents): grid.y slices the input-channel chunks; each slice writes its own output slab
+    const int chunkBeg = blockIdx.y * g.chunksPerSplit, chunkEnd = min(g.nChunks, chunkBeg + g.chunksPerSplit);
+    y += (size_t)blockIdx.y * g.slabStride;
+    for (int chunk = chunkBeg; chunk < chunkEnd; ++chunk) {
         const int ci0 = chunk * CK;
         __syncthreads();   // all reads of the previous chunk's halo and of both weight buffers are done
         // ---- stage halo chunk: loads are UNCONDITIONAL (clamped address, zero-selected afterwards) and issued in batches
@@ -1012,6 +1017,7 @@ static int make_geom(ConvGeom& g, int B, int D, int H, int W, int Cin, int Cout,
     choose_tile(g.Do, g.Ho, g.Wo, kd, kh, kw, g.TD, g.TH, g.TW);
     g.tilesD = cdiv(g.Do, g.TD); g.tilesH = cdiv(g.Ho, g.TH); g.tilesW = cdiv(g.Wo, g.TW);
     g.nNt = cdiv(Cout, NT); g.CoutPad = g.nNt * NT; g.nChunks = cdiv(Cin, CK);
+    g.chunksPerSplit = g.nChunks; g.slabStride = 0;
     g.HD = g.TD + kd - 1; g.HH = g.TH + kh - 1; g.HWd = g.TW + kw - 1;
     const long long nwg = (long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
     DIQT_REQUIRE(nwg < (1ll << 31), DIQT_E_SHAPE, "conv3d: grid too large");
@@ -1061,13 +1067,68 @@ extern "C" int diqt_conv_pack_weight(const float* w, float* packed, int Cout, in
     return check_launch("conv_pack_weight");
 }
 
+// forward split-K plan: launches with fewer than ~1.5 resident rounds' worth of workgroups slice the Cin chunks
+static int fwd_ksplit(const ConvGeom& g) {
+    static const bool off = [] { const char* e = getenv("DIQT_CONV_NOSPLIT"); return e && e[0] == '1'; }();
+    const long long nwg = (long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
+    if (off || nwg >= 384 || g.nChunks < 2) return 1;
+    int ks = (int)(512 / nwg);
+    if (ks > g.nChunks) ks = g.nChunks;
+    if (ks > 16) ks = 16;
+    if (ks < 1) ks = 1;
+    const int per = cdiv(g.nChunks, ks);
+    return cdiv(g.nChunks, per);
+}
+
+// y[i] = sum_s slab[s][i] + bias[i % Cout] + residual[i]
+__global__ __launch_bounds__(256) void conv_fwd_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
+                                                              const float* __restrict__ residual, float* __restrict__ y,
+                                                              size_t n, int Cout, int ks) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = slabs[i];
+        for (int k = 1; k < ks; ++k) s += slabs[(size_t)k * n + i];
+        if (bias) s += bias[i % Cout];
+        if (residual) s += residual[i];
+        y[i] = s;
+    }
+}
+
+extern "C" size_t diqt_conv3d_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                                                  int pd, int ph, int pw, int epd, int eph, int epw) {
+    ConvGeom g;
+    if (make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return 0;
+    const int ks = fwd_ksplit(g);
+    return ks > 1 ? (size_t)ks * g.B * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float) : 0;
+}
+
+static int conv3d_fwd_impl(const float* x, const float* packed, const float* bias, const float* residual,
+                           float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                           int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
+
 extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
                                float* y, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
+    return conv3d_fwd_impl(x, packed, bias, residual, y, nullptr, 0, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph,
+                           epw, stream);
+}
+
+extern "C" int diqt_conv3d_fwd_ws(const float* x, const float* packed, const float* bias, const float* residual,
+                                  float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin,
+                                  int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw,
+                                  void* stream) {
+    return conv3d_fwd_impl(x, packed, bias, residual, y, workspace, workspace_bytes, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph,
+                           pw, epd, eph, epw, stream);
+}
+
+static int conv3d_fwd_impl(const float* x, const float* packed, const float* bias, const float* residual,
+                           float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                           int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
     DIQT_REQUIRE(x && packed && y, DIQT_E_ALIGN, "conv3d_fwd: null pointer");
     ConvGeom g;
     int rc = make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
     if (rc) return rc;
+    g.chunksPerSplit = g.nChunks;
+    g.slabStride = 0;
     DIQT_REQUIRE(aligned16(packed), DIQT_E_ALIGN, "conv3d_fwd: packed weights must be 16-byte aligned");
     const bool vec4 = (Cin % 4 == 0) && aligned16(x);
     const int HV = g.HD * g.HH * g.HWd;
@@ -1116,6 +1177,21 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    const int ks = workspace ? fwd_ksplit(g) : 1;
+    if (ks > 1) {
+        const size_t n = (size_t)g.B * g.Do * g.Ho * g.Wo * g.Cout;
+        DIQT_REQUIRE(workspace_bytes >= (size_t)ks * n * sizeof(float) && aligned16(workspace), DIQT_E_WORKSPACE,
+                     "conv3d_fwd: split-K workspace %zu < %zu", workspace_bytes, (size_t)ks * n * sizeof(float));
+        g.chunksPerSplit = cdiv(g.nChunks, ks);
+        g.slabStride = n;
+        float* slabs = static_cast<float*>(workspace);
+        hipLaunchKernelGGL(kern, dim3(nwg, ks), dim3(256), lds, (hipStream_t)stream, x, packed, nullptr, nullptr, slabs, g);
+        rc = check_launch("conv3d_fwd(split-K)");
+        if (rc) return rc;
+        hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, slabs, bias,
+                           residual, y, n, g.Cout, ks);
+        return check_launch("conv3d_fwd(split-K reduce)");
     }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
     return check_launch("conv3d_fwd");

@@ -969,6 +969,7 @@ __global__ void learned_sinu_bwd_kernel(const float* __restrict__ t, const float
 // of pipeline fill on these; here one wave owns one output column and streams its weight row once.
 // ---------------------------------------------------------------------------------------------
 constexpr int LS_MB = 8;      // rows per register block
+template <bool VEC>
 __global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                int M, int K, int N) {
@@ -979,11 +980,22 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __re
         float acc[LS_MB];
 #pragma unroll
         for (int j = 0; j < LS_MB; ++j) acc[j] = 0.f;
-        for (int k = lane; k < K; k += 64) {
-            const float wv = w[k];
+        if (VEC) {                  // K % 4 == 0, 16-byte aligned: K = 256 is one 16-byte load per lane and row
+            for (int k4 = lane; k4 < (K >> 2); k4 += 64) {
+                const float4 wv = reinterpret_cast<const float4*>(w)[k4];
+                float4 xv[LS_MB];
 #pragma unroll
-            for (int j = 0; j < LS_MB; ++j)
-                if (m0 + j < M) acc[j] += x[(size_t)(m0 + j) * K + k] * wv;
+                for (int j = 0; j < LS_MB; ++j)
+                    xv[j] = reinterpret_cast<const float4*>(x + (size_t)min(m0 + j, M - 1) * K)[k4];
+#pragma unroll
+                for (int j = 0; j < LS_MB; ++j) acc[j] += xv[j].x * wv.x + xv[j].y * wv.y + xv[j].z * wv.z + xv[j].w * wv.w;
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) {
+                const float wv = w[k];
+#pragma unroll
+                for (int j = 0; j < LS_MB; ++j) acc[j] += x[(size_t)min(m0 + j, M - 1) * K + k] * wv;
+            }
         }
 #pragma unroll
         for (int j = 0; j < LS_MB; ++j) {
@@ -1489,7 +1501,10 @@ extern "C" int diqt_linear_small_fwd(const float* x, const float* W, const float
                                      void* stream) {
     DIQT_REQUIRE(x && W && y, DIQT_E_ALIGN, "linear_small_fwd: null pointer");
     DIQT_REQUIRE(M > 0 && M <= 64 && K > 0 && N > 0, DIQT_E_SHAPE, "linear_small_fwd: needs 0 < M <= 64 (got %d)", M);
-    hipLaunchKernelGGL(linear_small_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, STREAM, x, W, bias, y, M, K, N);
+    if (K % 4 == 0 && aligned16(x) && aligned16(W))
+        hipLaunchKernelGGL(linear_small_fwd_kernel<true>, dim3((N + 3) / 4), dim3(256), 0, STREAM, x, W, bias, y, M, K, N);
+    else
+        hipLaunchKernelGGL(linear_small_fwd_kernel<false>, dim3((N + 3) / 4), dim3(256), 0, STREAM, x, W, bias, y, M, K, N);
     return check_launch("linear_small_fwd");
 }
 

@@ -120,8 +120,10 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0)):
     if TIMER.enabled:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-    _lib.call("diqt_conv3d_fwd", x5, packed, bias, residual, y, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw,
-              _stream())
+    n = _lib.query("diqt_conv3d_fwd_workspace_bytes", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
+    ws = _workspace(n, x5.device) if n else None
+    _lib.call("diqt_conv3d_fwd_ws", x5, packed, bias, residual, y, ws, n, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw,
+              epd, eph, epw, _stream())
     if TIMER.enabled:
         e.record()
         TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_kernel",

@@ -72,6 +72,15 @@ int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, cons
                     float* y, int B, int D, int H, int W, int Cin, int Cout,
                     int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
 
+/* Same operator with a caller-owned workspace: launches too small to fill the chip (8^3 / 16^3 levels) slice the
+ * input-channel chunks over grid.y into output slabs and a second kernel sums them (+ bias + residual) in a fixed
+ * order.  diqt_conv3d_fwd_workspace_bytes() returns 0 when the shape is not split.                              */
+size_t diqt_conv3d_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                                       int pd, int ph, int pw, int epd, int eph, int epw);
+int diqt_conv3d_fwd_ws(const float* x, const float* packed, const float* bias, const float* residual,
+                       float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                       int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
+
 /* LDS bytes the MFMA kernel needs for this geometry (> 160 KiB: use diqt_conv3d_direct_*); < 0 on bad shape */
 long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, int kw, int pd, int ph, int pw,
                                 int epd, int eph, int epw);

@@ -164,6 +164,62 @@ template <int VAR> void run(const char* name, float* out, int wgs) {
         if (rep == 5) printf("%-44s %d WG/CU: %.3f ms  %.1f TFLOP/s\n", name, wgs / 256, ms, wgs * 4 * nm * 4096.0 / ms / 1e9);
     }
 }
+// 8-wave workgroup (1 per CU): per stage = 3 taps x 32 MFMA per wave, then 4 ds_write_b128 of the next weight stage + barrier
+__global__ __launch_bounds__(512, 1) void k9(float* out, int iters, int tapsPerStage) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < 32768; i += 512) {
+        unsigned u = (unsigned)i * 2654435761u + blockIdx.x * 40503u; u ^= u >> 15; u *= 2246822519u; u ^= u >> 13;
+        lds[i] = ((int)(u & 0xFFFFFF) - 0x800000) * (1.0f / 0x800000);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    f32x16 acc[2];
+    for (int t = 0; t < 2; ++t) for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    const float* ap = lds + wave * 1152 + l31 * 36 + 4 * h;
+    const float* bp = lds + 16384 + l31 * 36 + 4 * h;
+    float4 wv = make_float4(1e-3f * lane, 0.f, 1.f, 2.f);
+    const int stages = iters * 14 / tapsPerStage;
+    for (int st = 0; st < stages; ++st) {
+        for (int tp = 0; tp < tapsPerStage; ++tp) {
+            const float* at = ap + ((st * tapsPerStage + tp) % 27) * 36;
+            const float* bt = bp + tp * 2304;
+            float4 a = *(const float4*)at, b0 = *(const float4*)bt, b1 = *(const float4*)(bt + 32 * 36);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 an, b0n, b1n;
+                if (q < 3) { an = *(const float4*)(at + 8 * (q + 1)); b0n = *(const float4*)(bt + 8 * (q + 1)); b1n = *(const float4*)(bt + 32 * 36 + 8 * (q + 1)); }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+                if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
+            }
+        }
+        // next stage's weights: tapsPerStage * 8 KB / 512 threads = tapsPerStage b128 writes per thread (other buffer)
+        for (int r = 0; r < tapsPerStage; ++r) *(float4*)(lds + 24576 + ((st & 1) * 3 + r) * 2048 % 8192 + threadIdx.x * 4) = wv;
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int t = 0; t < 2; ++t) for (int j = 0; j < 16; ++j) s += acc[t][j];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+void run9(float* out, int tps) {
+    hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+    const int iters = 600;
+    hipFuncSetAttribute((const void*)k9, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(s);
+        hipLaunchKernelGGL(k9, dim3(256), dim3(512), 140 * 1024, 0, out, iters, tps);
+        hipEventRecord(e); hipEventSynchronize(e);
+        float ms; hipEventElapsedTime(&ms, s, e);
+        const double nm = (double)(iters * 14 / tps) * tps * 32;
+        if (rep == 5) printf("8-wave WG, barrier + W write every %d taps        1 WG/CU: %.3f ms  %.1f TFLOP/s\n", tps, ms, 256 * 8 * nm * 4096.0 / ms / 1e9);
+    }
+}
 int main(int argc, char** argv) {
     float* out; hipMalloc(&out, (4096 * 256 + (1 << 20)) * 4 + (1 << 21)); hipMemset(out, 0, (4096 * 256 + (1 << 20)) * 4 + (1 << 21));
     int rnd = argc > 1 ? atoi(argv[1]) : 0;
@@ -180,5 +236,6 @@ int main(int argc, char** argv) {
         run<6>("  + cold group + W ds_write + barrier per tap", out, w);
         run<8>("A from LDS, W global->VGPR prefetched, no barrier", out, w);
     }
+    run9(out, 1); run9(out, 3); run9(out, 9);
     return 0;
 }

@@ -41,6 +41,8 @@ struct ConvGeom {
     int tilesD, tilesH, tilesW;
     int nNt, nChunks, CoutPad;
     int HD, HH, HWd;            // halo extents
+    unsigned xBytes, yBytes;    // tensor extents for the buffer descriptors (BUF kernels; 0 when >= 1 GiB)
+    int stagger;                // experiment: first-round workgroups sleep (slot % stagger) x ~6.4k cycles before starting
     int chunksPerSplit;         // forward split-K over input-channel chunks (grid.y slices; == nChunks when unsplit)
     unsigned long long slabStride;   // floats between the split-K output slabs
     unsigned long long* dbg;    // diagnostic cycle stamps (NULL in production)
@@ -78,7 +80,16 @@ __global__ void conv_pack_weight_kernel(const float* __restrict__ w, float* __re
 // ---------------------------------------------------------------------------------------------
 // forward / backward-data
 // ---------------------------------------------------------------------------------------------
-template <bool VEC4>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// buffer offsets past every descriptor's range (tensors are < 1 GiB on this path): loads return 0, stores are dropped.
+// voxel/row offsets use BUF_OOB, channel offsets BUF_OOB_C, so that any sum of the two stays out of range without wrapping
+constexpr unsigned BUF_OOB = 0x80000000u, BUF_OOB_C = 0x40000000u;
+
+// BUF = true (VEC4 and tensors < 1 GiB): halo staging and the epilogue go through buffer descriptors -- the per-tile
+// tables hold byte offsets (or BUF_OOB for padding voxels / rows outside the output), the hardware range check supplies
+// the zeros and drops the masked stores, and a piece costs ~6 instructions instead of ~25.  These phases share a SIMD
+// with the co-resident workgroup's MFMA stream, which stretches every non-MFMA instruction ~3x (profiles/r01_conv_ablation.md).
+template <bool VEC4, bool BUF>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ wp,
                                                           const float* __restrict__ bias,
@@ -96,6 +107,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     const int l31 = lane & 31, h = lane >> 5;
 
     const unsigned nwg = gridDim.x;
+    if (g.stagger > 1 && blockIdx.x < 512) {
+        const int nsl = __builtin_amdgcn_readfirstlane((int)((blockIdx.x / 8) % g.stagger));
+        for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(100);
+    }
     const unsigned L = xcd_remap(blockIdx.x, nwg);
     const int nt = L % g.nNt;
     int mt = L / g.nNt;
@@ -110,8 +125,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     if (tid < MTILE) {
         const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
         const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
-        int off = -1;
-        if (od < g.Do && oh < g.Ho && ow < g.Wo) off = ((b * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+        int off = BUF ? (int)BUF_OOB : -1;
+        if (od < g.Do && oh < g.Ho && ow < g.Wo) {
+            off = ((b * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+            if (BUF) off *= g.Cout * 4;          // byte offset of the output row
+        }
         out_off[tid] = off;
     }
 
@@ -119,10 +137,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     for (int hv = tid; hv < HV; hv += 256) {
         const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
         const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
-        int src = -1;
-        if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) src = ((b * g.D + iz) * g.H + iy) * g.W + ix;
+        int src = BUF ? (int)BUF_OOB : -1;
+        if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+            src = ((b * g.D + iz) * g.H + iy) * g.W + ix;
+            if (BUF) src *= g.Cin * 4;           // byte offset of the input voxel's channel row
+        }
         halo_src[hv] = src;
     }
+    // buffer descriptors (wave-uniform inputs only); the slab base of a split-K launch is folded into the y descriptor below
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, BUF ? (int)g.xBytes : 0, 0x00020000);
 
     // this lane's voxel (row of the A operand) -> halo index at tap (0,0,0)
     int hidx_lane;
@@ -148,8 +171,29 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     for (int chunk = chunkBeg; chunk < chunkEnd; ++chunk) {
         const int ci0 = chunk * CK;
         __syncthreads();   // all reads of the previous chunk's halo and of both weight buffers are done
+                if (chunk == 1) DIQT_STAMP();
         // ---- stage halo chunk: loads are UNCONDITIONAL (clamped address, zero-selected afterwards) and issued in batches
         //      of 8 before any LDS store, so a batch costs one memory round trip instead of eight serialized ones ----
+        if (BUF) {
+            const unsigned coff = (ci0 + wc4 < g.Cin) ? (unsigned)(ci0 + wc4) * 4u : BUF_OOB_C;   // this thread's channel quad
+            for (int base = 0; base < HV * 8; base += 256 * 8) {
+                u32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    // unconditional table read (clamped index) + select: a guarded read becomes an exec-masked branch
+                    // with its own ds_read -> s_waitcnt round trip per piece
+                    const unsigned t = (unsigned)halo_src[min(idx >> 3, HV - 1)] + coff;
+                    const unsigned voff = (idx < HV * 8) ? t : BUF_OOB;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    if (idx < HV * 8) *reinterpret_cast<u32x4*>(halo + (idx >> 3) * LDSROW + wc4) = v[u];
+                }
+            }
+        } else
         for (int base = 0; base < HV * 8; base += 256 * 8) {
             float4 v[8];
             bool ok[8];
@@ -178,13 +222,22 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
                         ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        // ---- weights of tap 0 ----
+        if (chunk == 1) DIQT_STAMP();
+        // ---- weights: panel of tap 0 -> LDS now; panel t+1 is written at the START of tap t (its buffer was last read in
+        //      tap t-1, retired by the barrier) from registers loaded during tap t-1, so neither the global latency nor the
+        //      LDS write sits between the last MFMA of a tap and its barrier ----
         const float* wchunk = wp + ((size_t)chunk * T * g.CoutPad + n0) * CK;
+        float4 r0, r1;
         {
-            const float4 r0 = *reinterpret_cast<const float4*>(wchunk + (size_t)wrow * CK + wc4);
-            const float4 r1 = *reinterpret_cast<const float4*>(wchunk + (size_t)(wrow + 32) * CK + wc4);
-            *reinterpret_cast<float4*>(wbuf + wrow * LDSROW + wc4) = r0;
-            *reinterpret_cast<float4*>(wbuf + (wrow + 32) * LDSROW + wc4) = r1;
+            const float4 p0 = *reinterpret_cast<const float4*>(wchunk + (size_t)wrow * CK + wc4);
+            const float4 p1 = *reinterpret_cast<const float4*>(wchunk + (size_t)(wrow + 32) * CK + wc4);
+            *reinterpret_cast<float4*>(wbuf + wrow * LDSROW + wc4) = p0;
+            *reinterpret_cast<float4*>(wbuf + (wrow + 32) * LDSROW + wc4) = p1;
+            if (T > 1) {
+                const float* wt = wchunk + (size_t)g.CoutPad * CK;
+                r0 = *reinterpret_cast<const float4*>(wt + (size_t)wrow * CK + wc4);
+                r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
+            }
         }
         __syncthreads();
         DIQT_STAMP();
@@ -193,11 +246,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
         for (int kz = 0; kz < g.kd; ++kz)
             for (int ky = 0; ky < g.kh; ++ky)
                 for (int kx = 0; kx < g.kw; ++kx, ++tap) {
-                    // prefetch next tap's weight panel into registers
-                    float4 r0, r1;
-                    const bool more = (tap + 1 < T);
-                    if (more) {
-                        const float* wt = wchunk + (size_t)(tap + 1) * g.CoutPad * CK;
+                    if (tap + 1 < T) {
+                        float* wnext = wbuf + ((tap + 1) & 1) * (NT * LDSROW);
+                        *reinterpret_cast<float4*>(wnext + wrow * LDSROW + wc4) = r0;
+                        *reinterpret_cast<float4*>(wnext + (wrow + 32) * LDSROW + wc4) = r1;
+                    }
+                    if (tap + 2 < T) {
+                        const float* wt = wchunk + (size_t)(tap + 2) * g.CoutPad * CK;
                         r0 = *reinterpret_cast<const float4*>(wt + (size_t)wrow * CK + wc4);
                         r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
                     }
@@ -227,11 +282,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
                         if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
                     }
-                    if (more) {
-                        float* wnext = wbuf + ((tap + 1) & 1) * (NT * LDSROW);
-                        *reinterpret_cast<float4*>(wnext + wrow * LDSROW + wc4) = r0;
-                        *reinterpret_cast<float4*>(wnext + (wrow + 32) * LDSROW + wc4) = r1;
-                    }
                     __syncthreads();
                 }
         DIQT_STAMP();
@@ -241,6 +291,22 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     const int co0 = n0 + l31, co1 = n0 + 32 + l31;
     const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
     const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+    if (BUF) {
+        const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+        const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
+        const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned off = (unsigned)out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+            float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+            if (residual) {        // wave-uniform
+                v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+                v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+        }
+    } else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1017,7 +1083,8 @@ static int make_geom(ConvGeom& g, int B, int D, int H, int W, int Cin, int Cout,
     choose_tile(g.Do, g.Ho, g.Wo, kd, kh, kw, g.TD, g.TH, g.TW);
     g.tilesD = cdiv(g.Do, g.TD); g.tilesH = cdiv(g.Ho, g.TH); g.tilesW = cdiv(g.Wo, g.TW);
     g.nNt = cdiv(Cout, NT); g.CoutPad = g.nNt * NT; g.nChunks = cdiv(Cin, CK);
-    g.chunksPerSplit = g.nChunks; g.slabStride = 0;
+    g.chunksPerSplit = g.nChunks; g.slabStride = 0; g.xBytes = 0; g.yBytes = 0;
+    { static const int stg = [] { const char* e = getenv("DIQT_CONV_STAGGER"); return e ? atoi(e) : 0; }(); g.stagger = stg; }
     g.HD = g.TD + kd - 1; g.HH = g.TH + kh - 1; g.HWd = g.TW + kw - 1;
     const long long nwg = (long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
     DIQT_REQUIRE(nwg < (1ll << 31), DIQT_E_SHAPE, "conv3d: grid too large");
@@ -1163,9 +1230,15 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
             return check_launch("conv3d_fwd(persistent)");
         }
     }
-    const size_t lds = ((size_t)HV * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int);
+    static const size_t ldspad = [] { const char* e = getenv("DIQT_CONV_LDSPAD"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();   // occupancy experiment
+    const size_t lds = ((size_t)HV * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int) + ldspad;
     DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_fwd: halo tile needs %zu B of LDS", lds);
-    auto kern = vec4 ? conv_fwd_kernel<true> : conv_fwd_kernel<false>;
+    const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
+    const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
+    static const bool nobuf = [] { const char* e = getenv("DIQT_CONV_NOBUF"); return e && e[0] == '1'; }();
+    const bool buf = vec4 && !nobuf && xb < (1ull << 30) && yb < (1ull << 30);
+    if (buf) { g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; }
+    auto kern = vec4 ? (buf ? conv_fwd_kernel<true, true> : conv_fwd_kernel<true, false>) : conv_fwd_kernel<false, false>;
     static unsigned long long* dbg_buf = nullptr;
     static const bool dbg_on = [] { const char* e = getenv("DIQT_CONV_DBG"); return e && e[0] == '1'; }();
     if (dbg_on) {     // diagnostic build path only: cycle stamps per workgroup, read back with diqt_debug_conv_stamps()

@@ -79,12 +79,12 @@ if os.environ.get("DIQT_CONV_DBG") == "1":
             print(f"  {nm:22s} median {np.median(st[:, i]):10.0f} cycles = {100 * np.median(st[:, i] / tot):5.1f} % of workgroup life")
         print(f"  workgroup life median {np.median(tot):.0f} cycles, {n} persistent workgroups")
         sys.exit(0)
-    d = np.diff(st[:, :6], axis=1)
-    names = ["tables+stage chunk0", "taps chunk0", "stage chunk1", "taps chunk1", "epilogue"]
+    d = np.diff(st[:, :8], axis=1)
+    names = ["tables+stage chunk0", "taps chunk0", "chunk1: entry barrier", "chunk1: halo load+store", "chunk1: W0 + barrier", "taps chunk1", "epilogue"]
     print(f"stamps from {n} workgroups (cycles of the constant-rate counter, median / p90):")
     for i, nm in enumerate(names):
         print(f"  {nm:22s} {np.median(d[:, i]):10.0f} {np.percentile(d[:, i], 90):10.0f}")
-    tot = st[:, 5] - st[:, 0]
+    tot = st[:, 7] - st[:, 0]
     print(f"  {'workgroup lifetime':22s} {np.median(tot):10.0f} {np.percentile(tot, 90):10.0f}")
-    span = st[:, 5].max() - st[:, 0].min()
+    span = st[:, 7].max() - st[:, 0].min()
     print(f"  kernel span {span} ticks; sum of lifetimes / (512 slots) = {tot.sum() / 512:.0f}")

@@ -42,6 +42,7 @@ struct ConvGeom {
     int nNt, nChunks, CoutPad;
     int HD, HH, HWd;            // halo extents
     unsigned xBytes, yBytes;    // tensor extents for the buffer descriptors (BUF kernels; 0 when >= 1 GiB)
+    int tilesPerWg;             // forward kernel: consecutive tiles per workgroup
     int stagger;                // experiment: first-round workgroups sleep (slot % stagger) x ~6.4k cycles before starting
     int chunksPerSplit;         // forward split-K over input-channel chunks (grid.y slices; == nChunks when unsplit)
     unsigned long long slabStride;   // floats between the split-K output slabs
@@ -111,7 +112,17 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
         const int nsl = __builtin_amdgcn_readfirstlane((int)((blockIdx.x / 8) % g.stagger));
         for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(100);
     }
-    const unsigned L = xcd_remap(blockIdx.x, nwg);
+    // a workgroup walks g.tilesPerWg consecutive tiles (1 by default; DIQT_CONV_TPW for the turn-over experiment)
+    const unsigned totalTiles = (unsigned)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
+    unsigned long long stamps[8];
+    int nst = 0;
+#define DIQT_STAMP() do { if (g.dbg && nst < 8) stamps[nst++] = __builtin_readcyclecounter(); } while (0)
+    const unsigned long long rt0 = g.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    y += (size_t)blockIdx.y * g.slabStride;   // split-K slab (0 when unsplit)
+    for (int rep = 0; rep < g.tilesPerWg; ++rep) {
+    const unsigned L = xcd_remap(blockIdx.x, nwg) * g.tilesPerWg + rep;
+    if (L >= totalTiles) break;
+    if (rep) __syncthreads();       // the previous tile's epilogue is done with out_off
     const int nt = L % g.nNt;
     int mt = L / g.nNt;
     const int tx = mt % g.tilesW; mt /= g.tilesW;
@@ -158,16 +169,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    unsigned long long stamps[8];
-    int nst = 0;
-#define DIQT_STAMP() do { if (g.dbg && nst < 8) stamps[nst++] = __builtin_readcyclecounter(); } while (0)
     DIQT_STAMP();
 
     const int wrow = tid >> 3, wc4 = (tid & 7) * 4;      // weight staging: rows wrow, wrow+32
 
     // split-K (small spatial extents): grid.y slices the input-channel chunks; each slice writes its own output slab
     const int chunkBeg = blockIdx.y * g.chunksPerSplit, chunkEnd = min(g.nChunks, chunkBeg + g.chunksPerSplit);
-    y += (size_t)blockIdx.y * g.slabStride;
     for (int chunk = chunkBeg; chunk < chunkEnd; ++chunk) {
         const int ci0 = chunk * CK;
         __syncthreads();   // all reads of the previous chunk's halo and of both weight buffers are done
@@ -325,8 +332,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
         }
     }
     DIQT_STAMP();
-    if (g.dbg && tid == 0)
+    }   // tiles of this workgroup
+    if (g.dbg && tid == 0) {
         for (int q = 0; q < 8; ++q) g.dbg[(size_t)blockIdx.x * 8 + q] = q < nst ? stamps[q] : 0ull;
+        if (g.stagger == -1) {      // clock probe: slots 1 and 6 carry the constant-rate (100 MHz) counter at start / end
+            g.dbg[(size_t)blockIdx.x * 8 + 1] = rt0;
+            g.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+            g.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_readcyclecounter();
+        }
+    }
 #undef DIQT_STAMP
 }
 
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
 // current item's 27 x 32 MFMAs run and is written to LDS at the item boundary (async-stage split), so HBM
 // latency, workgroup launch and index math are off the MFMA critical path.  Same math, same LDS images.
 // ---------------------------------------------------------------------------------------------
-template <bool VEC4, int NR, int KD, int KH, int KW>
+template <bool VEC4, bool BUF, int NR, int KD, int KH, int KW>
 __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ wp,
                                                                   const float* __restrict__ bias,
@@ -377,22 +391,43 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
         for (int hv = tid; hv < HV; hv += 256) {
             const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
             const int iz = p.d0 + hz - g.pd, iy = p.h0 + hy - g.ph, ix = p.w0 + hx - g.pw;
-            int src = -1;
-            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+            int src = BUF ? (int)BUF_OOB : -1;
+            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
                 src = ((p.b * g.D + iz) * g.H + iy) * g.W + ix;
+                if (BUF) src *= g.Cin * 4;
+            }
             halo_src[slot * HV + hv] = src;
         }
         if (tid < MTILE) {
             const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
             const int od = p.d0 + td, oh = p.h0 + th, ow = p.w0 + tw;
-            out_off[slot * MTILE + tid] = (od < g.Do && oh < g.Ho && ow < g.Wo)
-                                              ? ((p.b * g.Do + od) * g.Ho + oh) * g.Wo + ow : -1;
+            int off = BUF ? (int)BUF_OOB : -1;
+            if (od < g.Do && oh < g.Ho && ow < g.Wo) {
+                off = ((p.b * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+                if (BUF) off *= g.Cout * 4;
+            }
+            out_off[slot * MTILE + tid] = off;
         }
     };
     float4 R[NR];
     unsigned okmask = 0;
     // one 16-byte piece of the next item's halo chunk (piece r of thread tid covers halo element tid + 256 r)
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, BUF ? (int)g.xBytes : 0, 0x00020000);
+    unsigned voffs[NR];       // BUF: byte offsets of the next item's halo pieces (table read hoisted out of the tap loop)
+    auto read_offsets = [&](int slot) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int idx = tid + 256 * r;
+            const unsigned t = (unsigned)halo_src[slot * HV + min(idx >> 3, HV - 1)];
+            voffs[r] = idx < HV * 8 ? t : BUF_OOB;
+        }
+    };
     auto load_piece = [&](int r, int slot, int ci0) -> float4 {
+        if (BUF) {
+            const int c4 = (tid & 7) * 4;
+            const unsigned coff = (ci0 + c4 < g.Cin) ? (unsigned)(ci0 + c4) * 4u : BUF_OOB_C;
+            return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voffs[r] + coff, 0, 0));
+        }
         const int idx = tid + 256 * r;
         const int hv = (idx < HV * 8) ? (idx >> 3) : 0, c4 = (idx & 7) * 4;
         const int src = halo_src[slot * HV + hv];
@@ -421,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
             const int idx = tid + 256 * r;
             if (idx < HV * 8)
                 *reinterpret_cast<float4*>(halo + (idx >> 3) * LDSROW + (idx & 7) * 4) =
-                    (okmask >> r) & 1u ? R[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    (BUF || ((okmask >> r) & 1u)) ? R[r] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -440,6 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
     TilePos pos = decode(tile);
     fill_tables(pos, 0);
     __syncthreads();
+    if (BUF) read_offsets(0);
     issue_loads(0, 0);
     // stagger: the second resident set of workgroups starts half a tap late, so the two waves sharing a SIMD do not
     // reach their barriers / LDS-read waits in lockstep (speed only)
@@ -449,6 +485,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
         for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(16);
     }
 
+    // static tile walk: a per-XCD atomic tile queue and alternating wave priorities were tried against the ~8 % MFMA-rate
+    // advantage of the older co-resident workgroup (profiles/r01_conv_ablation.md): 4 tiles per workgroup are too coarse to steal
     while (true) {
         const int nextTile = tile + G8;
         const bool haveNextTile = nextTile < tileEnd;
@@ -474,6 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
                 fill_tables(npos, slot ^ 1);
             }
             __syncthreads();
+            if (BUF && lastChunk && haveNextTile) read_offsets(slot ^ 1);
             DIQT_ACC(1);
             // the next item's halo chunk is prefetched into registers ONE PIECE PER TAP, each piece issued right after
             // that tap's weight-panel loads: vmcnt retires in order, so the end-of-tap wait for the weight panel then
@@ -540,6 +579,22 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* _
                 const int co0 = pos.n0 + l31, co1 = pos.n0 + 32 + l31;
                 const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
                 const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+                if (BUF) {
+                    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+                    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
+                    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned off = (unsigned)out_off[slot * MTILE + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+                        if (residual) {
+                            v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+                            v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+                    }
+                } else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1083,7 +1138,7 @@ static int make_geom(ConvGeom& g, int B, int D, int H, int W, int Cin, int Cout,
     choose_tile(g.Do, g.Ho, g.Wo, kd, kh, kw, g.TD, g.TH, g.TW);
     g.tilesD = cdiv(g.Do, g.TD); g.tilesH = cdiv(g.Ho, g.TH); g.tilesW = cdiv(g.Wo, g.TW);
     g.nNt = cdiv(Cout, NT); g.CoutPad = g.nNt * NT; g.nChunks = cdiv(Cin, CK);
-    g.chunksPerSplit = g.nChunks; g.slabStride = 0; g.xBytes = 0; g.yBytes = 0;
+    g.chunksPerSplit = g.nChunks; g.slabStride = 0; g.xBytes = 0; g.yBytes = 0; g.tilesPerWg = 1;
     { static const int stg = [] { const char* e = getenv("DIQT_CONV_STAGGER"); return e ? atoi(e) : 0; }(); g.stagger = stg; }
     g.HD = g.TD + kd - 1; g.HH = g.TH + kh - 1; g.HWd = g.TW + kw - 1;
     const long long nwg = (long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
@@ -1206,9 +1261,15 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
     if (persist_ok && HV * 8 <= 256 * 13 && (k333 || k133)) {
         const size_t plds = ((size_t)HV * (LDSROW + 2) + 2 * NT * LDSROW) * sizeof(float) + 2 * MTILE * sizeof(int);
         if (plds <= 160 * 1024) {
+            const unsigned long long pxb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
+            const unsigned long long pyb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
+            const bool pbuf = vec4 && pxb < (1ull << 30) && pyb < (1ull << 30);
+            if (pbuf) { g.xBytes = (unsigned)pxb; g.yBytes = (unsigned)pyb; }
             void (*pk)(const float*, const float*, const float*, const float*, float*, ConvGeom, int, int) =
-                k333 ? (vec4 ? conv_fwd_persist_kernel<true, 13, 3, 3, 3> : conv_fwd_persist_kernel<false, 13, 3, 3, 3>)
-                     : (vec4 ? conv_fwd_persist_kernel<true, 13, 1, 3, 3> : conv_fwd_persist_kernel<false, 13, 1, 3, 3>);
+                k333 ? (vec4 ? (pbuf ? conv_fwd_persist_kernel<true, true, 13, 3, 3, 3> : conv_fwd_persist_kernel<true, false, 13, 3, 3, 3>)
+                             : conv_fwd_persist_kernel<false, false, 13, 3, 3, 3>)
+                     : (vec4 ? (pbuf ? conv_fwd_persist_kernel<true, true, 13, 1, 3, 3> : conv_fwd_persist_kernel<true, false, 13, 1, 3, 3>)
+                             : conv_fwd_persist_kernel<false, false, 13, 1, 3, 3>);
             if (plds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
@@ -1252,6 +1313,11 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int ks = workspace ? fwd_ksplit(g) : 1;
+    static const int tpw_env = [] { const char* e = getenv("DIQT_CONV_TPW"); return e ? atoi(e) : 0; }();
+    int tpw = tpw_env > 0 ? tpw_env : 1;      // measured: 2 or 4 tiles per workgroup change nothing (457 / 464 / 459 us), see profiles/r01_conv_ablation.md
+    if (dbg_on) tpw = 1;
+    g.tilesPerWg = tpw;
+    const unsigned gridx = (nwg + tpw - 1) / tpw;
     if (ks > 1) {
         const size_t n = (size_t)g.B * g.Do * g.Ho * g.Wo * g.Cout;
         DIQT_REQUIRE(workspace_bytes >= (size_t)ks * n * sizeof(float) && aligned16(workspace), DIQT_E_WORKSPACE,
@@ -1259,14 +1325,14 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
         g.chunksPerSplit = cdiv(g.nChunks, ks);
         g.slabStride = n;
         float* slabs = static_cast<float*>(workspace);
-        hipLaunchKernelGGL(kern, dim3(nwg, ks), dim3(256), lds, (hipStream_t)stream, x, packed, nullptr, nullptr, slabs, g);
+        hipLaunchKernelGGL(kern, dim3(gridx, ks), dim3(256), lds, (hipStream_t)stream, x, packed, nullptr, nullptr, slabs, g);
         rc = check_launch("conv3d_fwd(split-K)");
         if (rc) return rc;
         hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, slabs, bias,
                            residual, y, n, g.Cout, ks);
         return check_launch("conv3d_fwd(split-K reduce)");
     }
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
+    hipLaunchKernelGGL(kern, dim3(gridx), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
     return check_launch("conv3d_fwd");
 }
 

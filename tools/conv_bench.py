@@ -77,7 +77,22 @@ if os.environ.get("DIQT_CONV_DBG") == "1":
         tot = st[:, :4].sum(axis=1)
         for i, nm in enumerate(["wait at item start", "store halo+W0+tables", "tap loops", "epilogues"]):
             print(f"  {nm:22s} median {np.median(st[:, i]):10.0f} cycles = {100 * np.median(st[:, i] / tot):5.1f} % of workgroup life")
-        print(f"  workgroup life median {np.median(tot):.0f} cycles, {n} persistent workgroups")
+        print(f"  workgroup life median {np.median(tot):.0f} cycles, {n} persistent workgroups; min {tot.min()} p10 {np.percentile(tot, 10):.0f} "
+              f"p90 {np.percentile(tot, 90):.0f} max {tot.max()}")
+        order = np.argsort(tot)
+        for nm, sel in (("fastest 10%", order[: n // 10]), ("middle", order[n // 2 - n // 20: n // 2 + n // 20]), ("slowest 10%", order[-(n // 10):])):
+            print(f"    {nm:12s}: life {np.median(tot[sel]):.0f}  wait {np.median(st[sel, 0]):.0f} store {np.median(st[sel, 1]):.0f} "
+                  f"taps {np.median(st[sel, 2]):.0f} epi {np.median(st[sel, 3]):.0f}   blockIdx/8 %4 histogram {np.bincount((sel // 8) % 4, minlength=4)}  blockIdx>=256: {np.mean(sel >= 256):.2f}")
+        for xcd in range(0):
+            m = np.arange(n) % 8 == xcd
+            print(f"    XCD {xcd}: life median {np.median(tot[m]):.0f}  max {tot[m].max()}   wait {np.median(st[m, 0]):.0f} store {np.median(st[m, 1]):.0f} taps {np.median(st[m, 2]):.0f} epi {np.median(st[m, 3]):.0f}")
+        sys.exit(0)
+    if os.environ.get("DIQT_CONV_STAGGER") == "-1":
+        cyc = (st[:, 7] - st[:, 0]).astype(np.float64)
+        rt = (st[:, 6] - st[:, 1]).astype(np.float64)          # 100 MHz ticks
+        f = cyc / rt * 100.0
+        print(f"effective shader clock inside the kernel (s_memtime / s_memrealtime): median {np.median(f):.0f} MHz, "
+              f"p10 {np.percentile(f, 10):.0f}, p90 {np.percentile(f, 90):.0f}; workgroup lifetime median {np.median(rt) / 100:.1f} us")
         sys.exit(0)
     d = np.diff(st[:, :8], axis=1)
     names = ["tables+stage chunk0", "taps chunk0", "chunk1: entry barrier", "chunk1: halo load+store", "chunk1: W0 + barrier", "taps chunk1", "epilogue"]
@@ -86,5 +101,11 @@ if os.environ.get("DIQT_CONV_DBG") == "1":
         print(f"  {nm:22s} {np.median(d[:, i]):10.0f} {np.percentile(d[:, i], 90):10.0f}")
     tot = st[:, 7] - st[:, 0]
     print(f"  {'workgroup lifetime':22s} {np.median(tot):10.0f} {np.percentile(tot, 90):10.0f}")
+    # only the LAST launch's stamps are in the buffer; the cycle counter is per-XCD, so compare within an XCD
+    for xcd in range(8):
+        m = np.arange(n) % 8 == xcd
+        t0, t1 = st[m, 0], st[m, 7]
+        print(f"  XCD {xcd}: lifetime median {np.median(t1 - t0):8.0f}  first start -> last end {t1.max() - t0.min():9.0f} cycles;"
+              f"  end-time spread of the last 64 finishers {np.sort(t1)[-1] - np.sort(t1)[-64]:8.0f}")
     span = st[:, 7].max() - st[:, 0].min()
     print(f"  kernel span {span} ticks; sum of lifetimes / (512 slots) = {tot.sum() / 512:.0f}")

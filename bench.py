@@ -42,6 +42,21 @@ def unet_kwargs(size):
                 pixel_shuffle_upsample=True, boundary=False, batch_sample=False, batch_sample_factor=3, deep_feature=False)
 
 
+def pmc_traffic(batch, size):
+    """HBM bytes per average conv_fwd launch of one C2 sampler step, from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE collected separately; FETCH_SIZE doubled for gfx950, MI355X_MICROARCH.md).  The counters
+    cannot be read from inside this process, so this is the profiled value of the same command, or None off-config."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+    if batch != 8 or size != 32 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]
+        return next(v["hbm_bytes_per_launch"] for name, v in k.items() if "conv_fwd_kernel<true, true>" in name)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,8 +160,9 @@ def main():
             ms, flops, n = summ["conv_fwd_kernel"]
             roof = dict(bound="mfma", kernel="conv_fwd_kernel", achieved=round(flops / (ms * 1e-3) / 1e12, 2),
                         peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=None, launches=n, avg_launch_ms=round(ms / n, 4),
-                        share_of_step=round(ms / (1e3 * dt), 3))
+                        traffic=pmc_traffic(B, S), launches=n, avg_launch_ms=round(ms / n, 4),
+                        share_of_step=round(ms / (1e3 * dt), 3),
+                        flops_per_launch=round(flops / n / 1e9, 3), flops_unit="GFLOP (algorithmic, 2*MAC) per average launch")
         assert torch.isfinite(state["img"]).all()
 
     # ---------------- training: K micro-steps through ImagenTrainer.forward ----------------

@@ -774,6 +774,26 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         if (zero_grad) g[i] = 0.f;
     }
 }
+// gradient accumulation into the flat arena: dst[off_t + i] += src_t[i] for every tensor t of a table
+// table[t] = {src pointer, dst offset (elements), n (elements)} as 3 x int64; grid = (blocks per tensor, tensors)
+__global__ __launch_bounds__(256) void multi_accumulate_kernel(float* __restrict__ dst, const long long* __restrict__ table) {
+    const long long* e = table + 3 * (size_t)blockIdx.y;
+    const float* __restrict__ src = reinterpret_cast<const float*>(e[0]);
+    float* __restrict__ d = dst + e[1];
+    const size_t n = (size_t)e[2];
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
+        const size_t n4 = n >> 2;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            float4 a = reinterpret_cast<float4*>(d)[i];
+            const float4 b = reinterpret_cast<const float4*>(src)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            reinterpret_cast<float4*>(d)[i] = a;
+        }
+        for (size_t i = (n4 << 2) + blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] += src[i];
+    } else {
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] += src[i];
+    }
+}
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, size_t n, float w) {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         e[i] += (p[i] - e[i]) * w;
@@ -1380,6 +1400,13 @@ extern "C" int diqt_adam_step(float* param, float* grad, float* exp_avg, float* 
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, STREAM, param, grad, exp_avg, exp_avg_sq, n,
                        lr, beta1, beta2, eps, weight_decay, bias_correction1, sqrtf(bias_correction2), zero_grad);
     return check_launch("adam_step");
+}
+extern "C" int diqt_multi_accumulate(float* dst, const long long* table, int count, int blocks_per_tensor, void* stream) {
+    DIQT_REQUIRE(dst && table, DIQT_E_ALIGN, "multi_accumulate: null pointer");
+    if (count <= 0) return DIQT_OK;
+    DIQT_REQUIRE(count <= 65535 && blocks_per_tensor > 0, DIQT_E_SHAPE, "multi_accumulate: count %d out of range", count);
+    hipLaunchKernelGGL(multi_accumulate_kernel, dim3(blocks_per_tensor, count), dim3(256), 0, STREAM, dst, table);
+    return check_launch("multi_accumulate");
 }
 extern "C" int diqt_ema_lerp(float* ema, const float* param, size_t n, float one_minus_decay, void* stream) {
     DIQT_REQUIRE(ema && param, DIQT_E_ALIGN, "ema_lerp: null pointer");

@@ -67,6 +67,7 @@ class FlatArena:
             self.offsets.append(off)
             off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
         self.numel = off
+        self._collected = set()
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev) if with_grad else None
         with torch.no_grad():
@@ -75,6 +76,42 @@ class FlatArena:
                 p.data = self.flat[o:o + p.numel()].view_as(p)
                 if with_grad and p.requires_grad:
                     p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    # ---- gradient accumulation without one add kernel per parameter -------------------------------------------------
+    # autograd's AccumulateGrad adds into a defined ``p.grad`` with one small kernel per parameter (~290 per micro-step
+    # for the C2 U-Net).  begin_backward() detaches the arena views so autograd just hands over each fresh gradient;
+    # collect() adds them into the arena with ONE multi-tensor launch and re-installs the views.
+    def begin_backward(self):
+        self._collected = set()
+        for p in self.params:
+            if p.requires_grad:
+                p.grad = None
+
+    def collect(self, indices=None):
+        idx = range(len(self.params)) if indices is None else indices
+        srcs, offs, done = [], [], []
+        for i in idx:
+            if i in self._collected:
+                continue
+            p = self.params[i]
+            if not p.requires_grad:
+                continue
+            g, o = p.grad, self.offsets[i]
+            view = self.grad[o:o + p.numel()].view_as(p)
+            if g is not None and g.data_ptr() != view.data_ptr():
+                srcs.append(g.detach().contiguous().view(-1))
+                offs.append(o)
+            p.grad = view
+            done.append(i)
+        self._collected.update(done)
+        if not srcs:
+            return
+        if self.grad.is_cuda:
+            from . import ops
+            ops.multi_accumulate(self.grad, srcs, offs)
+        else:                                   # host arenas (gloo tests): plain torch
+            for t, o in zip(srcs, offs):
+                self.grad[o:o + t.numel()].add_(t)
 
     def intact(self):
         """False if something (e.g. ``module.to()``) re-allocated a parameter and broke the views."""
@@ -135,7 +172,8 @@ class BucketedGradReducer:
         return hook
 
     def _launch(self, b):
-        lo, hi, _ = self.buckets[b]
+        lo, hi, idx = self.buckets[b]
+        self.arena.collect(idx)                 # this micro-step's gradients of the bucket join the accumulated ones
         buf = self.arena.grad[lo:hi]
         if buf.is_cuda:
             h = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)

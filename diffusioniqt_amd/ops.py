@@ -980,6 +980,19 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
     bump_weight_epoch()
 
 
+def multi_accumulate(dst_flat, srcs, offsets):
+    """dst_flat[off : off + t.numel()] += t for every (t, off): one launch for a whole micro-step's parameter gradients."""
+    _chk(dst_flat, *srcs)
+    if not srcs:
+        return
+    rows = []
+    for t, off in zip(srcs, offsets):
+        assert t.is_contiguous() and t.dtype == torch.float32
+        rows.append((t.data_ptr(), int(off), t.numel()))
+    table = torch.tensor(rows, dtype=torch.int64).to(dst_flat.device, non_blocking=True)
+    _lib.call("diqt_multi_accumulate", dst_flat, table, len(rows), 16, _stream())   # same stream as the producers/allocator
+
+
 def ema_lerp(ema, param, one_minus_decay):
     _chk(ema, param)
     _lib.call("diqt_ema_lerp", ema, param, ema.numel(), float(one_minus_decay), _stream())

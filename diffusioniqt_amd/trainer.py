@@ -751,9 +751,14 @@ class ImagenTrainer(nn.Module):
                 # like accelerate.accumulate: the loss is divided by the accumulation steps, DDP syncs on the boundary
                 if exists(reducer):
                     reducer.prepare_backward(sync=sync)
+                arena = getattr(self, '_arena', None)
+                if arena is not None:
+                    arena.begin_backward()
                 (loss / self.gradient_accumulation_steps).backward()
                 if exists(reducer):
                     reducer.finalize_backward()
+                if arena is not None:
+                    arena.collect()             # whatever no bucket launch has collected yet (all of it on non-sync steps)
                 self._sync_now = sync
                 self.update(unet_number=unet_number)
             total_loss += loss.item()

@@ -252,6 +252,10 @@ int diqt_mse_clamp_bwd(const float* pred_clamped, const float* target, const flo
 int diqt_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_correction1, float bias_correction2, int zero_grad, void* stream);
+/* Gradient accumulation (accelerate's accumulate()/DDP no_sync, trainer.py:300,1118): the per-parameter gradients of one
+ * micro-step are added into the flat gradient arena in ONE launch.  table[t] = {src device pointer, dst element offset,
+ * element count} (3 x int64, device memory); every tensor gets `blocks_per_tensor` workgroups.                    */
+int diqt_multi_accumulate(float* dst, const long long* table, int count, int blocks_per_tensor, void* stream);
 int diqt_ema_lerp(float* ema, const float* param, size_t n, float one_minus_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

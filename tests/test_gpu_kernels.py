@@ -348,6 +348,24 @@ def test_diffusion_steps_loss_adam(ops):
     close(ed, e + (wr.detach() - e) * 0.25, tol=1e-5, what="ema")
 
 
+def test_multi_accumulate_matches_per_tensor_adds(ops):
+    """Gradient accumulation into the flat arena: one launch == the per-parameter `grad += new` adds (bit-exact)."""
+    g = torch.Generator().manual_seed(11)
+    sizes = [1, 3, 64, 1000, 27 * 64 * 64, 17, 4096 + 2]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    flat = torch.randn(off, generator=g)
+    srcs = [torch.randn(n, generator=g) for n in sizes]
+    ref = flat.clone()
+    for t, o in zip(srcs, offs):
+        ref[o:o + t.numel()] += t
+    dflat = flat.to(DEV)
+    ops.multi_accumulate(dflat, [t.to(DEV) for t in srcs], offs)
+    assert torch.equal(dflat.cpu(), ref)
+
+
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(RuntimeError):
         ops.mish(torch.randn(4))

@@ -75,6 +75,9 @@ PROTOTYPES = {
     "diqt_attn_softmax_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "diqt_bgemm": (I, [P, P, P, I, I, I, I, I, I, L, L, L, I, I, I, F, F, P]),
     "diqt_multi_accumulate": (I, [P, P, I, I, P]),
+    "diqt_abs_quantile": (I, [P, P, I, Z, ctypes.c_uint, F, P]),
+    "diqt_dynamic_threshold": (I, [P, P, P, I, Z, P]),
+    "diqt_mask_blend": (I, [P, P, P, P, Z, P]),
     "diqt_linear_small_workspace_bytes": (Z, [I, I, I]),
     "diqt_linear_small_fwd": (I, [P, P, P, P, I, I, I, P]),
     "diqt_linear_small_bwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, P]),

@@ -1072,6 +1072,81 @@ __global__ __launch_bounds__(256) void linear_small_dx_sum_kernel(const float* _
     for (int q = 0; q < slices; ++q) s += part[(size_t)q * MK + i];
     dx[i] = s;
 }
+
+// ---------------------------------------------------------------------------------------------
+// dynamic thresholding (imagen_pytorch3D.py:2006-2021): s[b] = torch.quantile(|x0[b]|, p) with linear interpolation
+// between the order statistics k and k+1 -- 4-pass MSB radix select on the bit patterns of |x| (monotone for
+// non-negative floats), one workgroup per batch row, then x0 = clamp(x0, -s, s) / s.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void abs_quantile_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                            size_t per, unsigned k_lo, int need_hi, float weight) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_prefix, sh_k, sh_below, sh_min;
+    const float* xr = x + (size_t)blockIdx.x * per;
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, k = k_lo, below = 0;      // below: elements strictly smaller than the selected prefix range
+    for (int pass = 3; pass >= 0; --pass) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const int shift = pass * 8;
+        const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (size_t i = tid; i < per; i += 1024) {
+            const unsigned key = __float_as_uint(xr[i]) & 0x7FFFFFFFu;
+            if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0, bin = 0;
+            for (; bin < 256; ++bin) {
+                if (cum + hist[bin] > k) break;
+                cum += hist[bin];
+            }
+            sh_prefix = prefix | (bin << shift);
+            sh_k = k - cum;
+            sh_below = below + cum;
+        }
+        __syncthreads();
+        prefix = sh_prefix; k = sh_k; below = sh_below;
+        __syncthreads();
+    }
+    // prefix = key of the k_lo-th smallest |x|; `below` = #elements < it; k = rank inside the run of equal keys
+    float v_lo = __uint_as_float(prefix), v_hi = v_lo;
+    if (need_hi) {
+        // count of elements equal to the key = hist of the last pass at its bin; k < that count.  If another equal element
+        // follows, v_hi == v_lo; otherwise v_hi is the smallest key above.
+        const unsigned eq = hist[prefix & 255u];
+        if (k + 1 >= eq) {
+            if (tid == 0) sh_min = 0x7F800000u;      // +inf
+            __syncthreads();
+            unsigned m = 0x7F800000u;
+            for (size_t i = tid; i < per; i += 1024) {
+                const unsigned key = __float_as_uint(xr[i]) & 0x7FFFFFFFu;
+                if (key > prefix && key < m) m = key;
+            }
+            atomicMin(&sh_min, m);
+            __syncthreads();
+            v_hi = __uint_as_float(sh_min);
+        }
+    }
+    if (tid == 0)     // torch.lerp: a + w (b - a) for w < 0.5, b - (b - a)(1 - w) otherwise
+        out[blockIdx.x] = weight < 0.5f ? v_lo + weight * (v_hi - v_lo) : v_hi - (v_hi - v_lo) * (1.f - weight);
+}
+
+__global__ __launch_bounds__(256) void dynamic_threshold_kernel(const float* __restrict__ x0, const float* __restrict__ s,
+                                                                float* __restrict__ out, size_t per) {
+    const int b = blockIdx.y;
+    const float sb = s[b];
+    const size_t o = (size_t)b * per;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256)
+        out[o + i] = fminf(fmaxf(x0[o + i], -sb), sb) / sb;
+}
+
+// out = mask != 0 ? y : x     (inpainting: img * ~mask + noised * mask, imagen_pytorch3D.py:2121-2123)
+__global__ __launch_bounds__(256) void mask_blend_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ mask, float* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = mask[i] != 0.f ? y[i] : x[i];
+}
 }  // namespace diqt
 
 using namespace diqt;
@@ -1559,4 +1634,24 @@ extern "C" int diqt_linear_small_bwd(const float* x, const float* W, const float
         rc = check_launch("linear_small_bwd/dx_sum");
     }
     return rc;
+}
+
+extern "C" int diqt_abs_quantile(const float* x, float* out, int B, size_t per, unsigned k_lo, float weight, void* stream) {
+    DIQT_REQUIRE(x && out, DIQT_E_ALIGN, "abs_quantile: null pointer");
+    DIQT_REQUIRE(B > 0 && per > 0 && k_lo < per && weight >= 0.f && weight < 1.f, DIQT_E_SHAPE, "abs_quantile: bad rank");
+    const int need_hi = (weight > 0.f && (size_t)k_lo + 1 < per) ? 1 : 0;
+    hipLaunchKernelGGL(abs_quantile_kernel, dim3(B), dim3(1024), 0, STREAM, x, out, per, k_lo, need_hi, weight);
+    return check_launch("abs_quantile");
+}
+extern "C" int diqt_dynamic_threshold(const float* x0, const float* s, float* out, int B, size_t per, void* stream) {
+    DIQT_REQUIRE(x0 && s && out, DIQT_E_ALIGN, "dynamic_threshold: null pointer");
+    DIQT_REQUIRE(B > 0 && per > 0, DIQT_E_SHAPE, "dynamic_threshold: bad shape");
+    hipLaunchKernelGGL(dynamic_threshold_kernel, dim3(grid_for(per, 256, 1024), B), dim3(256), 0, STREAM, x0, s, out, per);
+    return check_launch("dynamic_threshold");
+}
+extern "C" int diqt_mask_blend(const float* x, const float* y, const float* mask, float* out, size_t n, void* stream) {
+    DIQT_REQUIRE(x && y && mask && out, DIQT_E_ALIGN, "mask_blend: null pointer");
+    if (n == 0) return DIQT_OK;
+    hipLaunchKernelGGL(mask_blend_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, STREAM, x, y, mask, out, n);
+    return check_launch("mask_blend");
 }

@@ -949,11 +949,8 @@ class Imagen(nn.Module):
         """Ancestral sampler (:2059-2160).  Per step: one U-Net eval (HIP) + ONE fused posterior-step kernel;
         the per-step coefficients for all steps are computed on the host up front.  ``noise`` (optional) is a list
         [init, step_0, ...] of injected tensors with the reference's draw order (:2080, :2051)."""
-        assert not exists(inpaint_images) and not exists(inpaint_masks), \
-            'inpainting resample loop is listed under SURVEY.md §8(f) next'
-        if dynamic_threshold or pred_objective != 'x_start':
-            raise NotImplementedError('dynamic thresholding / noise- and v-objectives are SURVEY.md §8(f) "next" items; '
-                                      "the IQT configs use pred_obj='x_start', dynamic_threshold=False")
+        if pred_objective not in ('noise', 'x_start', 'v'):
+            raise ValueError(f'unknown objective {pred_objective}')
         device = self.device
         batch = shape[0]
         noise = list(noise) if exists(noise) else None
@@ -963,6 +960,12 @@ class Imagen(nn.Module):
         if exists(init_images):
             img = ops.add(img, init_images.to(device).float())
 
+        has_inpainting = exists(inpaint_images) and exists(inpaint_masks)                  # (:2090-2091)
+        resample_times = inpaint_resample_times if has_inpainting else 1
+        if has_inpainting:
+            inpaint_images = inpaint_images.to(device).float().expand(shape).contiguous()
+            mask_f = inpaint_masks.to(device).bool().expand(shape).float().contiguous()
+
         timesteps = list(noise_scheduler.get_sampling_timesteps(batch, device='cpu'))
         skip_steps = default(skip_steps, 0)
         if skip_steps > 1:
@@ -971,16 +974,43 @@ class Imagen(nn.Module):
         # host: coefficients of every step, uploaded once  [T, 3, B] ; log-SNR conditioning [T, B]
         coefs = torch.stack([torch.stack(noise_scheduler.posterior_coefficients(t, tn)) for t, tn in timesteps])
         conds = torch.stack([noise_scheduler.get_condition(t) for t, _ in timesteps])
-        coefs, conds = coefs.to(device), conds.to(device)
+        # x0 from a noise / v prediction (:343-357) and the inpainting re-noise coefficients (:324-341), per step [T, 2, B]
+        al, sg = log_snr_to_alpha_sigma(conds)
+        al_n, sg_n = log_snr_to_alpha_sigma(torch.stack([noise_scheduler.get_condition(tn) for _, tn in timesteps]))
+        if pred_objective == 'noise':
+            x0c = torch.stack((1. / al.clamp(min=1e-8), -sg / al.clamp(min=1e-8)), dim=1)
+        else:
+            x0c = torch.stack((al, -sg), dim=1)
+        last = torch.stack([(tn == 0) for _, tn in timesteps])                                        # [T, B]
+        renoise = torch.stack((torch.where(last, torch.ones_like(al), al / al_n),
+                               torch.where(last, torch.zeros_like(al), (sg * al_n - sg_n * al) / al_n)), dim=1)
+        coefs, conds, x0c, renoise, qs = (t.to(device) for t in (coefs, conds, x0c, renoise, torch.stack((al, sg), dim=1)))
         lo, hi, mode = self._clamp_cfg()
         lowres = lowres_cond_img.to(device).float().contiguous() if exists(lowres_cond_img) else None
+        inf = float('inf')
 
         noisy_dev, x0_dev = [], []
         x_start = None
         for i in range(len(timesteps)):
-            pred = unet.forward_with_cond_scale(img, None, conds[i], cond_images=cond_images, cond_scale=cond_scale,
-                                                lowres_cond_img=lowres, self_cond=x_start if unet.self_cond else None)
-            img, x_start = ops.ddpm_step(img, pred.contiguous(), draw(), coefs[i, 0], coefs[i, 1], coefs[i, 2], lo, hi, mode)
+            all_last = bool(last[i].all())
+            for r in reversed(range(resample_times)):
+                if has_inpainting:                                                         # (:2119-2123)
+                    noised = ops.q_sample(inpaint_images, draw(), qs[i, 0], qs[i, 1])
+                    img = ops.mask_blend(img, noised, mask_f)
+                pred = unet.forward_with_cond_scale(img, None, conds[i], cond_images=cond_images, cond_scale=cond_scale,
+                                                    lowres_cond_img=lowres, self_cond=x_start if unet.self_cond else None)
+                pred = pred.contiguous()
+                if pred_objective != 'x_start':                                            # (:1996-2003)
+                    pred = ops.axpby3(img, pred, None, x0c[i, 0], x0c[i, 1], None, 0.0, 0.0, 0)
+                if dynamic_threshold:                                                      # (:2006-2021)
+                    s = ops.abs_quantile(pred, self.dynamic_thresholding_percentile)
+                    s.clamp_(min=1. if self.configs['Data']['norm'] == 'min-max' else float(self.min_bound))
+                    pred = ops.dynamic_threshold(pred, s)
+                    img, x_start = ops.ddpm_step(img, pred, draw(), coefs[i, 0], coefs[i, 1], coefs[i, 2], -inf, inf, 1)
+                else:
+                    img, x_start = ops.ddpm_step(img, pred, draw(), coefs[i, 0], coefs[i, 1], coefs[i, 2], lo, hi, mode)
+                if has_inpainting and not (r == 0 or all_last):                            # (:2139-2146)
+                    img = ops.axpby3(img, draw(), None, renoise[i, 0], renoise[i, 1], None, 0.0, 0.0, 0)
             noisy_dev.append(img)
             x0_dev.append(x_start)
         noisy_dev.append(img)
@@ -1026,7 +1056,8 @@ class Imagen(nn.Module):
             lowres_cond_img = img if unet.lowres_cond else None
             shape = (batch_size, self.channels, image_size, image_size, image_size)
             img, lst_pred_noisy, lst_pred = self.p_sample_loop(
-                unet, shape, cond_images=cond_images, init_images=unet_init_images, skip_steps=unet_skip_steps,
+                unet, shape, cond_images=cond_images, inpaint_images=inpaint_images, inpaint_masks=inpaint_masks,
+                inpaint_resample_times=inpaint_resample_times, init_images=unet_init_images, skip_steps=unet_skip_steps,
                 cond_scale=unet_cond_scale, lowres_cond_img=lowres_cond_img, noise_scheduler=noise_scheduler,
                 pred_objective=pred_objective, dynamic_threshold=dynamic_threshold, use_tqdm=use_tqdm, noise=noise)
             outputs.append(img)
@@ -1039,8 +1070,8 @@ class Imagen(nn.Module):
     def p_losses(self, unet, x_start, times, *, noise_scheduler, lowres_cond_img=None, cond_images=None, noise=None,
                  pred_objective='noise', p2_loss_weight_gamma=0., **kwargs):
         """imagen_pytorch3D.py:2277-2387 -> (loss, pred, x_noisy, lowres)."""
-        if pred_objective != 'x_start':
-            raise NotImplementedError("noise-/v-objective training: SURVEY.md §8(f) next (IQT uses 'x_start')")
+        if pred_objective not in ('noise', 'x_start', 'v'):
+            raise ValueError(f'unknown objective {pred_objective}')
         device = x_start.device
         x_start = self.normalize_img(x_start).float().contiguous()
         lowres_cond_img = maybe(self.normalize_img)(lowres_cond_img)
@@ -1057,8 +1088,15 @@ class Imagen(nn.Module):
         weight = None
         if p2_loss_weight_gamma > 0:                                                       # (:2368-2370)
             weight = ((self.p2_loss_weight_k + log_snr.exp()) ** -p2_loss_weight_gamma).to(device)
-        # in-place clamp_(min_bound) + MSE mean in one kernel; returns the clamped pred like the reference (:2361-2364)
-        loss, pred = ops.mse_clamp(pred, x_start, lo=float(self.min_bound), do_clamp=True, weight=weight)
+        if pred_objective == 'x_start':
+            # in-place clamp_(min_bound) + MSE mean in one kernel; returns the clamped pred like the reference (:2361-2364)
+            loss, pred = ops.mse_clamp(pred, x_start, lo=float(self.min_bound), do_clamp=True, weight=weight)
+        else:
+            if pred_objective == 'noise':                                                  # (:2344-2345)
+                target = noise
+            else:                                                                          # v = alpha*eps - sigma*x0 (:2348-2352)
+                target = ops.axpby3(noise, x_start, None, alpha.to(device), (-sigma).to(device), None, 0.0, 0.0, 0)
+            loss, pred = ops.mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=weight)
         return loss, pred, x_noisy, lowres_cond_img
 
     def forward(self, images, lowres_img=None, unet=None, text_embeds=None, text_masks=None, unet_number=None,

@@ -917,6 +917,38 @@ def ddpm_step(x_t, pred, noise, ca, cb, cn, lo, hi, clamp_mode):
     return x_next, x0
 
 
+def abs_quantile(x, q):
+    """torch.quantile(x.flatten(1).abs(), q, dim=-1) (linear interpolation) by radix select: [B] thresholds."""
+    import numpy as np
+    _chk(x)
+    B = x.shape[0]
+    per = x.numel() // B
+    rank = np.float32(q) * np.float32(per - 1)             # the fp32 rank arithmetic of aten's quantile_compute
+    k_lo = int(np.floor(rank))
+    weight = float(np.float32(rank - np.float32(k_lo)))
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    _lib.call("diqt_abs_quantile", x, out, B, per, k_lo, weight, _stream())
+    return out
+
+
+def dynamic_threshold(x0, s):
+    """clamp(x0, -s[b], s[b]) / s[b]"""
+    _chk(x0, s)
+    B = x0.shape[0]
+    out = torch.empty_like(x0)
+    _lib.call("diqt_dynamic_threshold", x0, s, out, B, x0.numel() // B, _stream())
+    return out
+
+
+def mask_blend(x, y, mask):
+    """mask ? y : x (mask: 0/1 float tensor of x's shape)"""
+    _chk(x, y, mask)
+    assert x.shape == y.shape == mask.shape
+    out = torch.empty_like(x)
+    _lib.call("diqt_mask_blend", x, y, mask, out, x.numel(), _stream())
+    return out
+
+
 def axpby3(a, b, c, c0, c1, c2, lo=0.0, hi=0.0, clamp_mode=0):
     _chk(a, b, c, c0, c1, c2)
     B = a.shape[0]

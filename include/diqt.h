@@ -252,6 +252,15 @@ int diqt_mse_clamp_bwd(const float* pred_clamped, const float* target, const flo
 int diqt_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_correction1, float bias_correction2, int zero_grad, void* stream);
+/* Dynamic thresholding of the predicted x0 (imagen_pytorch3D.py:2006-2021; elucidated_imagen.py:340-358):
+ * out[b] = torch.quantile(|x[b, :]|, q) with linear interpolation.  The caller passes the fp32 rank split the way
+ * torch does: rank = q * (per - 1) in fp32, k_lo = floor(rank), weight = rank - k_lo.                              */
+int diqt_abs_quantile(const float* x, float* out, int B, size_t per_batch, unsigned k_lo, float weight, void* stream);
+/* out = clamp(x0, -s[b], s[b]) / s[b] */
+int diqt_dynamic_threshold(const float* x0, const float* s, float* out, int B, size_t per_batch, void* stream);
+/* Inpainting blend (imagen_pytorch3D.py:2121-2123): out = mask != 0 ? y : x  (mask as 0/1 floats, n elements) */
+int diqt_mask_blend(const float* x, const float* y, const float* mask, float* out, size_t n, void* stream);
+
 /* Gradient accumulation (accelerate's accumulate()/DDP no_sync, trainer.py:300,1118): the per-parameter gradients of one
  * micro-step are added into the flat gradient arena in ONE launch.  table[t] = {src device pointer, dst element offset,
  * element count} (3 x int64, device memory); every tensor gets `blocks_per_tensor` workgroups.                    */

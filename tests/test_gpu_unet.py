@@ -138,3 +138,76 @@ def test_unet_config2_shape_vs_oracle_fresh_inputs():
         yr = O.unet_forward(sd, O.unet_config(**kw), x, t, ls, lowres_cond_img=lr)
     rel = close(y, yr, 2e-4, "config-2 unet")
     assert rel <= 2e-5, rel
+
+
+SAMPLER_OPTION_CASES = [
+    ('noise_dyn', 'noise', True, 'z-score', 4, {}),
+    ('v_static', 'v', False, 'z-score', 4, {}),
+    ('x0_dyn_minmax', 'x_start', True, 'min-max', 4, {}),
+    ('skip2', 'x_start', False, 'z-score', 6, {'skip_steps': 2}),
+    ('inpaint', 'x_start', False, 'z-score', 3, {'inpaint_resample_times': 1}),
+]
+
+
+def _imagen_for(gu, objective, dyn, norm, Tn, mb):
+    from diffusioniqt_amd.imagen_pytorch3D import Imagen, NullUnet
+    unet, sd, cfg = build(gu, 0)
+    configs = {'Data': {'norm': norm}, 'Train': {'batch_sample': False}}
+    return Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=mb, image_sizes=(8, 8), channels=1,
+                  pred_objectives=objective, timesteps=Tn, dynamic_thresholding=dyn, dynamic_thresholding_percentile=0.9,
+                  p2_loss_weight_gamma=0.0, cond_drop_prob=0.0).to(DEV)
+
+
+@pytest.mark.parametrize("tag,objective,dyn,norm,Tn,extra", SAMPLER_OPTION_CASES)
+def test_sampler_options_match_reference_golden(tag, objective, dyn, norm, Tn, extra):
+    """SURVEY.md §8(f) item 4 on the HIP path: noise/v objectives, dynamic thresholding (radix-select quantile),
+    skip_steps and inpainting against fixtures of the real reference (oracle/make_golden_next.py)."""
+    g = load_golden('ddpmA_options')
+    gu = load_golden('unetA_tiny')
+    mb = float(g['min_bound'])
+    imagen = _imagen_for(gu, objective, dyn, norm, Tn, mb)
+    kw = dict(extra)
+    if tag == 'inpaint':
+        kw.update(inpaint_images=T(g['inpaint:images']).to(DEV), inpaint_masks=T(g['inpaint:mask']).to(DEV))
+    img, noisy, x0 = imagen.sample(batch_size=2, start_image_or_video=T(g['lowres']).to(DEV), start_at_unet_number=2,
+                                   use_tqdm=False, noise=list(T(g[f'{tag}:draws'])), **kw)
+    clampf = (lambda t: t.clamp(-1., 1.)) if norm == 'min-max' else (lambda t: t.clamp(min=mb))
+    # dynamic thresholding divides by the per-sample quantile: looser bound (the selected order statistics are exact,
+    # the U-Net outputs they are taken from carry the usual fp32 conv error)
+    tol = 2e-3 if dyn else 5e-4
+    close(img, T(g[f'{tag}:img']), tol, f"{tag} img")
+    ref_noisy = T(g[f'{tag}:noisy'])
+    assert len(noisy) == ref_noisy.shape[0]
+    close(T(np.stack(noisy[:-2])), ref_noisy[:-2], tol, f"{tag} noisy list")
+    close(clampf(T(np.stack(noisy[-2:]))), ref_noisy[-2:], tol, f"{tag} noisy tail")
+    close(T(np.stack(x0)), T(g[f'{tag}:x0']), tol, f"{tag} x0 list")
+
+
+@pytest.mark.parametrize("objective", ['noise', 'v'])
+def test_noise_and_v_objective_training_match_reference_golden(objective):
+    g = load_golden('ddpmA_options')
+    gu = load_golden('unetA_tiny')
+    imagen = _imagen_for(gu, objective, False, 'z-score', 4, float(g['min_bound']))
+    times = T(g['times'])
+    imagen.noise_schedulers[1].sample_random_times = lambda b, device: times.clone()
+    u = imagen.unets[1]
+    u.train()
+    loss, pred, _, _ = imagen(T(g['hr']).to(DEV), lowres_img=T(g['lowres']).to(DEV), unet_number=2, noise=T(g['noise']).to(DEV))
+    ref = float(g[f'loss_{objective}'])
+    assert abs(loss.item() - ref) <= 2e-5 * abs(ref)
+    close(pred, T(g[f'pred_{objective}']), 2e-4, "pred")
+    loss.backward()
+    named = dict(u.named_parameters())
+    for k in ('final_conv.weight', 'init_conv.weight'):
+        close(named[k].grad, T(g[f'grad_{objective}:{k}']), 1e-3, f"grad {k}")
+
+
+def test_abs_quantile_matches_torch_quantile():
+    from diffusioniqt_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for shape, q in (((3, 1, 8, 8, 8), 0.9), ((2, 4097), 0.95), ((4, 1, 32, 32, 32), 0.95), ((2, 5), 0.5), ((1, 7), 1.0 - 1e-7)):
+        x = torch.randn(*shape, generator=gen)
+        x[0].view(-1)[:3] = 2.5                     # ties around the selected rank
+        ref = torch.quantile(x.flatten(1).abs(), q, dim=-1)
+        got = ops.abs_quantile(x.to(DEV), q).cpu()
+        assert torch.allclose(got, ref, atol=0, rtol=1e-6), (shape, q, got, ref)

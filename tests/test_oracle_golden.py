@@ -124,3 +124,52 @@ def test_ddpm_trajectory():
     assert torch.allclose(torch.stack(noisy[:-2]), ref_noisy[:-2], atol=1e-4, rtol=1e-4)
     assert torch.allclose(torch.stack(noisy[-2:]).clamp(min=mb), ref_noisy[-2:], atol=1e-4, rtol=1e-4)
     assert torch.allclose(torch.stack(x0), T(g['x0']), atol=1e-4, rtol=1e-4)
+
+
+SAMPLER_OPTION_CASES = [
+    # tag, objective, dynamic threshold, norm, T, extra kwargs
+    ('noise_dyn', 'noise', True, 'z-score', 4, {}),
+    ('v_static', 'v', False, 'z-score', 4, {}),
+    ('x0_dyn_minmax', 'x_start', True, 'min-max', 4, {}),
+    ('skip2', 'x_start', False, 'z-score', 6, {'skip_steps': 2}),
+    ('inpaint', 'x_start', False, 'z-score', 3, {'inpaint_resample_times': 1}),
+]
+
+
+@pytest.mark.parametrize("tag,objective,dyn,norm,Tn,extra", SAMPLER_OPTION_CASES)
+def test_sampler_options_oracle_vs_reference(tag, objective, dyn, norm, Tn, extra):
+    """noise/v objectives, dynamic thresholding (p = 0.9), skip_steps, inpainting."""
+    g = load_golden('ddpmA_options')
+    gu = load_golden('unetA_tiny')
+    sd, cfg = build_sd(gu), cfg_of(gu)
+    draws = list(T(g[f'{tag}:draws']))
+    kw = dict(extra)
+    if tag == 'inpaint':
+        kw.update(inpaint_images=T(g['inpaint:images']), inpaint_masks=T(g['inpaint:mask']))
+    mb = float(g['min_bound'])
+    with torch.no_grad():
+        img, noisy, x0 = O.p_sample_loop(sd, cfg, T(g['lowres']), draws[0], draws[1:], timesteps=Tn, min_bound=mb, norm=norm,
+                                         pred_objective=objective, dynamic_threshold=dyn, percentile=0.9, **kw)
+    clampf = (lambda t: t.clamp(-1., 1.)) if norm == 'min-max' else (lambda t: t.clamp(min=mb))
+    assert torch.allclose(img, T(g[f'{tag}:img']), atol=2e-4, rtol=2e-4)
+    ref_noisy = T(g[f'{tag}:noisy'])
+    assert len(noisy) == ref_noisy.shape[0]
+    assert torch.allclose(torch.stack(noisy[:-2]), ref_noisy[:-2], atol=2e-4, rtol=2e-4)
+    assert torch.allclose(clampf(torch.stack(noisy[-2:])), ref_noisy[-2:], atol=2e-4, rtol=2e-4)   # CPU numpy aliasing, see above
+    assert torch.allclose(torch.stack(x0), T(g[f'{tag}:x0']), atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("objective", ['noise', 'v'])
+def test_noise_and_v_objective_losses_oracle_vs_reference(objective):
+    g = load_golden('ddpmA_options')
+    gu = load_golden('unetA_tiny')
+    sd, cfg = build_sd(gu), cfg_of(gu)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    loss, pred, _, _ = O.p_losses(sd, cfg, T(g['hr']), T(g['lowres']), T(g['times']), T(g['noise']),
+                                  min_bound=float(g['min_bound']), pred_objective=objective)
+    assert abs(loss.item() - float(g[f'loss_{objective}'])) <= 2e-5 * abs(float(g[f'loss_{objective}']))
+    assert torch.allclose(pred, T(g[f'pred_{objective}']), atol=2e-4, rtol=2e-4)
+    loss.backward()
+    for k in ('final_conv.weight', 'init_conv.weight'):
+        ref = T(g[f'grad_{objective}:{k}'])
+        assert torch.allclose(sd[k].grad, ref, atol=1e-3 * ref.abs().max().item(), rtol=1e-3), k

@@ -154,11 +154,14 @@ class ElucidatedImagen(nn.Module):
         return torch.nn.functional.pad(sigmas, (0, 1), value=0.)
 
     def threshold_x_start(self, x_start, dynamic_threshold=True):
+        """elucidated_imagen.py:298-311: clamp(-1, 1), or per-sample s = max(quantile(|x0|, p), 1) then clamp(-s, s) / s."""
+        x_start = x_start.contiguous()
         if dynamic_threshold:
-            raise NotImplementedError('dynamic (quantile) thresholding is listed under SURVEY.md §8(f) "next"; '
-                                      'pass dynamic_thresholding=False')
+            s = ops.abs_quantile(x_start, self.dynamic_thresholding_percentile)
+            s.clamp_(min=1.)
+            return ops.dynamic_threshold(x_start, s)
         one = torch.ones(x_start.shape[0], device=x_start.device)
-        return ops.axpby3(x_start.contiguous(), None, None, one, None, None, -1., 1., 2)
+        return ops.axpby3(x_start, None, None, one, None, None, -1., 1., 2)
 
     def _unet_kwargs(self, unet, lowres_cond_img, lowres_noise_times):
         inner = unet.module if hasattr(unet, 'module') else unet
@@ -177,7 +180,8 @@ class ElucidatedImagen(nn.Module):
         x_in = ops.axpby3(noised_images.contiguous(), None, None, cin, None, None)
         net_out = unet_forward(x_in, self.c_noise(sig).to(dev), **kwargs)
         if clamp and dynamic_threshold:
-            raise NotImplementedError('dynamic thresholding: SURVEY.md §8(f) next')
+            out = ops.axpby3(noised_images.contiguous(), net_out.contiguous(), None, cskip, cout, None, 0., 0., 0)
+            return self.threshold_x_start(out, True)
         return ops.axpby3(noised_images.contiguous(), net_out.contiguous(), None, cskip, cout, None, -1., 1., 2 if clamp else 0)
 
     @torch.no_grad()

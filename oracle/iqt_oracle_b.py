@@ -331,15 +331,24 @@ def lowres_q_sample(x, t, noise):
     return a.view(sh) * x + s.view(sh) * noise
 
 
-def preconditioned(unet_fn, noised, sigma: Tensor, sigma_data, clamp=False):
-    """preconditioned_network_forward — :329-358 (static clamp(-1,1); dynamic thresholding is a 'next' item)."""
+def threshold_x_start(x_start: Tensor, dynamic: bool, percentile: float = 0.95) -> Tensor:
+    """elucidated_imagen.py:298-311"""
+    if not dynamic:
+        return x_start.clamp(-1., 1.)
+    s = torch.quantile(x_start.flatten(1).abs(), percentile, dim=-1).clamp(min=1.)
+    s = s.view(-1, *((1,) * (x_start.ndim - 1)))
+    return x_start.clamp(-s, s) / s
+
+
+def preconditioned(unet_fn, noised, sigma: Tensor, sigma_data, clamp=False, dynamic=False, percentile=0.95):
+    """preconditioned_network_forward — :329-358"""
     ps = sigma.view(-1, *((1,) * (noised.ndim - 1)))
     net = unet_fn(c_in(sigma_data, ps) * noised, c_noise(sigma))
     out = c_skip(sigma_data, ps) * noised + c_out(sigma_data, ps) * net
-    return out.clamp(-1., 1.) if clamp else out
+    return threshold_x_start(out, dynamic, percentile) if clamp else out
 
 
-def edm_sample(unet_fn, shape, init_noise: Tensor, step_noises: Sequence[Tensor], hp: dict):
+def edm_sample(unet_fn, shape, init_noise: Tensor, step_noises: Sequence[Tensor], hp: dict, dynamic=False, percentile=0.95):
     """one_unet_sample — elucidated_imagen.py:382-532 with injected noise (draw order :430, :476).
     ``unet_fn(x, c_noise)`` closes over the low-res conditioning."""
     sigmas = sample_schedule(hp['num_sample_steps'], hp['rho'], hp['sigma_min'], hp['sigma_max'])
@@ -350,11 +359,13 @@ def edm_sample(unet_fn, shape, init_noise: Tensor, step_noises: Sequence[Tensor]
         eps = hp['S_noise'] * step_noises[ind]
         sigma_hat = sigma + gamma * sigma
         images_hat = images + math.sqrt(sigma_hat ** 2 - sigma ** 2) * eps
-        out = preconditioned(unet_fn, images_hat, torch.full((b,), sigma_hat), hp['sigma_data'], clamp=True)
+        out = preconditioned(unet_fn, images_hat, torch.full((b,), sigma_hat), hp['sigma_data'], clamp=True, dynamic=dynamic,
+                             percentile=percentile)
         d = (images_hat - out) / sigma_hat
         images_next = images_hat + (sigma_next - sigma_hat) * d
         if sigma_next != 0:
-            out2 = preconditioned(unet_fn, images_next, torch.full((b,), sigma_next), hp['sigma_data'], clamp=True)
+            out2 = preconditioned(unet_fn, images_next, torch.full((b,), sigma_next), hp['sigma_data'], clamp=True,
+                                  dynamic=dynamic, percentile=percentile)
             d2 = (images_next - out2) / sigma_next
             images_next = images_hat + 0.5 * (sigma_next - sigma_hat) * (d + d2)
         images = images_next

@@ -156,13 +156,14 @@ def test_unet3d_forward_and_grads_match_reference_golden():
         assert (p.grad is None) == (k in unused), k
 
 
-def make_edm(unet_kw, steps):
+def make_edm(unet_kw, steps, dynamic=False, percentile=0.95):
     from diffusioniqt_amd.imagen_video import Unet3D
     from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
     base = Unet3D(**{**unet_kw, 'lowres_cond': False, 'dim_mults': (1, 2), 'layer_attns': False})
     sr = Unet3D(**unet_kw)
     elu = ElucidatedImagen(unets=(base, sr), image_sizes=(8, 8), channels=1, condition_on_text=False, auto_normalize_img=False,
-                           cond_drop_prob=0.0, num_sample_steps=steps, dynamic_thresholding=False)
+                           cond_drop_prob=0.0, num_sample_steps=steps, dynamic_thresholding=dynamic,
+                           dynamic_thresholding_percentile=percentile)
     u = elu.unets[1]
     u.load_state_dict(O.hash_fill_state_dict(u.state_dict(), 11))
     return elu.to(DEV)
@@ -193,6 +194,18 @@ def test_edm_sample_and_loss_match_reference_golden():
     for k in g:
         if k.startswith('grad:'):
             close(named[k[5:]].grad, T(g[k]), 3e-3, k)
+
+
+def test_edm_sample_dynamic_thresholding_matches_reference_golden():
+    gu = load_golden('unet3d_tiny')
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(str(gu['kwargs'])).items()}
+    g = load_golden('edm_sample_dyn')
+    elu = make_edm(kw, 3, dynamic=True, percentile=float(g['percentile']))
+    noise = [T(g['lowres_noise']), T(g['init_noise'])] + list(T(g['step_noise']))
+    img = elu.sample(batch_size=2, video_frames=8, start_image_or_video=T(g['lowres']).to(DEV), start_at_unet_number=2,
+                     use_tqdm=False, noise=noise)
+    err = (img.cpu() - T(g['img'])).abs()
+    assert err.max().item() <= 5e-3 and (err > 2e-4).float().mean().item() < 0.03, (err.max().item(), (err > 2e-4).float().mean().item())
 
 
 def test_edm_drives_the_true_conv3d_unet_superset():

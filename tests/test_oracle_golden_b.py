@@ -54,6 +54,22 @@ def test_edm_schedule_and_sample_trajectory():
     assert ((img - T(g['img'])).abs() > 1e-4).float().mean() < 0.02
 
 
+def test_edm_sample_with_dynamic_thresholding():
+    """elucidated_imagen.py:298-311 (percentile 0.9, s >= 1), B = 2."""
+    g = load_golden('edm_sample_dyn')
+    gu = load_golden('unet3d_tiny')
+    sd, cfg = build(gu)
+    hp = dict(OB.EDM_DEFAULTS, num_sample_steps=3)
+    lt = torch.full((2,), float(g['lowres_noise_level']))
+    lowres = OB.lowres_q_sample(T(g['lowres']), lt, T(g['lowres_noise']))
+    fn = lambda x, cn: OB.unet3d_forward(sd, cfg, x, cn, lowres_cond_img=lowres, lowres_noise_times=lt)
+    with torch.no_grad():
+        img = OB.edm_sample(fn, (2, 1, 8, 8, 8), T(g['init_noise']), list(T(g['step_noise'])), hp, dynamic=True,
+                            percentile=float(g['percentile']))
+    assert torch.allclose(img, T(g['img']), atol=2e-3, rtol=0), (img - T(g['img'])).abs().max()
+    assert ((img - T(g['img'])).abs() > 1e-4).float().mean() < 0.02
+
+
 def test_edm_training_loss_and_grads():
     g = load_golden('edm_loss')
     gu = load_golden('unet3d_tiny')

@@ -1147,6 +1147,71 @@ __global__ __launch_bounds__(256) void mask_blend_kernel(const float* __restrict
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         out[i] = mask[i] != 0.f ? y[i] : x[i];
 }
+
+// ---------------------------------------------------------------------------------------------
+// whole-volume inference (test_all.py:182-300, data.py:138-202): sliding-window patches of a resident [D][H][W] volume
+// ---------------------------------------------------------------------------------------------
+// out[n][P^3] = (vol[idx[n] + (i,j,k)] - mean) / std ; nz[n] = number of non-zero RAW voxels of the patch (5 % rejection rule)
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ vol, const int* __restrict__ idx,
+                                                           float* __restrict__ out, int* __restrict__ nz, int D, int H, int W,
+                                                           int P, float mean, float stdv) {
+    __shared__ int sh[4];
+    const int n = blockIdx.y;
+    const int i0 = idx[3 * n], j0 = idx[3 * n + 1], k0 = idx[3 * n + 2];
+    const size_t per = (size_t)P * P * P;
+    int cnt = 0;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < per; e += (size_t)gridDim.x * 256) {
+        const int k = (int)(e % P), j = (int)((e / P) % P), i = (int)(e / ((size_t)P * P));
+        const float v = vol[((size_t)(i0 + i) * H + (j0 + j)) * W + (k0 + k)];
+        cnt += v != 0.f;
+        if (out) out[(size_t)n * per + e] = (v - mean) / stdv;
+    }
+    if (nz) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&nz[n], sh[0] + sh[1] + sh[2] + sh[3]);
+    }
+}
+// pred[idx[n] + (i,j,k)] = patch[n][i][j][k] for lo[a] <= coordinate < P - hi[a]   (margins m[n] = {lo0,hi0,lo1,hi1,lo2,hi2})
+__global__ __launch_bounds__(256) void patch_scatter_kernel(const float* __restrict__ patches, const int* __restrict__ idx,
+                                                            const int* __restrict__ m, float* __restrict__ pred, int D, int H,
+                                                            int W, int P) {
+    const int n = blockIdx.y;
+    const int i0 = idx[3 * n], j0 = idx[3 * n + 1], k0 = idx[3 * n + 2];
+    const int* mm = m + 6 * n;
+    const size_t per = (size_t)P * P * P;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < per; e += (size_t)gridDim.x * 256) {
+        const int k = (int)(e % P), j = (int)((e / P) % P), i = (int)(e / ((size_t)P * P));
+        if (i < mm[0] || i >= P - mm[1] || j < mm[2] || j >= P - mm[3] || k < mm[4] || k >= P - mm[5]) continue;
+        pred[((size_t)(i0 + i) * H + (j0 + j)) * W + (k0 + k)] = patches[(size_t)n * per + e];
+    }
+}
+// pred[i] = min_val where the normalised low-res voxel equals min_val (test_all.py:300); vol is RAW
+__global__ __launch_bounds__(256) void background_reset_kernel(float* __restrict__ pred, const float* __restrict__ vol, size_t n,
+                                                               float mean, float stdv, float min_val) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        if ((vol[i] - mean) / stdv == min_val) pred[i] = min_val;
+}
+// two-stage minimum: partial[block] then out[0]
+__global__ __launch_bounds__(256) void min_stage1_kernel(const float* __restrict__ x, float* __restrict__ partial, size_t n) {
+    __shared__ float sh[4];
+    float m = INFINITY;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fminf(m, x[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = fminf(fminf(sh[0], sh[1]), fminf(sh[2], sh[3]));
+}
+__global__ __launch_bounds__(64) void min_stage2_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+    float m = INFINITY;
+    for (int i = threadIdx.x; i < nb; i += 64) m = fminf(m, partial[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+    if (threadIdx.x == 0) out[0] = m;
+}
 }  // namespace diqt
 
 using namespace diqt;
@@ -1654,4 +1719,44 @@ extern "C" int diqt_mask_blend(const float* x, const float* y, const float* mask
     if (n == 0) return DIQT_OK;
     hipLaunchKernelGGL(mask_blend_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, STREAM, x, y, mask, out, n);
     return check_launch("mask_blend");
+}
+
+extern "C" int diqt_patch_gather(const float* vol, const int* idx, float* out, int* nonzero, int n_patches, int D, int H, int W,
+                                 int P, float mean, float stdv, void* stream) {
+    DIQT_REQUIRE(vol && idx && (out || nonzero), DIQT_E_ALIGN, "patch_gather: null pointer");
+    DIQT_REQUIRE(D > 0 && H > 0 && W > 0 && P > 0 && P <= D && P <= H && P <= W, DIQT_E_SHAPE, "patch_gather: bad shape");
+    if (n_patches <= 0) return DIQT_OK;
+    DIQT_REQUIRE(n_patches <= 65535, DIQT_E_SHAPE, "patch_gather: at most 65535 patches per call");
+    if (nonzero) {
+        hipError_t e = hipMemsetAsync(nonzero, 0, (size_t)n_patches * sizeof(int), STREAM);
+        DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "patch_gather: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid_for((size_t)P * P * P, 256, 64), n_patches), dim3(256), 0, STREAM, vol, idx, out,
+                       nonzero, D, H, W, P, mean, stdv);
+    return check_launch("patch_gather");
+}
+extern "C" int diqt_patch_scatter(const float* patches, const int* idx, const int* margins, float* pred, int n_patches, int D,
+                                  int H, int W, int P, void* stream) {
+    DIQT_REQUIRE(patches && idx && margins && pred, DIQT_E_ALIGN, "patch_scatter: null pointer");
+    DIQT_REQUIRE(D > 0 && H > 0 && W > 0 && P > 0 && P <= D && P <= H && P <= W, DIQT_E_SHAPE, "patch_scatter: bad shape");
+    if (n_patches <= 0) return DIQT_OK;
+    DIQT_REQUIRE(n_patches <= 65535, DIQT_E_SHAPE, "patch_scatter: at most 65535 patches per call");
+    hipLaunchKernelGGL(patch_scatter_kernel, dim3(grid_for((size_t)P * P * P, 256, 64), n_patches), dim3(256), 0, STREAM, patches, idx,
+                       margins, pred, D, H, W, P);
+    return check_launch("patch_scatter");
+}
+extern "C" int diqt_background_reset(float* pred, const float* vol, size_t n, float mean, float stdv, float min_val, void* stream) {
+    DIQT_REQUIRE(pred && vol, DIQT_E_ALIGN, "background_reset: null pointer");
+    if (n == 0) return DIQT_OK;
+    hipLaunchKernelGGL(background_reset_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, STREAM, pred, vol, n, mean, stdv, min_val);
+    return check_launch("background_reset");
+}
+extern "C" int diqt_min_value(const float* x, size_t n, float* workspace_1024, float* out, void* stream) {
+    DIQT_REQUIRE(x && workspace_1024 && out && n > 0, DIQT_E_ALIGN, "min_value: null pointer / empty input");
+    const unsigned nb = grid_for(n, 256, 1024);
+    hipLaunchKernelGGL(min_stage1_kernel, dim3(nb), dim3(256), 0, STREAM, x, workspace_1024, n);
+    int rc = check_launch("min_value/stage1");
+    if (rc) return rc;
+    hipLaunchKernelGGL(min_stage2_kernel, dim3(1), dim3(64), 0, STREAM, workspace_1024, (int)nb, out);
+    return check_launch("min_value/stage2");
 }

@@ -1029,3 +1029,47 @@ def ema_lerp(ema, param, one_minus_decay):
     _chk(ema, param)
     _lib.call("diqt_ema_lerp", ema, param, ema.numel(), float(one_minus_decay), _stream())
     bump_weight_epoch()
+
+
+# --------------------------------------------------------------------------------------------
+# whole-volume inference (test_all.py:182-300)
+# --------------------------------------------------------------------------------------------
+def _chk_int(*ts):
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+            raise RuntimeError("index tables must be contiguous int32 HIP tensors")
+
+
+def patch_gather(vol, idx, P, mean, std, want_patches=True, want_nonzero=False):
+    """(patches [n,1,P,P,P] normalised, nonzero [n] int32) of the sliding-window origins ``idx`` [n,3] in a raw [D,H,W] volume."""
+    _chk(vol)
+    _chk_int(idx)
+    D, H, W = vol.shape
+    n = idx.shape[0]
+    out = torch.empty((n, 1, P, P, P), dtype=torch.float32, device=vol.device) if want_patches else None
+    nz = torch.empty(n, dtype=torch.int32, device=vol.device) if want_nonzero else None
+    for lo in range(0, n, 65535):
+        hi = min(n, lo + 65535)
+        _lib.call("diqt_patch_gather", vol, idx[lo:hi], out[lo:hi] if out is not None else None,
+                  nz[lo:hi] if nz is not None else None, hi - lo, D, H, W, P, float(mean), float(std), _stream())
+    return out, nz
+
+
+def patch_scatter(patches, idx, margins, pred, P):
+    _chk(patches, pred)
+    _chk_int(idx, margins)
+    D, H, W = pred.shape
+    _lib.call("diqt_patch_scatter", patches, idx, margins, pred, idx.shape[0], D, H, W, P, _stream())
+
+
+def background_reset(pred, vol, mean, std, min_val):
+    _chk(pred, vol)
+    _lib.call("diqt_background_reset", pred, vol, pred.numel(), float(mean), float(std), float(min_val), _stream())
+
+
+def min_value(x):
+    _chk(x)
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _lib.call("diqt_min_value", x, x.numel(), ws, out, _stream())
+    return out

@@ -261,6 +261,24 @@ int diqt_dynamic_threshold(const float* x0, const float* s, float* out, int B, s
 /* Inpainting blend (imagen_pytorch3D.py:2121-2123): out = mask != 0 ? y : x  (mask as 0/1 floats, n elements) */
 int diqt_mask_blend(const float* x, const float* y, const float* mask, float* out, size_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Whole-volume inference (test_all.py:182-300 with data.py:138-202): sliding-window patches of a volume resident in HBM.
+ * `idx` = int32 [n][3] patch origins; volumes are fp32 [D][H][W].
+ * ---------------------------------------------------------------------------------------------- */
+/* out[n][P][P][P] = (vol[origin + ijk] - mean) / std (out may be NULL); nonzero[n] = non-zero RAW voxels (may be NULL):
+ * supervisedIQT_INF.__getitem__ / normalize (data.py:168-199) incl. its 5 % non-zero rejection count.               */
+int diqt_patch_gather(const float* vol, const int* idx, float* out, int* nonzero, int n_patches, int D, int H, int W, int P,
+                      float mean, float stdv, void* stream);
+/* pred[origin + ijk] = patches[n][ijk] inside the crop margins[n] = {lo_i, hi_i, lo_j, hi_j, lo_k, hi_k}
+ * (the overlap//2 crop with edge special cases, test_all.py:235-298).  Patches are written in index order per launch;
+ * overlapping writes of one launch must carry equal margins-free regions (the caller launches overlapping blocks one by one). */
+int diqt_patch_scatter(const float* patches, const int* idx, const int* margins, float* pred, int n_patches, int D, int H, int W,
+                       int P, void* stream);
+/* pred[i] = min_val where (vol[i] - mean) / std == min_val (test_all.py:300) */
+int diqt_background_reset(float* pred, const float* vol, size_t n, float mean, float stdv, float min_val, void* stream);
+/* out[0] = min(x[0..n)); workspace: 1024 floats */
+int diqt_min_value(const float* x, size_t n, float* workspace_1024, float* out, void* stream);
+
 /* Gradient accumulation (accelerate's accumulate()/DDP no_sync, trainer.py:300,1118): the per-parameter gradients of one
  * micro-step are added into the flat gradient arena in ONE launch.  table[t] = {src device pointer, dst element offset,
  * element count} (3 x int64, device memory); every tensor gets `blocks_per_tensor` workgroups.                    */

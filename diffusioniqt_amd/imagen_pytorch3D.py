@@ -499,6 +499,157 @@ class SoftMaxAttention(_TokenAttention):
     linear = False
 
 
+# ---- ViT3D (imagen_pytorch3D.py:723-856, 871-910) -----------------------------------------------------------------
+class TokenLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm(emb) over the last (channel) axis of [b, tokens..., emb]: the HIP channel-LayerNorm with a bias."""
+
+    def forward(self, x):
+        return ops.chan_layernorm(x, self.weight, self.eps, bias=self.bias)
+
+
+class ResidualAdd(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        return ops.add(self.fn(x, **kwargs), x)
+
+
+class _ToVolume(nn.Module):
+    """Rearrange 'b (h w d) c -> b c h w d' (:778): a free view in channels-last memory."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.n = n
+
+    def forward(self, x):
+        return x.reshape(x.shape[0], self.n, self.n, self.n, x.shape[-1])
+
+
+class _ToTokens(nn.Module):
+    """Rearrange 'b c h w d -> b (h w d) c' (:791): a free view in channels-last memory."""
+
+    def forward(self, x):
+        return x.reshape(x.shape[0], -1, x.shape[-1])
+
+
+class FeedForwardBlock(nn.Sequential):
+    """:774-809 — registers the sub-modules under both their own names and ``net`` like the reference (shared tensors,
+    duplicated state_dict keys)."""
+
+    def __init__(self, emb_size, expansion=4, drop_p=0., patch_num=4, local=False):
+        super().__init__()
+        if local:
+            self.up_proj = nn.Sequential(_ToVolume(patch_num), Conv3d(emb_size, emb_size * expansion, kernel_size=1), Mish())
+            self.depth_conv = nn.Sequential(depthwise_separable_conv3d(emb_size * expansion, emb_size * expansion,
+                                                                       kernel_size=3, stride=1, padding=1), Mish())
+            self.down_proj = nn.Sequential(Conv3d(emb_size * expansion, emb_size, kernel_size=1), nn.Dropout(drop_p), _ToTokens())
+            self.net = nn.Sequential(self.up_proj, self.depth_conv, self.down_proj)
+        else:
+            self.net = nn.Sequential(Linear(emb_size, expansion * emb_size), Mish(), nn.Dropout(drop_p),
+                                     Linear(expansion * emb_size, emb_size))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class MultiHeadAttention(nn.Module):
+    """:811-838.  qkv channels are laid out '(h d qkv)'; one transpose kernel de-interleaves them into [rows, 3, h*d], after
+    which q, k, v and the heads are addressed by offsets / strides inside that tensor (no further copies)."""
+
+    def __init__(self, emb_size=128, num_heads=8, dim_head=64, dropout=0):
+        super().__init__()
+        self.emb_size, self.dim_head, self.num_heads = emb_size, dim_head, num_heads
+        self.inner_dim = dim_head * num_heads
+        self.qkv = Linear(emb_size, self.inner_dim * 3)
+        self.att_drop = nn.Dropout(dropout)
+        self.projection = Linear(self.inner_dim, emb_size)
+        self.scaling = dim_head ** -0.5
+
+    def forward(self, x, mask=None):
+        assert mask is None, "the reference's mask branch is a no-op (`mask_fill` result discarded, :829)"
+        b, n, _ = x.shape
+        h, d = self.num_heads, self.dim_head
+        hd = h * d
+        t = ops.transpose_mid(self.qkv(x).reshape(b * n, hd, 3, 1)).reshape(b * n, 3 * hd)     # rows: [q | k | v]
+        outs = []
+        for bi in range(b):
+            base = bi * n * 3 * hd
+            en = ops.bmm_strided(t, t, (h, n, n, d, False, True, d, 3 * hd, d, 3 * hd, n * n, n, self.scaling, (h, n, n),
+                                        base, base + hd))
+            att = self.att_drop(ops.softmax(en, dim=-1))
+            outs.append(ops.bmm_strided(att, t, (h, n, d, n, False, False, n * n, n, d, 3 * hd, d, hd, 1.0, (1, n, hd),
+                                                 0, base + 2 * hd)))
+        out = outs[0] if b == 1 else torch.cat(outs, dim=0)
+        return self.projection(out)
+
+
+class TransformerEncoderBlock(nn.Module):
+    def __init__(self, emb_size=256, num_heads=8, dim_head=64, drop_p=0., forward_expansion=4, forward_drop_p=0.,
+                 patch_num=4, local=True):
+        super().__init__()
+        self.block = nn.Sequential(
+            ResidualAdd(nn.Sequential(TokenLayerNorm(emb_size),
+                                      MultiHeadAttention(emb_size, num_heads=num_heads, dropout=drop_p, dim_head=dim_head),
+                                      nn.Dropout(drop_p))),
+            ResidualAdd(nn.Sequential(TokenLayerNorm(emb_size),
+                                      FeedForwardBlock(emb_size, expansion=forward_expansion, drop_p=forward_drop_p,
+                                                       patch_num=patch_num, local=local),
+                                      nn.Dropout(drop_p))))
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, depth=12, **kwargs):
+        super().__init__()
+        self.layers = nn.ModuleList([TransformerEncoderBlock(**kwargs) for _ in range(depth)])
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class PatchEmbedding(nn.Module):
+    """:841-856"""
+
+    def __init__(self, in_channels=3, patch_size=4, emb_size=128, img_size=224, reduction=False):
+        super().__init__()
+        self.patch_size = patch_size
+        self.projection = nn.Sequential(depthwise_separable_conv3d(in_channels, emb_size, kernel_size=patch_size,
+                                                                   stride=patch_size), _ToTokens())
+        self.positions = nn.Parameter(torch.randn((img_size // patch_size) ** 3, emb_size))
+
+    def forward(self, x):
+        x = self.projection(x)
+        return ops.add(x, self.positions.unsqueeze(0).expand_as(x).contiguous())
+
+
+class ViT3D(nn.Module):
+    """:871-910 — operates on channels-last volumes [b, X, Y, Z, C] like the other attention blocks."""
+
+    def __init__(self, in_channels=3, patch_size=16, num_heads=8, dim_head=64, img_size=224, depth=1, drop_p=0.1,
+                 forward_drop_p=0.3, forward_expansion=2, reduction=False, local=True, groups=1, **kwargs):
+        super().__init__()
+        self.reduction = reduction
+        self.emb_size = in_channels
+        n = img_size // patch_size
+        self.patch_embedding = PatchEmbedding(in_channels, patch_size, self.emb_size, img_size, reduction=reduction)
+        self.transformer_encoder = TransformerEncoder(depth, emb_size=self.emb_size, num_heads=num_heads, dim_head=dim_head,
+                                                      patch_num=n, drop_p=drop_p, forward_drop_p=forward_drop_p,
+                                                      forward_expansion=forward_expansion, local=local, **kwargs)
+        self.reconstruction = nn.Sequential(TokenLayerNorm(in_channels), _ToVolume(n), Upsample(patch_size),
+                                            depthwise_separable_conv3d(in_channels, in_channels, kernel_size=3, stride=1,
+                                                                       padding=1),
+                                            ChanLayerNorm(in_channels))
+
+    def forward(self, x):
+        return self.reconstruction(self.transformer_encoder(self.patch_embedding(x)))
+
+
 class _ChanFeedForward(nn.Sequential):
     """ChanFeedForward (:1108-1116): ChanLN -> 1x1 -> GELU -> ChanLN -> 1x1."""
 
@@ -624,9 +775,10 @@ class Unet(nn.Module):
                 klass = LinearAttentionTransformerBlock
             elif att_type == 'softmax':
                 klass = SoftMaxAttentionTransformerBlock
-            else:
-                raise NotImplementedError("att_type='vit' (ViT3D, imagen_pytorch3D.py:871-910) is listed under "
-                                          "SURVEY.md §8(f) 'next' and is not built yet")
+            else:                                                                      # (:1393-1395, 1429-1430)
+                return ViT3D(in_channels=d, patch_size=patch_size, num_heads=heads, dim_head=attn_dim_head, img_size=size,
+                             depth=depth, forward_drop_p=att_forward_drop, drop_p=att_drop,
+                             forward_expansion=att_forward_expansion, reduction=False, local=att_localvit, groups=groups)
             return klass(dim=d, depth=depth, heads=heads, dim_head=attn_dim_head, ff_mult=att_forward_expansion,
                          patch_size=patch_size, img_size=size, patch=True, groups=groups)
 

@@ -83,6 +83,22 @@ def test_unet_attention_variants_match_reference_golden(kind):
             close(named[k[5:]].grad, T(g[k]), 2e-3, k)
 
 
+@pytest.mark.parametrize('tag', ['local', 'mlp'])
+def test_unet_vit3d_attention_matches_reference_golden(tag):
+    g = load_golden(f'unetA_attn_vit_{tag}')
+    unet, sd, cfg = build(g, 3)
+    assert list(unet.state_dict().keys()) == [str(k) for k in g['keys']], "ViT3D state_dict keys/order differ from the reference"
+    unet.eval()
+    y = unet(T(g['x']).to(DEV), T(g['times']).to(DEV), T(g['log_snr']).to(DEV), lowres_cond_img=T(g['lowres']).to(DEV))
+    rel = close(y, T(g['y']), 3e-4, "vit unet fwd vs reference")
+    assert rel <= 5e-5, rel
+    (y ** 2).mean().backward()
+    named = dict(unet.named_parameters())
+    for k in g:
+        if k.startswith('grad:'):
+            close(named[k[5:]].grad, T(g[k]), 2e-3, k)
+
+
 def test_unet_memory_efficient_cross_embed_and_boundary_match_reference_golden():
     for name, seed in (('unetA_memeff', 2), ('unetA_boundary', 3)):
         g = load_golden(name)

@@ -92,6 +92,25 @@ def test_unet_attention_variants(kind):
             assert (got - ref).abs().max().item() <= 5e-4 * scale + 1e-7, k
 
 
+@pytest.mark.parametrize('tag', ['local', 'mlp'])
+def test_unet_vit3d_attention(tag):
+    """att_type='vit' (ViT3D, imagen_pytorch3D.py:871-910), local (conv) and MLP feed-forward."""
+    g = load_golden(f'unetA_attn_vit_{tag}')
+    sd = build_sd(g, seed=3)
+    cfg = cfg_of(g)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y = O.unet_forward(sdg, cfg, T(g['x']), T(g['times']), T(g['log_snr']), lowres_cond_img=T(g['lowres']))
+    assert torch.allclose(y, T(g['y']), atol=5e-5, rtol=1e-4)
+    (y ** 2).mean().backward()
+    for k in g:
+        if k.startswith('grad:'):
+            # FeedForwardBlock registers its sub-modules twice (own name + `net`): the tensor in effect is the `net.*` entry
+            name = k[5:].replace('.up_proj.1.', '.net.0.1.')
+            ref, got = T(g[k]), sdg[name].grad
+            scale = ref.abs().max().item() + 1e-12
+            assert (got - ref).abs().max().item() <= 5e-4 * scale + 1e-7, k
+
+
 def test_unet_memory_efficient_cross_embed_and_boundary():
     g = load_golden('unetA_memeff')
     sd, cfg = build_sd(g, seed=2), cfg_of(g)

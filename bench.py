@@ -165,6 +165,24 @@ def main():
                         flops_per_launch=round(flops / n / 1e9, 3), flops_unit="GFLOP (algorithmic, 2*MAC) per average launch")
         assert torch.isfinite(state["img"]).all()
 
+    # ---------------- EDM (Karras) stochastic Heun sampler on the same U-Net: one call of ElucidatedImagen.sample with
+    #                  n = max(4, K // 2) steps = 2n - 1 U-Net evals (elucidated_imagen.py:382-532); reported beside the headline ----
+    if args.mode in ("sample", "both"):
+        from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
+        n_edm = max(4, K // 2)
+        elu = ElucidatedImagen(unets=(NullUnet(), unet), image_sizes=(S, S), channels=1, condition_on_text=False,
+                               auto_normalize_img=False, cond_drop_prob=0.0, num_sample_steps=n_edm,
+                               dynamic_thresholding=False).to(device)
+        unet.eval()
+
+        def edm_sample():
+            elu.sample(batch_size=B, video_frames=S, start_image_or_video=lr.clamp(-1, 1), start_at_unet_number=2, use_tqdm=False)
+
+        dt = timed(edm_sample, 1, 1)
+        result["edm"] = dict(heun_steps=n_edm, unet_evals=2 * n_edm - 1, ms_per_heun_step=1e3 * dt / n_edm,
+                             heun_steps_per_s=n_edm / dt, patch_steps_per_s=world * B * n_edm / dt,
+                             patch_evals_per_s=world * B * (2 * n_edm - 1) / dt)
+
     # ---------------- training: K micro-steps through ImagenTrainer.forward ----------------
     if args.mode in ("train", "both"):
         trainer.training = True
@@ -235,6 +253,9 @@ def main():
             out["train"]["note"] = "ImagenTrainer.forward micro-step: fwd+bwd (558 GFLOP/patch), grad all-reduce + fused Adam every 4th, EMA"
         if "sample" in result:
             out["sample_steps_per_s"] = round(1e3 / result["sample"]["ms_per_step"], 3)
+        if "edm" in result:
+            out["edm"] = {k: round(v, 3) for k, v in result["edm"].items()}
+            out["edm"]["note"] = "ElucidatedImagen.sample (stochastic Heun, 2 U-Net evals per step except the last) driving the same C2 U-Net"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -460,6 +460,17 @@ struct IdentF {
     }
     __device__ void scalar(size_t i, int, int, float (&o)[1]) const { o[0] = x[i]; }
 };
+struct WeightedF {      // x[b][row][c] * w[b][row]  (GlobalContext pooling, imagen_video.py:975-979)
+    const float *x, *w;
+    int C;
+    __device__ void prep(int, int) {}
+    __device__ void vec4(size_t i, int, int, float (&o)[1][4]) const {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        const float ww = w[i / C];
+        o[0][0] = v.x * ww; o[0][1] = v.y * ww; o[0][2] = v.z * ww; o[0][3] = v.w * ww;
+    }
+    __device__ void scalar(size_t i, int, int, float (&o)[1]) const { o[0] = x[i] * w[i / C]; }
+};
 struct ProdF {
     const float *a, *b;
     __device__ void prep(int, int) {}
@@ -1390,6 +1401,14 @@ extern "C" int diqt_channel_mean(const float* x, float* pooled, void* workspace,
     DIQT_REQUIRE(B > 0 && rows > 0 && C > 0, DIQT_E_SHAPE, "channel_mean: bad shape");
     DIQT_REQUIRE(C % 4 != 0 || aligned16(x), DIQT_E_ALIGN, "channel_mean: misaligned x");
     return colreduce1(IdentF{x}, pooled, 1.f / rows, workspace, workspace_bytes, B, rows, C, stream, "channel_mean");
+}
+
+extern "C" int diqt_weighted_colsum(const float* x, const float* w, float* out, void* workspace, size_t workspace_bytes,
+                                    int B, int rows, int C, void* stream) {
+    DIQT_REQUIRE(x && w && out, DIQT_E_ALIGN, "weighted_colsum: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0, DIQT_E_SHAPE, "weighted_colsum: bad shape");
+    DIQT_REQUIRE(C % 4 != 0 || aligned16(x), DIQT_E_ALIGN, "weighted_colsum: misaligned x");
+    return colreduce1(WeightedF{x, w, C}, out, 1.f, workspace, workspace_bytes, B, rows, C, stream, "weighted_colsum");
 }
 
 extern "C" int diqt_gate_residual_fwd(const float* h, const float* gate, const float* res, const float* addc,

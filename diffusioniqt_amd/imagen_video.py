@@ -272,7 +272,7 @@ class GlobalContext(nn.Module):
         n = x.numel() // (B * C)
         ctx = self.to_k(x).reshape(B, n)
         p = ops.softmax(ctx, dim=-1)                                              # over all (f h w) positions
-        pooled = ops.bmm(p.reshape(B, 1, n), x.reshape(B, n, C))                  # [B, 1, C]
+        pooled = ops.weighted_pool(p, x.reshape(B, n, C))                         # [B, C] = softmax(ctx) . x
         return self.net(pooled.reshape(B, 1, 1, 1, C)).reshape(B, -1)
 
 

@@ -749,6 +749,37 @@ class _BmmFn(Function):
         return dA, dB, None, None, None
 
 
+class _WeightedPoolFn(Function):
+    """out[b, c] = sum_n w[b, n] x[b, n, c] (GlobalContext pooling): one column-reduction pass over x instead of a
+    1-row GEMM with K = n; the gradients are two thin GEMMs (dw = x dout, dx = w (x) dout)."""
+    @staticmethod
+    def forward(ctx, w, x):
+        _chk(w, x)
+        B, n, C = x.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        ws, nws = _reduce_ws(B, C, x.device)
+        _lib.call("diqt_weighted_colsum", x, w, out, ws, nws, B, n, C, _stream())
+        ctx.save_for_backward(w, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w, x = ctx.saved_tensors
+        B, n, C = x.shape
+        dout = dout.contiguous()
+        dw = dx = None
+        if ctx.needs_input_grad[0]:
+            dw = _bgemm_raw(x, dout.reshape(B, C, 1), False, False).reshape(B, n)
+        if ctx.needs_input_grad[1]:
+            dx = _bgemm_raw(w.reshape(B, n, 1), dout.reshape(B, 1, C), False, False)
+        return dw, dx
+
+
+def weighted_pool(w, x):
+    """w: [B, n] weights, x: [B, n, C] -> [B, C]"""
+    return _WeightedPoolFn.apply(w.contiguous(), x.contiguous())
+
+
 def bmm(A, Bm, transA=False, transB=False, alpha=1.0):
     return _BmmFn.apply(A.contiguous(), Bm.contiguous(), bool(transA), bool(transB), float(alpha))
 

@@ -171,6 +171,11 @@ int diqt_learned_sinu_bwd(const float* t, const float* w, const float* dout, flo
 /* pooled[b][c] = mean over rows_per_batch of x[b][.][c]  (AdaptiveAvgPool3d(1) :620,630) */
 int diqt_channel_mean(const float* x, float* pooled, void* workspace, size_t workspace_bytes,
                       int B, int rows_per_batch, int C, void* stream);
+/* out[b][c] = sum_rows w[b][row] * x[b][row][c] — the attention-weighted pooling of GlobalContext
+ * (imagen_video.py:975-979: einsum('b i n, b c n -> b c i', softmax(context), x)); workspace: diqt_reduce_workspace_bytes(B, C). */
+int diqt_weighted_colsum(const float* x, const float* w, float* out, void* workspace, size_t workspace_bytes,
+                         int B, int rows, int C, void* stream);
+
 /* y = h*gate[b][c] + res + alpha*addc[b][c]   (res, addc may be NULL).  The same entry yields the
  * backward dh = dy*gate + (1/rows)*dpooled[b][c] of the gate AND of the mean pool in one pass.        */
 int diqt_gate_residual_fwd(const float* h, const float* gate, const float* res, const float* addc, float alpha,

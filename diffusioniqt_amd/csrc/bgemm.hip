@@ -3,6 +3,7 @@
 // 32x32), K staged 16 at a time through LDS in k-major order so both MFMA operands are conflict-free
 // ds_read_b32.  General strides / transposes; edges are zero-filled.
 #include "common.h"
+#include <stdlib.h>
 
 namespace diqt {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -66,6 +67,145 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A,
         }
     }
 }
+// ---------------------------------------------------------------------------------------------
+// version 2 (M > 64): 128 x 64 tile per 256-thread workgroup, each wave 32 rows x 64 columns (2 accumulators), K staged 32
+// at a time in the conv kernel's LDS image (36-float padded rows, k-contiguous) so both operands are ds_read_b128
+// fragments; the next K-chunk is fetched global -> registers while the current one's 32 MFMAs per wave run.
+// ---------------------------------------------------------------------------------------------
+constexpr int G2M = 128, G2N = 64, G2K = 32, G2ROW = 36;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void bgemm2_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                        float* __restrict__ C, int M, int N, int K, long long sA, long long sB,
+                                                        long long sC, int lda, int ldb, int ldc, float alpha, float beta) {
+    __shared__ __attribute__((aligned(16))) float As[G2M * G2ROW];
+    __shared__ __attribute__((aligned(16))) float Bs[G2N * G2ROW];
+    const int g = blockIdx.z;
+    const float* Ag = A + (size_t)g * sA;
+    const float* Bg = Bm + (size_t)g * sB;
+    float* Cg = C + (size_t)g * sC;
+    const int m0 = blockIdx.y * G2M, n0 = blockIdx.x * G2N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const bool vecA = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(Ag) & 15u) == 0);
+    const bool vecB = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(Bg) & 15u) == 0);
+
+    // staging pieces: A = 128 x 32 floats = 1024 float4 (4 per thread), B = 64 x 32 = 512 float4 (2 per thread).
+    // non-transposed operand (k contiguous): piece e -> row e/8, k4 = (e%8)*4.  transposed (row index contiguous in memory):
+    // piece e -> k = e / (rows/4), r4 = (e % (rows/4)) * 4, scattered into 4 LDS rows.
+    float4 ra[4], rb[2];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!TA) {
+                const int m = m0 + (e >> 3), k = k0 + (e & 7) * 4;
+                if (m < M) {
+                    const float* p = Ag + (size_t)m * lda + k;
+                    if (vecA && k + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                    else { if (k < K) v.x = p[0]; if (k + 1 < K) v.y = p[1]; if (k + 2 < K) v.z = p[2]; if (k + 3 < K) v.w = p[3]; }
+                }
+            } else {
+                const int k = k0 + (e >> 5), m = m0 + (e & 31) * 4;
+                if (k < K) {
+                    const float* p = Ag + (size_t)k * lda + m;
+                    if (vecA && m + 3 < M) v = *reinterpret_cast<const float4*>(p);
+                    else { if (m < M) v.x = p[0]; if (m + 1 < M) v.y = p[1]; if (m + 2 < M) v.z = p[2]; if (m + 3 < M) v.w = p[3]; }
+                }
+            }
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TB) {
+                const int n = n0 + (e >> 3), k = k0 + (e & 7) * 4;
+                if (n < N) {
+                    const float* p = Bg + (size_t)n * ldb + k;
+                    if (vecB && k + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                    else { if (k < K) v.x = p[0]; if (k + 1 < K) v.y = p[1]; if (k + 2 < K) v.z = p[2]; if (k + 3 < K) v.w = p[3]; }
+                }
+            } else {
+                const int k = k0 + (e >> 4), n = n0 + (e & 15) * 4;
+                if (k < K) {
+                    const float* p = Bg + (size_t)k * ldb + n;
+                    if (vecB && n + 3 < N) v = *reinterpret_cast<const float4*>(p);
+                    else { if (n < N) v.x = p[0]; if (n + 1 < N) v.y = p[1]; if (n + 2 < N) v.z = p[2]; if (n + 3 < N) v.w = p[3]; }
+                }
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            if (!TA) *reinterpret_cast<float4*>(As + (e >> 3) * G2ROW + (e & 7) * 4) = ra[u];
+            else {
+                const int k = e >> 5, m = (e & 31) * 4;
+                As[(m + 0) * G2ROW + k] = ra[u].x; As[(m + 1) * G2ROW + k] = ra[u].y;
+                As[(m + 2) * G2ROW + k] = ra[u].z; As[(m + 3) * G2ROW + k] = ra[u].w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            if (TB) *reinterpret_cast<float4*>(Bs + (e >> 3) * G2ROW + (e & 7) * 4) = rb[u];
+            else {
+                const int k = e >> 4, n = (e & 15) * 4;
+                Bs[(n + 0) * G2ROW + k] = rb[u].x; Bs[(n + 1) * G2ROW + k] = rb[u].y;
+                Bs[(n + 2) * G2ROW + k] = rb[u].z; Bs[(n + 3) * G2ROW + k] = rb[u].w;
+            }
+        }
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    load_chunk(0);
+    for (int k0 = 0; k0 < K; k0 += G2K) {
+        __syncthreads();                 // the previous chunk's fragment reads are done
+        store_chunk();
+        __syncthreads();
+        if (k0 + G2K < K) load_chunk(k0 + G2K);
+        const float* ap = As + (wave * 32 + l31) * G2ROW + 4 * h;
+        const float* bp = Bs + l31 * G2ROW + 4 * h;
+        float4 a = *reinterpret_cast<const float4*>(ap);
+        float4 b0 = *reinterpret_cast<const float4*>(bp);
+        float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * G2ROW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 an, b0n, b1n;
+            if (q < 3) {
+                an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+                b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+                b1n = *reinterpret_cast<const float4*>(bp + 32 * G2ROW + 8 * (q + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+            if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
+        }
+    }
+    // D[row][col]: col = lane & 31 (+32 for acc1), row = (r&3) + 8*(r>>2) + 4*h
+    const int c0 = n0 + l31, c1 = n0 + 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= M) continue;
+        float* dst = Cg + (size_t)row * ldc;
+        if (c0 < N) { float v = alpha * acc0[r]; if (beta != 0.f) v += beta * dst[c0]; dst[c0] = v; }
+        if (c1 < N) { float v = alpha * acc1[r]; if (beta != 0.f) v += beta * dst[c1]; dst[c1] = v; }
+    }
+}
 }  // namespace diqt
 
 using namespace diqt;
@@ -75,6 +215,17 @@ extern "C" int diqt_bgemm(const float* A, const float* Bm, float* C, int batch, 
     DIQT_REQUIRE(A && Bm && C, DIQT_E_ALIGN, "bgemm: null pointer");
     DIQT_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc > 0, DIQT_E_SHAPE, "bgemm: bad shape");
     DIQT_REQUIRE(batch <= 65535, DIQT_E_SHAPE, "bgemm: batch > 65535");
+    static const bool v1 = [] { const char* e = getenv("DIQT_BGEMM_V1"); return e && e[0] == '1'; }();
+    if (M > 64 && !v1) {
+        const dim3 grid2((N + G2N - 1) / G2N, (M + G2M - 1) / G2M, batch);
+        DIQT_REQUIRE(grid2.y <= 65535, DIQT_E_SHAPE, "bgemm: M too large");
+        void (*k2)(const float*, const float*, float*, int, int, int, long long, long long, long long, int, int, int, float, float) =
+            transA ? (transB ? bgemm2_kernel<true, true> : bgemm2_kernel<true, false>)
+                   : (transB ? bgemm2_kernel<false, true> : bgemm2_kernel<false, false>);
+        hipLaunchKernelGGL(k2, grid2, dim3(256), 0, (hipStream_t)stream, A, Bm, C, M, N, K, strideA, strideB, strideC, lda, ldb,
+                           ldc, alpha, beta);
+        return check_launch("bgemm(v2)");
+    }
     const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, batch);
     hipLaunchKernelGGL(bgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, Bm, C, M, N, K, transA, transB, strideA,
                        strideB, strideC, lda, ldb, ldc, alpha, beta);

@@ -348,6 +348,44 @@ def test_diffusion_steps_loss_adam(ops):
     close(ed, e + (wr.detach() - e) * 0.25, tol=1e-5, what="ema")
 
 
+@pytest.mark.parametrize("g_,M,N,K", [(2, 300, 70, 45), (3, 129, 33, 64), (1, 1024, 2053, 64), (2, 513, 64, 2049), (4, 256, 64, 33)])
+def test_bgemm_large_tiles_all_layouts(ops, g_, M, N, K):
+    """128x64-tile batched GEMM (attention QK^T / PV shapes, odd extents, 16-byte aligned and unaligned leading dims)."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    A, Bm = torch.randn(g_, M, K, generator=gen), torch.randn(g_, K, N, generator=gen)
+    ref = torch.bmm(A.double(), Bm.double())
+    for tA in (False, True):
+        for tB in (False, True):
+            Ain = (A.transpose(1, 2).contiguous() if tA else A).to(DEV).requires_grad_()
+            Bin = (Bm.transpose(1, 2).contiguous() if tB else Bm).to(DEV).requires_grad_()
+            C = ops.bmm(Ain, Bin, tA, tB, 1.0)
+            close(C, ref, tol=3e-5, what=f"bgemm {tA}{tB} {M}x{N}x{K}")
+    dC = torch.randn(g_, M, N, generator=gen)
+    Ar, Br = A.double().requires_grad_(), Bm.double().requires_grad_()
+    torch.bmm(Ar, Br).backward(dC.double())
+    Ad, Bd = A.to(DEV).requires_grad_(), Bm.to(DEV).requires_grad_()
+    ops.bmm(Ad, Bd, False, False, 1.0).backward(dC.to(DEV))
+    close(Ad.grad, Ar.grad, tol=1e-4, what="bgemm dA")
+    close(Bd.grad, Br.grad, tol=1e-4, what="bgemm dB")
+
+
+def test_weighted_pool_global_context(ops):
+    """GlobalContext pooling (imagen_video.py:975-979): out[b,c] = sum_n softmax(ctx)[b,n] x[b,n,c]."""
+    gen = torch.Generator().manual_seed(21)
+    for (B, n, C) in ((2, 4096, 64), (3, 777, 20), (1, 32768, 128)):
+        w = torch.softmax(torch.randn(B, n, generator=gen), dim=-1)
+        x = torch.randn(B, n, C, generator=gen)
+        up = torch.randn(B, C, generator=gen)
+        wr, xr = w.double().requires_grad_(), x.double().requires_grad_()
+        torch.einsum('bn,bnc->bc', wr, xr).backward(up.double())
+        wd, xd = w.to(DEV).requires_grad_(), x.to(DEV).requires_grad_()
+        out = ops.weighted_pool(wd, xd)
+        close(out, torch.einsum('bn,bnc->bc', w.double(), x.double()), tol=3e-5, what="weighted pool")
+        out.backward(up.to(DEV))
+        close(wd.grad, wr.grad, tol=1e-4, what="weighted pool dw")
+        close(xd.grad, xr.grad, tol=1e-4, what="weighted pool dx")
+
+
 def test_multi_accumulate_matches_per_tensor_adds(ops):
     """Gradient accumulation into the flat arena: one launch == the per-parameter `grad += new` adds (bit-exact)."""
     g = torch.Generator().manual_seed(11)

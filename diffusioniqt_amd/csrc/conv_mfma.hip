@@ -345,6 +345,150 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward for Cin <= 4 (the init convs: 2 -> 64 3x3x3 of Family A, the (1,k,k) cross-embed convs of Family B): the GEMM K
+// axis is (tap, ci) packed densely -- K = taps * CINP in chunks of 32 -- instead of one 32-wide (mostly zero) channel chunk
+// per tap: 13.5x fewer MFMAs for 3x3x3 x 2 channels.  Per chunk an im2col tile As[128 voxels][32 k] is gathered from the
+// compact halo image in LDS through a 32-entry offset table, then the usual b128-fragment MFMA loop runs on it.
+// packed weights (conv_pack_smallcin_kernel): [chunk][co padded to 64][32 k],  k = tap * CINP + ci.
+// ---------------------------------------------------------------------------------------------
+// mode 0: effective (out, in) = (Cout, Cin), value w[o][i][tap];  mode 1 (backward-data of a conv with <= 4 OUTPUT channels):
+// effective (out, in) = (Cin, Cout), value w[i][o][T-1-tap]
+__global__ void conv_pack_smallcin_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int T,
+                                          int CINP, int CoutPadEff, int mode, size_t total) {
+    const int outEff = mode == 0 ? Cout : Cin, inEff = mode == 0 ? Cin : Cout;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % CK);
+        size_t r = i / CK;
+        const int o = (int)(r % CoutPadEff);
+        const int chunk = (int)(r / CoutPadEff);
+        const int k = chunk * CK + kk, tap = k / CINP, in = k % CINP;
+        float v = 0.f;
+        if (o < outEff && tap < T && in < inEff)
+            v = mode == 0 ? w[((size_t)o * Cin + in) * T + tap] : w[((size_t)in * Cin + o) * T + (T - 1 - tap)];
+        packed[i] = v;
+    }
+}
+
+template <int CINP>
+__global__ __launch_bounds__(256, 2) void conv_fwd_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ residual, float* __restrict__ y,
+                                                                   ConvGeom g, int nCh) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HV = g.HD * g.HH * g.HWd;
+    const int haloElems = (HV * CINP + 3) & ~3;
+    float* halo = smem;                                  // [HV][CINP]
+    float* As = smem + haloElems;                        // [128][36]
+    float* wbuf = As + MTILE * LDSROW;                   // [64][36]
+    int* out_off = reinterpret_cast<int*>(wbuf + NT * LDSROW);      // [128]
+    int* koff = out_off + MTILE;                                     // [32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = L % g.nNt;
+    int mt = L / g.nNt;
+    const int tx = mt % g.tilesW; mt /= g.tilesW;
+    const int ty = mt % g.tilesH; mt /= g.tilesH;
+    const int tz = mt % g.tilesD;
+    const int b = mt / g.tilesD;
+    const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
+    const int n0 = nt * NT;
+    const int T = g.kd * g.kh * g.kw;
+
+    if (tid < MTILE) {
+        const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
+        const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+        out_off[tid] = (od < g.Do && oh < g.Ho && ow < g.Wo) ? ((b * g.Do + od) * g.Ho + oh) * g.Wo + ow : -1;
+    }
+    for (int e = tid; e < HV * CINP; e += 256) {         // compact halo image, zero padded
+        const int hv = e / CINP, ci = e % CINP;
+        const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+        const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+        float v = 0.f;
+        if (ci < g.Cin && iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+            v = x[(size_t)(((b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin + ci];
+        halo[e] = v;
+    }
+    // the voxel this thread gathers for the im2col tile (rows 0..127, two 16-wide k halves)
+    const int gv = tid & (MTILE - 1), ghalf = tid >> 7;
+    const int gbase = (((gv / (g.TW * g.TH)) * g.HH + (gv / g.TW) % g.TH) * g.HWd + gv % g.TW) * CINP;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const int wrow = tid >> 3, wc4 = (tid & 7) * 4;
+    for (int chunk = 0; chunk < nCh; ++chunk) {
+        __syncthreads();                                 // previous chunk's fragment reads (and the halo stores) are done
+        if (tid < CK) {
+            const int k = chunk * CK + tid, tap = k / CINP, ci = k % CINP;
+            int o = -1;
+            if (tap < T) {
+                const int kx = tap % g.kw, ky = (tap / g.kw) % g.kh, kz = tap / (g.kw * g.kh);
+                o = ((kz * g.HH + ky) * g.HWd + kx) * CINP + ci;
+            }
+            koff[tid] = o;
+        }
+        {
+            const float* wc = wp + ((size_t)chunk * g.CoutPad + n0) * CK;
+            *reinterpret_cast<float4*>(wbuf + wrow * LDSROW + wc4) = *reinterpret_cast<const float4*>(wc + (size_t)wrow * CK + wc4);
+            *reinterpret_cast<float4*>(wbuf + (wrow + 32) * LDSROW + wc4) =
+                *reinterpret_cast<const float4*>(wc + (size_t)(wrow + 32) * CK + wc4);
+        }
+        __syncthreads();
+        {
+            float v[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int o = koff[ghalf * 16 + kk];
+                v[kk] = halo[gbase + (o < 0 ? 0 : o)];                   // unconditional read, select afterwards
+                v[kk] = o < 0 ? 0.f : v[kk];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(As + gv * LDSROW + ghalf * 16 + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+        }
+        __syncthreads();
+        const float* ap = As + (wave * 32 + l31) * LDSROW + 4 * h;
+        const float* bp = wbuf + l31 * LDSROW + 4 * h;
+        float4 a = *reinterpret_cast<const float4*>(ap);
+        float4 b0 = *reinterpret_cast<const float4*>(bp);
+        float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 an, b0n, b1n;
+            if (q < 3) {
+                an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+                b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+                b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+            if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
+        }
+    }
+    const int co0 = n0 + l31, co1 = n0 + 32 + l31;
+    const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
+    const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int off = out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        if (off < 0) continue;
+        const size_t o = (size_t)off * g.Cout;
+        if (co0 < g.Cout) { float v = acc0[r] + bias0; if (residual) v += residual[o + co0]; y[o + co0] = v; }
+        if (co1 < g.Cout) { float v = acc1[r] + bias1; if (residual) v += residual[o + co1]; y[o + co1] = v; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // persistent forward / backward-data kernel (the default): <= 2 workgroups per CU walk the tile list of
 // "their" XCD; the halo chunk of the NEXT (tile, chunk) item is fetched global -> registers while the
 // current item's 27 x 32 MFMAs run and is written to LDS at the item boundary (async-stage split), so HBM
@@ -1175,12 +1319,26 @@ extern "C" long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, 
     return (long long)(((size_t)g.HD * g.HH * g.HWd * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int));
 }
 
+// forward convs with <= 4 input channels and more than one tap use the tap-packed kernel (and its weight packing)
+static inline int smallcin_pad(int Cin, int T) {
+    static const bool off = [] { const char* e = getenv("DIQT_CONV_NOSMALLCIN"); return e && e[0] == '1'; }();
+    if (off || Cin > 4 || T < 2) return 0;
+    return Cin == 3 ? 4 : Cin;
+}
+
 extern "C" int diqt_conv_pack_weight(const float* w, float* packed, int Cout, int Cin, int kd, int kh, int kw,
                                      int mode, void* stream) {
     DIQT_REQUIRE(w && packed, DIQT_E_ALIGN, "conv_pack_weight: null pointer");
     DIQT_REQUIRE(Cout > 0 && Cin > 0 && kd > 0 && kh > 0 && kw > 0 && (mode == 0 || mode == 1), DIQT_E_SHAPE,
                  "conv_pack_weight: bad shape/mode");
     const int T = kd * kh * kw;
+    if (const int CINP = smallcin_pad(mode == 0 ? Cin : Cout, T)) {
+        const int CoutPadE = cdiv(mode == 0 ? Cout : Cin, NT) * NT, nCh = cdiv(T * CINP, CK);
+        const size_t total = (size_t)nCh * CoutPadE * CK;
+        hipLaunchKernelGGL(conv_pack_smallcin_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed,
+                           Cout, Cin, T, CINP, CoutPadE, mode, total);
+        return check_launch("conv_pack_weight(small Cin)");
+    }
     const int outEff = mode == 0 ? Cout : Cin, inEff = mode == 0 ? Cin : Cout;
     const int CoutPadEff = cdiv(outEff, NT) * NT, nChunksEff = cdiv(inEff, CK);
     const size_t total = (size_t)nChunksEff * T * CoutPadEff * CK;
@@ -1255,6 +1413,22 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
     const bool vec4 = (Cin % 4 == 0) && aligned16(x);
     const int HV = g.HD * g.HH * g.HWd;
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
+    if (const int CINP = smallcin_pad(Cin, kd * kh * kw)) {
+        const int nCh = cdiv(kd * kh * kw * CINP, CK);
+        const size_t slds = ((size_t)((HV * CINP + 3) & ~3) + (size_t)MTILE * LDSROW + (size_t)NT * LDSROW) * sizeof(float) +
+                            (MTILE + CK) * sizeof(int);
+        if (slds <= 80 * 1024) {
+            void (*ks)(const float*, const float*, const float*, const float*, float*, ConvGeom, int) =
+                CINP == 1 ? conv_fwd_smallcin_kernel<1> : (CINP == 2 ? conv_fwd_smallcin_kernel<2> : conv_fwd_smallcin_kernel<4>);
+            if (slds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+                DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            }
+            hipLaunchKernelGGL(ks, dim3(nwg), dim3(256), slds, (hipStream_t)stream, x, packed, bias, residual, y, g, nCh);
+            return check_launch("conv3d_fwd(small Cin)");
+        }
+        DIQT_REQUIRE(false, DIQT_E_UNSUPPORTED, "conv3d_fwd: small-Cin halo needs %zu B of LDS", slds);
+    }
     // opt-in: measured equal to the one-tile-per-workgroup kernel on MI355X (118 vs 121 TFLOP/s, profiles/r01_conv_ablation.md)
     static const bool persist_ok = [] { const char* e = getenv("DIQT_CONV_PERSIST"); return e && e[0] == '1'; }();
     const bool k333 = kd == 3 && kh == 3 && kw == 3, k133 = kd == 1 && kh == 3 && kw == 3;

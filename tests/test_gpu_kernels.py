@@ -55,6 +55,11 @@ CONV_CASES = [
     (2, (6, 8, 8), 32, 32, (1, 3, 3), (0, 1, 1)),          # pseudo-3D spatial conv
     (2, (6, 8, 8), 8, 40, (1, 7, 7), (0, 3, 3)),           # cross-embed (1,7,7)
     (2, (5, 1, 1), 33, 7, (3, 1, 1), (1, 0, 0)),           # temporal conv, odd channels
+    (2, (6, 16, 16), 2, 16, (1, 15, 15), (0, 7, 7)),       # Family-B cross-embed (1,15,15) on 2 channels: tap-packed K (15 chunks)
+    (2, (9, 10, 12), 1, 20, (3, 3, 3), (1, 1, 1)),         # Cin = 1, ragged extents (tap-packed, 1 chunk)
+    (1, (8, 8, 8), 3, 70, (3, 3, 3), (1, 1, 1)),           # Cin = 3 padded to 4, two N tiles
+    (2, (8, 8, 8), 24, 2, (3, 3, 3), (1, 1, 1)),           # Cout = 2: the backward-data pass is a tap-packed conv
+    (1, (6, 8, 8), 4, 8, (1, 7, 7), (0, 3, 3)),            # Cin = 4 (1,7,7)
 ]
 
 

@@ -78,8 +78,11 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void bgemm2_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                         float* __restrict__ C, int M, int N, int K, long long sA, long long sB,
                                                         long long sC, int lda, int ldb, int ldc, float alpha, float beta) {
-    __shared__ __attribute__((aligned(16))) float As[G2M * G2ROW];
-    __shared__ __attribute__((aligned(16))) float Bs[G2N * G2ROW];
+    // operand images: k-contiguous rows [row][36] for an operand whose K axis is contiguous in memory (b128 fragments), k-major
+    // [k][rows + 4] for a transposed one (its rows are contiguous in memory: 16-byte LDS writes, conflict-free b32 fragments)
+    constexpr int AT = G2M + 4, BT = G2N + 4;
+    __shared__ __attribute__((aligned(16))) float As[TA ? G2K * AT : G2M * G2ROW];
+    __shared__ __attribute__((aligned(16))) float Bs[TB ? G2N * G2ROW : G2K * BT];
     const int g = blockIdx.z;
     const float* Ag = A + (size_t)g * sA;
     const float* Bg = Bm + (size_t)g * sB;
@@ -143,21 +146,13 @@ __global__ __launch_bounds__(256, 2) void bgemm2_kernel(const float* __restrict_
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 256 * u;
             if (!TA) *reinterpret_cast<float4*>(As + (e >> 3) * G2ROW + (e & 7) * 4) = ra[u];
-            else {
-                const int k = e >> 5, m = (e & 31) * 4;
-                As[(m + 0) * G2ROW + k] = ra[u].x; As[(m + 1) * G2ROW + k] = ra[u].y;
-                As[(m + 2) * G2ROW + k] = ra[u].z; As[(m + 3) * G2ROW + k] = ra[u].w;
-            }
+            else *reinterpret_cast<float4*>(As + (e >> 5) * AT + (e & 31) * 4) = ra[u];
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u;
             if (TB) *reinterpret_cast<float4*>(Bs + (e >> 3) * G2ROW + (e & 7) * 4) = rb[u];
-            else {
-                const int k = e >> 4, n = (e & 15) * 4;
-                Bs[(n + 0) * G2ROW + k] = rb[u].x; Bs[(n + 1) * G2ROW + k] = rb[u].y;
-                Bs[(n + 2) * G2ROW + k] = rb[u].z; Bs[(n + 3) * G2ROW + k] = rb[u].w;
-            }
+            else *reinterpret_cast<float4*>(Bs + (e >> 4) * BT + (e & 15) * 4) = rb[u];
         }
     };
 
@@ -170,19 +165,22 @@ __global__ __launch_bounds__(256, 2) void bgemm2_kernel(const float* __restrict_
         store_chunk();
         __syncthreads();
         if (k0 + G2K < K) load_chunk(k0 + G2K);
-        const float* ap = As + (wave * 32 + l31) * G2ROW + 4 * h;
-        const float* bp = Bs + l31 * G2ROW + 4 * h;
-        float4 a = *reinterpret_cast<const float4*>(ap);
-        float4 b0 = *reinterpret_cast<const float4*>(bp);
-        float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * G2ROW);
+        // fragment of k-group q: lane half h supplies k = 8q + 4h + j to the j-th MFMA pair
+        auto frag_a = [&](int q) -> float4 {
+            if (!TA) return *reinterpret_cast<const float4*>(As + (wave * 32 + l31) * G2ROW + 4 * h + 8 * q);
+            const float* p = As + (8 * q + 4 * h) * AT + wave * 32 + l31;
+            return make_float4(p[0], p[AT], p[2 * AT], p[3 * AT]);
+        };
+        auto frag_b = [&](int q, int half) -> float4 {
+            if (TB) return *reinterpret_cast<const float4*>(Bs + (half * 32 + l31) * G2ROW + 4 * h + 8 * q);
+            const float* p = Bs + (8 * q + 4 * h) * BT + half * 32 + l31;
+            return make_float4(p[0], p[BT], p[2 * BT], p[3 * BT]);
+        };
+        float4 a = frag_a(0), b0 = frag_b(0, 0), b1 = frag_b(0, 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 an, b0n, b1n;
-            if (q < 3) {
-                an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
-                b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
-                b1n = *reinterpret_cast<const float4*>(bp + 32 * G2ROW + 8 * (q + 1));
-            }
+            if (q < 3) { an = frag_a(q + 1); b0n = frag_b(q + 1, 0); b1n = frag_b(q + 1, 1); }
             __builtin_amdgcn_sched_barrier(0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);

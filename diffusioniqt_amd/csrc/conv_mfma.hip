@@ -1558,6 +1558,59 @@ static bool bw2_plan(const ConvGeom& g, BwGeom2& b2, bool& splitCo, int& ksplit,
     return lds <= 160 * 1024;
 }
 
+// ---- 1x1x1 filters: dW = dY^T X is a plain GEMM with K = all voxels.  It runs on the batched GEMM (bgemm.hip) with the
+//      K axis cut into `ks` slices mapped to the batch index (one output slab per slice) + a fixed-order slab sum. ----
+extern "C" int diqt_bgemm(const float* A, const float* Bm, float* C, int batch, int M, int N, int K, int transA, int transB,
+                          long long strideA, long long strideB, long long strideC, int lda, int ldb, int ldc, float alpha,
+                          float beta, void* stream);
+
+struct PwPlan { bool ok; long long V; int ks; bool xFirst; int M, N; };
+static PwPlan pw_plan(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd,
+                      int eph, int epw) {
+    static const bool off = [] { const char* e = getenv("DIQT_BWDW_NOGEMM"); return e && e[0] == '1'; }();
+    PwPlan p{};
+    p.ok = !off && kd == 1 && kh == 1 && kw == 1 && pd == 0 && ph == 0 && pw == 0 && epd == 0 && eph == 0 && epw == 0;
+    if (!p.ok) return p;
+    p.V = (long long)B * D * H * W;
+    p.xFirst = Cin >= Cout;                      // the larger channel count takes the 128-row side of the tile
+    p.M = p.xFirst ? Cin : Cout; p.N = p.xFirst ? Cout : Cin;
+    if (p.M <= 64 || p.V < 4096) { p.ok = false; return p; }      // small problems stay on the conv kernel
+    const int tiles = cdiv(p.M, 128) * cdiv(p.N, 64);
+    int ks = 1;
+    while (ks * 2 * tiles <= 256 && p.V % (ks * 2) == 0 && p.V / (ks * 2) >= 256) ks *= 2;      // one workgroup per CU
+    p.ks = ks;
+    return p;
+}
+
+// dw[co][ci] = sum_s slab[s][...]; slabs are [M][N] = [ci][co] when xFirst, else [co][ci].  A block reduces 64 consecutive
+// slab elements: 4 thread groups each sum a contiguous quarter of the slabs (coalesced 256-byte reads, 4 loads in flight),
+// then the quarters are combined in a fixed order.
+__global__ __launch_bounds__(256) void pw_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cout, int Cin,
+                                                        int ks, int xFirst) {
+    __shared__ float part[4][64];
+    const int total = Cout * Cin;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+    const int k0 = sg * ks / 4, k1 = (sg + 1) * ks / 4;
+    float s = 0.f;
+    if (e < total) {
+        const float* p = slabs + e;
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            const float a0 = p[(size_t)k * total], a1 = p[(size_t)(k + 1) * total];
+            const float a2 = p[(size_t)(k + 2) * total], a3 = p[(size_t)(k + 3) * total];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; k < k1; ++k) s += p[(size_t)k * total];
+    }
+    part[sg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sg == 0 && e < total) {
+        const float v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        const int dst = xFirst ? (e % Cout) * Cin + e / Cout : e;       // slab element (ci, co) -> dw[co][ci]
+        dw[dst] = v;
+    }
+}
+
 extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd,
                                                          int kh, int kw, int pd, int ph, int pw, int epd, int eph,
                                                          int epw) {
@@ -1571,7 +1624,12 @@ extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, in
     if (bw2_plan(bg.g, b2, splitCo, ks2, lds2) && ks2 * (splitCo ? 1 : BW2_KPAR_A) > ksplit) ksplit = ks2 * (splitCo ? 1 : BW2_KPAR_A);
     const size_t slab = (size_t)bg.g.nChunks * kd * kh * kw * bg.g.CoutPad * CK * sizeof(float);
     const size_t colsum = (size_t)1024 * Cout * sizeof(float);
-    const size_t need = (size_t)ksplit * slab + (size_t)ksplit * bg.g.CoutPad * sizeof(float);   // + bias partials (v2)
+    size_t need = (size_t)ksplit * slab + (size_t)ksplit * bg.g.CoutPad * sizeof(float);   // + bias partials (v2)
+    const PwPlan pp = pw_plan(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
+    if (pp.ok) {
+        const size_t gemm = (size_t)pp.ks * Cout * Cin * sizeof(float);
+        if (gemm > need) need = gemm;
+    }
     return need > colsum ? need : colsum;
 }
 
@@ -1588,6 +1646,33 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     const size_t need = diqt_conv3d_bwd_weight_workspace_bytes(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
     DIQT_REQUIRE(workspace_bytes >= need, DIQT_E_WORKSPACE, "conv3d_bwd_weight: workspace %zu < %zu", workspace_bytes, need);
     DIQT_REQUIRE(aligned16(workspace), DIQT_E_ALIGN, "conv3d_bwd_weight: workspace must be 16-byte aligned");
+    const PwPlan pp = pw_plan(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
+    if (pp.ok) {
+        float* slabs = static_cast<float*>(workspace);
+        const long long kslice = pp.V / pp.ks;
+        const float* Am = pp.xFirst ? x : dy;
+        const float* Bmm = pp.xFirst ? dy : x;
+        const int ldA = pp.xFirst ? Cin : Cout, ldB = pp.xFirst ? Cout : Cin;
+        rc = diqt_bgemm(Am, Bmm, slabs, pp.ks, pp.M, pp.N, (int)kslice, 1, 0, kslice * ldA, kslice * ldB, (long long)pp.M * pp.N,
+                        ldA, ldB, pp.N, 1.f, 0.f, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(pw_reduce_kernel, dim3((unsigned)cdiv(Cout * Cin, 64)), dim3(256), 0, (hipStream_t)stream, slabs,
+                           dw, Cout, Cin, pp.ks, pp.xFirst ? 1 : 0);
+        rc = check_launch("conv3d_bwd_weight(1x1x1 reduce)");
+        if (rc) return rc;
+        if (dbias) {
+            const size_t rows = (size_t)pp.V;
+            // wide layers at the coarse levels have few rows: slice them finely so the column sums still fill the chip
+            unsigned nblk = (unsigned)((rows + 15) / 16);
+            if (nblk > 1024) nblk = 1024;
+            hipLaunchKernelGGL(colsum_stage1_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), (hipStream_t)stream, dy, slabs, rows, Cout);
+            rc = check_launch("colsum_stage1");
+            if (rc) return rc;
+            hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(Cout, 4)), dim3(256), 0, (hipStream_t)stream, slabs, dbias, (int)nblk, Cout);
+            rc = check_launch("colsum_stage2");
+        }
+        return rc;
+    }
     const bool vec4 = (Cin % 4 == 0) && aligned16(x) && aligned16(dy);
     const size_t lds = ((size_t)g.TD * g.HH * g.HWd * (CK + 1) + (size_t)MTILE * (NT + 1)) * sizeof(float);
     DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_bwd_weight: tile needs %zu B of LDS", lds);
@@ -1637,8 +1722,8 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     if (rc) return rc;
     if (dbias && !bias_part) {
         const size_t rows = (size_t)g.B * g.Do * g.Ho * g.Wo;
-        unsigned nblk = (unsigned)((rows + 255) / 256);
-        if (nblk > 512) nblk = 512;
+        unsigned nblk = (unsigned)((rows + 15) / 16);
+        if (nblk > 1024) nblk = 1024;
         if (nblk < 1) nblk = 1;
         // the slabs were consumed by the reduce kernel above (same stream) -> reuse the workspace
         hipLaunchKernelGGL(colsum_stage1_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), s, dy, slabs, rows, Cout);

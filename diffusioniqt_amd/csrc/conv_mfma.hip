@@ -1159,7 +1159,27 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
         }
     }
 
-    float* slab = slabs + ((size_t)blockIdx.y * KPAR + kpar) * g.nChunks * T * g.CoutPad * CK;
+    // the two waves of a SIMD hold partial sums of the same taps (alternate k-steps): combine them through LDS so a workgroup
+    // writes ONE slab (halves the slab traffic and the split-K reduce)
+    if (KPAR == 2) {
+        __syncthreads();
+        float* red = smem;                       // [4][MAXT][16][64] floats (the launch reserves this much LDS)
+        if (wave >= 4) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((wave & 3) * MAXT + t) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[((wave * MAXT + t) * 16 + r) * 64 + lane];
+        }
+        if (wave >= 4) return;                   // no barrier follows on this path
+    }
+    float* slab = slabs + (size_t)blockIdx.y * g.nChunks * T * g.CoutPad * CK;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         if (t < ntap) {
@@ -1531,7 +1551,7 @@ static int bw_plan(BwGeom& bg, int B, int D, int H, int W, int Cin, int Cout, in
 }
 
 constexpr int BW2_MAXT_A = 7, BW2_MAXT_B = 3;   // A: 4 SIMDs x 7 taps per group, 2 k-interleaved waves per SIMD
-constexpr int BW2_KPAR_A = 2;                   // slabs written per workgroup in mode A
+constexpr int BW2_KPAR_A = 1;                   // slabs written per workgroup in mode A (the k-interleaved wave pairs are combined in LDS)
 // version-2 plan; returns false when the shape needs the generic (version-1) kernel
 static bool bw2_plan(const ConvGeom& g, BwGeom2& b2, bool& splitCo, int& ksplit, size_t& lds) {
     static const bool off = [] { const char* e = getenv("DIQT_BWDW_V1"); return e && e[0] == '1'; }();
@@ -1555,6 +1575,10 @@ static bool bw2_plan(const ConvGeom& g, BwGeom2& b2, bool& splitCo, int& ksplit,
     b2.tilesPerSplit = cdiv(b2.MT, ksplit);
     ksplit = cdiv(b2.MT, b2.tilesPerSplit);
     lds = ((size_t)HV * CK + (size_t)MTILE * COB) * sizeof(float) + (2 * (size_t)HV + 2 * MTILE) * sizeof(int);
+    if (!splitCo) {                                   // room for the end-of-kernel combine of the wave pairs
+        const size_t red = (size_t)4 * BW2_MAXT_A * 16 * 64 * sizeof(float);
+        if (red > lds) lds = red;
+    }
     return lds <= 160 * 1024;
 }
 
@@ -1563,6 +1587,9 @@ static bool bw2_plan(const ConvGeom& g, BwGeom2& b2, bool& splitCo, int& ksplit,
 extern "C" int diqt_bgemm(const float* A, const float* Bm, float* C, int batch, int M, int N, int K, int transA, int transB,
                           long long strideA, long long strideB, long long strideC, int lda, int ldb, int ldc, float alpha,
                           float beta, void* stream);
+extern "C" int diqt_weighted_colsum(const float* x, const float* w, float* out, void* workspace, size_t workspace_bytes,
+                                    int B, int rows, int C, void* stream);
+extern "C" size_t diqt_reduce_workspace_bytes(int B, int C);
 
 struct PwPlan { bool ok; long long V; int ks; bool xFirst; int M, N; };
 static PwPlan pw_plan(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd,
@@ -1630,6 +1657,10 @@ extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, in
         const size_t gemm = (size_t)pp.ks * Cout * Cin * sizeof(float);
         if (gemm > need) need = gemm;
     }
+    if (Cout == 1 && kd * kh * kw == 1) {
+        const size_t red = diqt_reduce_workspace_bytes(1, Cin);
+        if (red > need) need = red;
+    }
     return need > colsum ? need : colsum;
 }
 
@@ -1647,6 +1678,24 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     DIQT_REQUIRE(workspace_bytes >= need, DIQT_E_WORKSPACE, "conv3d_bwd_weight: workspace %zu < %zu", workspace_bytes, need);
     DIQT_REQUIRE(aligned16(workspace), DIQT_E_ALIGN, "conv3d_bwd_weight: workspace must be 16-byte aligned");
     const PwPlan pp = pw_plan(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
+    if (Cout == 1 && kd == 1 && kh == 1 && kw == 1 && pd == 0 && ph == 0 && pw == 0 && epd == 0 && eph == 0 && epw == 0 &&
+        workspace_bytes >= diqt_reduce_workspace_bytes(1, Cin) && (long long)B * D * H * W < (1ll << 31)) {
+        // final 1x1x1 conv to one channel: dW[0][ci] = sum_v dY[v] X[v][ci] is a weighted column sum, dbias = sum_v dY[v]
+        const int rows = (int)((long long)B * D * H * W);
+        rc = diqt_weighted_colsum(x, dy, dw, workspace, workspace_bytes, 1, rows, Cin, stream);
+        if (rc) return rc;
+        if (dbias) {
+            float* part = static_cast<float*>(workspace);
+            unsigned nblk = (unsigned)((rows + 255) / 256);
+            if (nblk > 1024) nblk = 1024;
+            hipLaunchKernelGGL(colsum_stage1_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), (hipStream_t)stream, dy, part, (size_t)rows, 1);
+            rc = check_launch("colsum_stage1");
+            if (rc) return rc;
+            hipLaunchKernelGGL(colsum_stage2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, dbias, (int)nblk, 1);
+            rc = check_launch("colsum_stage2");
+        }
+        return rc;
+    }
     if (pp.ok) {
         float* slabs = static_cast<float*>(workspace);
         const long long kslice = pp.V / pp.ks;

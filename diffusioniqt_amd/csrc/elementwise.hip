@@ -1019,13 +1019,14 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __re
                 for (int j = 0; j < LS_MB; ++j)
                     xv[j] = reinterpret_cast<const float4*>(x + (size_t)min(m0 + j, M - 1) * K)[k4];
 #pragma unroll
-                for (int j = 0; j < LS_MB; ++j) acc[j] += xv[j].x * wv.x + xv[j].y * wv.y + xv[j].z * wv.z + xv[j].w * wv.w;
+                for (int j = 0; j < LS_MB; ++j)      // explicit fma chain: hipcc otherwise contracts / packs the rows differently,
+                    acc[j] = fmaf(xv[j].w, wv.w, fmaf(xv[j].z, wv.z, fmaf(xv[j].y, wv.y, fmaf(xv[j].x, wv.x, acc[j]))));   // and a row's bits would depend on its position
             }
         } else {
             for (int k = lane; k < K; k += 64) {
                 const float wv = w[k];
 #pragma unroll
-                for (int j = 0; j < LS_MB; ++j) acc[j] += x[(size_t)min(m0 + j, M - 1) * K + k] * wv;
+                for (int j = 0; j < LS_MB; ++j) acc[j] = fmaf(x[(size_t)min(m0 + j, M - 1) * K + k], wv, acc[j]);
             }
         }
 #pragma unroll
@@ -1067,7 +1068,7 @@ __global__ __launch_bounds__(256) void linear_small_dx_part_kernel(const float* 
                 const float wv = W[(size_t)n * K + k];
 #pragma unroll
                 for (int j = 0; j < LS_MB; ++j)
-                    if (m0 + j < M) acc[j] += dy[(size_t)(m0 + j) * N + n] * wv;      // wave-uniform address: scalar load
+                    if (m0 + j < M) acc[j] = fmaf(dy[(size_t)(m0 + j) * N + n], wv, acc[j]);      // wave-uniform address: scalar load
             }
         if (k < K)
 #pragma unroll

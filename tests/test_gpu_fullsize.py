@@ -1,0 +1,88 @@
+"""Size-independent properties at BASELINE.json's full C2 size (SRUnet256 dim 64, mults (1,2,4), B = 8, 32^3) on a real
+MI355X — the oracle cannot run this size in seconds, so parity is checked through properties the domain offers:
+
+* batch-permutation equivariance of the U-Net (patches are independent units; GroupNorm / SE statistics are per sample):
+  bit-exact, which also pins that no kernel mixes batch entries or depends on launch geometry per sample;
+* run-to-run determinism of a sampler step (every reduction in the path has a fixed order): bit-exact;
+* the split-K / tile decomposition is invisible: one sample evaluated alone equals the same sample inside the batch of 8
+  up to the documented fp32 tolerance (the batch size changes tile->workgroup assignment and split-K decisions);
+* linearity of the dominant conv in its input at the dominant shape (64->64 3x3x3 @ 8x32^3);
+* the ancestral sampler with an oracle-exact predictor: if the U-Net output is replaced by the true x0, T steps of
+  ddpm_step reproduce the posterior chain x_s = ca x_t + cb x0 + cn eps accumulated in float64 on the host.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def c2():
+    from bench import unet_kwargs
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256
+    torch.manual_seed(42)
+    unet = SRUnet256(**unet_kwargs(32)).to(DEV).eval()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 1, 32, 32, 32, generator=g).to(DEV)
+    lr = torch.randn(8, 1, 32, 32, 32, generator=g).to(DEV)
+    t = torch.rand(8, generator=g).to(DEV)
+    return unet, x, lr, t
+
+
+def test_unet_batch_permutation_equivariance_bit_exact(c2):
+    unet, x, lr, t = c2
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=DEV)
+    with torch.no_grad():
+        y = unet(x, None, t, lowres_cond_img=lr)
+        yp = unet(x[perm].contiguous(), None, t[perm].contiguous(), lowres_cond_img=lr[perm].contiguous())
+    assert torch.isfinite(y).all()
+    assert torch.equal(yp, y[perm]), "a kernel mixes or mis-addresses batch entries"
+
+
+def test_unet_eval_is_deterministic_and_batch_size_invariant(c2):
+    unet, x, lr, t = c2
+    with torch.no_grad():
+        y1 = unet(x, None, t, lowres_cond_img=lr)
+        y2 = unet(x, None, t, lowres_cond_img=lr)
+        ya = unet(x[2:3].contiguous(), None, t[2:3].contiguous(), lowres_cond_img=lr[2:3].contiguous())
+    assert torch.equal(y1, y2), "U-Net eval is not run-to-run deterministic"
+    err = (ya - y1[2:3]).abs().max().item()
+    assert err <= 2e-4 * y1.abs().max().item() + 1e-6, f"batch-of-1 vs batch-of-8 differ by {err:.3e}"
+
+
+def test_dominant_conv_is_linear_in_its_input():
+    from diffusioniqt_amd import ops, _lib
+    _lib.load()
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(8, 32, 32, 32, 64, generator=g).to(DEV)
+    x2 = torch.randn(8, 32, 32, 32, 64, generator=g).to(DEV)
+    w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.03).to(DEV)
+    with torch.no_grad():
+        y1, y2 = ops.conv3d(x1, w, None, (1, 1, 1)), ops.conv3d(x2, w, None, (1, 1, 1))
+        y12 = ops.conv3d(2.0 * x1 - 0.5 * x2, w, None, (1, 1, 1))
+    ref = 2.0 * y1 - 0.5 * y2
+    err = (y12 - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item(), f"conv linearity violated: {err:.3e}"
+
+
+def test_sampler_chain_with_exact_predictor_matches_float64_closed_form():
+    """ddpm_step x T with pred = x0 (imagen_pytorch3D.py:290-309, 2051-2055) against a float64 accumulation of the same chain."""
+    from diffusioniqt_amd import ops
+    from diffusioniqt_amd.imagen_pytorch3D import GaussianDiffusionContinuousTimes
+    T, B = 32, 8
+    sched = GaussianDiffusionContinuousTimes(noise_schedule='cosine', timesteps=T)
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(B, 1, 32, 32, 32, generator=g)
+    img = torch.randn(B, 1, 32, 32, 32, generator=g)
+    noises = [torch.randn(B, 1, 32, 32, 32, generator=g) for _ in range(T)]
+    ref = img.double()
+    dimg, dx0 = img.to(DEV), x0.to(DEV)
+    for i, (t, tn) in enumerate(sched.get_sampling_timesteps(B, device='cpu')):
+        ca, cb, cn = sched.posterior_coefficients(t, tn)
+        dimg, _ = ops.ddpm_step(dimg, dx0, noises[i].to(DEV), ca.to(DEV), cb.to(DEV), cn.to(DEV), -float('inf'), float('inf'), 1)
+        sh = (-1, 1, 1, 1, 1)       # the per-step coefficients themselves are pinned by the reference fixtures (schedulesA)
+        ref = ca.double().view(sh) * ref + cb.double().view(sh) * x0.double() + cn.double().view(sh) * noises[i].double()
+    err = (dimg.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item() + 1e-6, f"{T}-step chain drifted by {err:.3e}"

@@ -86,3 +86,21 @@ def test_sampler_chain_with_exact_predictor_matches_float64_closed_form():
         ref = ca.double().view(sh) * ref + cb.double().view(sh) * x0.double() + cn.double().view(sh) * noises[i].double()
     err = (dimg.cpu().double() - ref).abs().max().item()
     assert err <= 2e-5 * ref.abs().max().item() + 1e-6, f"{T}-step chain drifted by {err:.3e}"
+
+
+def test_backward_is_run_to_run_deterministic(c2):
+    """Every gradient reduction has a fixed order (split-K slabs, GroupNorm / SE column sums, bias sums): two backward passes on
+    the same inputs give bit-identical parameter gradients at the full C2 size."""
+    unet, x, lr, t = c2
+    unet.train()
+    grads = []
+    for _ in range(2):
+        unet.zero_grad(set_to_none=True)
+        y = unet(x, None, t, lowres_cond_img=lr)
+        (y ** 2).mean().backward()
+        grads.append({n: p.grad.detach().clone() for n, p in unet.named_parameters() if p.grad is not None})
+    unet.eval()
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 200
+    bad = [n for n in grads[0] if not torch.equal(grads[0][n], grads[1][n])]
+    assert not bad, f"non-deterministic gradients: {bad[:5]}"
+    assert all(torch.isfinite(g).all() for g in grads[0].values())

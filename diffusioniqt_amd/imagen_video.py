@@ -192,12 +192,18 @@ class Attention(nn.Module):
             extra = ops.concat_channels(ckv.reshape(G, -1), extra)                # [context..., null]   (:471-481)
         kv_ext = ops.concat_channels(extra, kv.reshape(G, n * 2 * d))             # [G, (E+n)*2d]
         M = E + n
-        sim = ops.bmm_strided(q, kv_ext, (G, n * h, M, d, False, True, n * h * d, d, M * 2 * d, 2 * d, n * h * M, M,
-                                          self.scale, (G, n, h, M), 0, 0))
         rel = null_bias = None
         if exists(self.rel_pos_bias):
             rel = self.rel_pos_bias(n, x.device)                                  # [2n-1, h]
             null_bias = self.null_attn_bias                                        # only added together with the bias (:497-500)
+        if not torch.is_grad_enabled() and d in (32, 64) and G <= 65535:
+            # sampling path: fused QK^T -> bias/mask -> softmax -> PV, the [G, n*h, M] scores stay in registers
+            out = ops.mqa_attention_nograd(q.contiguous(), kv_ext.reshape(G, M, 2 * d).contiguous(),
+                                           rel.contiguous() if exists(rel) else None,
+                                           null_bias.contiguous() if exists(null_bias) else None, n, h, d, E, n, self.causal, self.scale)
+            return self.to_out(out)
+        sim = ops.bmm_strided(q, kv_ext, (G, n * h, M, d, False, True, n * h * d, d, M * 2 * d, 2 * d, n * h * M, M,
+                                          self.scale, (G, n, h, M), 0, 0))
         p = ops.attn_softmax(sim, rel, null_bias, n, h, E, n, self.causal)
         out = ops.bmm_strided(p, kv_ext, (G, n * h, d, M, False, False, n * h * M, M, M * 2 * d, 2 * d, n * h * d, d,
                                           1.0, (G, n, h * d), 0, d))

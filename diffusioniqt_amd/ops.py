@@ -870,6 +870,16 @@ class _AttnSoftmaxFn(Function):
         return dsim, drel, dnull, None, None, None, None, None
 
 
+def mqa_attention_nograd(q, kv_ext, rel, null_bias, n, h, d, n_extra, n_self, causal, scale):
+    """Fused multi-query attention forward (no autograd: sampling path).  q: [G, n, h*d]; kv_ext: [G, n_extra + n_self, 2d]."""
+    _chk(q, kv_ext, rel, null_bias)
+    G = q.shape[0]
+    out = torch.empty((G, n, h * d), dtype=torch.float32, device=q.device)
+    _lib.call("diqt_mqa_attention_fwd", q, kv_ext, rel, null_bias, out, G, n, h, d, n_extra, n_self, int(causal), float(scale),
+              _stream())
+    return out
+
+
 def attn_softmax(sim, rel, null_bias, n, h, n_extra, n_self, causal):
     """softmax over keys of sim[G, n, h, n_extra + n_self] with T5-style relative bias table rel[2n-1, h] on the self
     keys, null_bias[h] on the null key (last extra key) and an optional causal mask (imagen_video.py:490-518)."""

@@ -307,6 +307,13 @@ int diqt_attn_softmax_fwd(const float* sim, const float* rel, const float* null_
                           int G, int n, int h, int n_extra, int n_self, int causal, void* stream);
 int diqt_attn_softmax_bwd(const float* p, const float* dp, float* dsim, float* drel, float* dnull_bias,
                           int G, int n, int h, int n_extra, int n_self, int causal, void* stream);
+/* Fused multi-query attention forward for the sampling path (imagen_video.py:410-525 Attention.forward): q[G][n][h][d],
+ * kv[G][n_extra + n_self][2d] (k | v per key row; extra keys first, learned null key last of them), optional relative
+ * position table rel[2n-1][h] on the self keys with null_bias[h] on the null key, optional causal mask ->
+ * out[G][n][h*d] = softmax(scale q.k + bias) v.  The [G, n*h, keys] score tensor is never materialised.  d = 32 or 64. */
+int diqt_mqa_attention_fwd(const float* q, const float* kv, const float* rel, const float* null_bias, float* out, int G,
+                           int n, int h, int d, int n_extra, int n_self, int causal, float scale, void* stream);
+
 /* batched fp32 MFMA GEMM: C[g] = alpha * op(A[g]) * op(B[g]) (+ beta*C[g]); row-major, strides in floats */
 int diqt_bgemm(const float* A, const float* Bm, float* C, int batch, int M, int N, int K,
                int transA, int transB, long long strideA, long long strideB, long long strideC,

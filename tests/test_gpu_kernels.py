@@ -394,6 +394,34 @@ def test_weighted_pool_global_context(ops):
         close(xd.grad, xr.grad, tol=1e-4, what="weighted pool dx")
 
 
+@pytest.mark.parametrize("G,n,h,d,E,use_rel,causal", [(2, 40, 4, 64, 1, False, False), (3, 16, 8, 64, 1, True, True),
+                                                       (1, 300, 2, 32, 3, False, False), (2, 33, 3, 32, 1, True, False),
+                                                       (1, 1, 8, 64, 1, True, True), (1, 2048, 8, 64, 5, False, False)])
+def test_fused_mqa_attention_forward(ops, G, n, h, d, E, use_rel, causal):
+    """diqt_mqa_attention_fwd == softmax(scale q k^T + rel bias / null bias, causal mask) v (imagen_video.py:483-520) in fp64."""
+    gen = torch.Generator().manual_seed(G * 100 + n)
+    q = torch.randn(G, n, h * d, generator=gen)
+    kv = torch.randn(G, E + n, 2 * d, generator=gen)
+    rel = torch.randn(2 * n - 1, h, generator=gen) if use_rel else None
+    nb = torch.randn(h, generator=gen) if use_rel else None
+    scale = d ** -0.5
+    qd = q.double().reshape(G, n, h, d)
+    k, v = kv.double()[..., :d], kv.double()[..., d:]
+    sim = torch.einsum('gihd,gjd->gihj', qd, k) * scale
+    if use_rel:
+        i = torch.arange(n)[:, None]; j = torch.arange(n)[None, :]
+        sim[..., E:] += rel.double()[(i - j + n - 1)].permute(0, 2, 1)[None]          # [n, h, n] indexed (i, hh, j)
+        sim[..., E - 1] += nb.double()[None, None, :]
+    if causal:
+        i = torch.arange(n)[:, None]; j = torch.arange(n)[None, :]
+        mask = (j > i)[None, :, None, :].expand(G, n, h, n)
+        sim[..., E:] = sim[..., E:].masked_fill(mask, float('-inf'))
+    ref = torch.einsum('gihj,gjd->gihd', sim.softmax(dim=-1), v).reshape(G, n, h * d)
+    got = ops.mqa_attention_nograd(q.to(DEV), kv.to(DEV), rel.to(DEV) if use_rel else None, nb.to(DEV) if use_rel else None,
+                                   n, h, d, E, n, causal, scale)
+    close(got, ref, tol=3e-5, what="fused MQA attention")
+
+
 def test_multi_accumulate_matches_per_tensor_adds(ops):
     """Gradient accumulation into the flat arena: one launch == the per-parameter `grad += new` adds (bit-exact)."""
     g = torch.Generator().manual_seed(11)

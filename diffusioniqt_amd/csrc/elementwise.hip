@@ -813,6 +813,34 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const f
 // ---------------------------------------------------------------------------------------------
 // softmax over the middle axis of [outer][n][inner]
 // ---------------------------------------------------------------------------------------------
+// inner == 1, few long rows (GlobalContext: 8 rows of 32768 positions): one 1024-thread workgroup per row
+__global__ __launch_bounds__(1024) void softmax_longrow_kernel(const float* __restrict__ x, float* __restrict__ y, int n, float scale) {
+    __shared__ float sh[16];
+    const float* xr = x + (size_t)blockIdx.x * n;
+    float* yr = y + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 1024) mx = fmaxf(mx, xr[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) sh[w] = mx;
+    __syncthreads();
+    mx = sh[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, sh[k]);
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < n; i += 1024) s += __expf(xr[i] - mx);
+    s = wave_sum(s);
+    if (lane == 0) sh[w] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += sh[k];
+    const float inv = scale / tot;
+    for (int i = tid; i < n; i += 1024) yr[i] = __expf(xr[i] - mx) * inv;
+}
+
 // inner == 1: one wave per row
 __global__ __launch_bounds__(256) void softmax_row_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           size_t rows, int n, float scale) {
@@ -1579,7 +1607,9 @@ extern "C" int diqt_softmax_fwd(const float* x, float* y, size_t outer, int n, i
     DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "softmax_fwd: null pointer");
     DIQT_REQUIRE(n > 0 && inner > 0, DIQT_E_SHAPE, "softmax_fwd: bad shape");
     if (outer == 0) return DIQT_OK;
-    if (inner == 1)
+    if (inner == 1 && outer <= 1024 && n >= 4096)
+        hipLaunchKernelGGL(softmax_longrow_kernel, dim3((unsigned)outer), dim3(1024), 0, STREAM, x, y, n, scale);
+    else if (inner == 1)
         hipLaunchKernelGGL(softmax_row_kernel, dim3(grid_for(outer, 4, 8192)), dim3(256), 0, STREAM, x, y, outer, n, scale);
     else
         hipLaunchKernelGGL(softmax_col_kernel, dim3(grid_for(outer * inner, 256)), dim3(256), 0, STREAM, x, y, outer, n, inner, scale);

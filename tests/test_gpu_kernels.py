@@ -377,6 +377,15 @@ def test_bgemm_large_tiles_all_layouts(ops, g_, M, N, K):
     close(Bd.grad, Br.grad, tol=1e-4, what="bgemm dB")
 
 
+def test_softmax_few_long_rows(ops):
+    """GlobalContext soft-max over all positions: 8 rows of 32768 (one workgroup per row)."""
+    gen = torch.Generator().manual_seed(5)
+    for rows, n in ((8, 32768), (3, 5000), (1, 4096)):
+        x = torch.randn(rows, n, generator=gen) * 3
+        got = ops.softmax(x.to(DEV), dim=-1, scale=0.5)
+        close(got, 0.5 * torch.softmax(x.double(), dim=-1), tol=3e-5, what=f"softmax {rows}x{n}")
+
+
 def test_weighted_pool_global_context(ops):
     """GlobalContext pooling (imagen_video.py:975-979): out[b,c] = sum_n softmax(ctx)[b,n] x[b,n,c]."""
     gen = torch.Generator().manual_seed(21)

@@ -1558,7 +1558,7 @@ static bool bw2_plan(const ConvGeom& g, BwGeom2& b2, bool& splitCo, int& ksplit,
     if (off) return false;
     const int T = g.kd * g.kh * g.kw, HV = g.HD * g.HH * g.HWd;
     splitCo = T <= BW2_MAXT_B;
-    if (splitCo ? (HV * 8 > 256 * 4) : (HV * 8 > 512 * 7)) return false;
+    if (splitCo ? (HV * 8 > 256 * 8) : (HV * 8 > 512 * 7)) return false;      // register-staged halo pieces: NRX = 8 / 7 per thread
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     b2.g = g;
     b2.lTW = ilog2(g.TW); b2.lTH = ilog2(g.TH);
@@ -1741,7 +1741,7 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     int bias_parts = 0;
     if (bw2_plan(g, b2, splitCo, ks2, lds2)) {
         void (*k2)(const float*, const float*, float*, float*, BwGeom2) =
-            splitCo ? (vec4 ? conv_bwd_weight2_kernel<true, 4, 16, BW2_MAXT_B, true, 256> : conv_bwd_weight2_kernel<false, 4, 16, BW2_MAXT_B, true, 256>)
+            splitCo ? (vec4 ? conv_bwd_weight2_kernel<true, 8, 16, BW2_MAXT_B, true, 256> : conv_bwd_weight2_kernel<false, 8, 16, BW2_MAXT_B, true, 256>)
                     : (vec4 ? conv_bwd_weight2_kernel<true, 7, 2, BW2_MAXT_A, false, 512> : conv_bwd_weight2_kernel<false, 7, 2, BW2_MAXT_A, false, 512>);
         if (lds2 > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);

@@ -1699,6 +1699,76 @@ extern "C" int diqt_attn_softmax_fwd(const float* sim, const float* rel, const f
     return check_launch("attn_softmax_fwd");
 }
 extern "C" int diqt_attn_softmax_bwd(const float* p, const float* dp, float* dsim, float* drel, float* dnull_bias, int G,
+                                     int n, int h, int n_extra, int n_self, int causal, void* stream);
+// deterministic relative-bias gradient: every wave accumulates its rows into a private LDS table (for one row the keys map to
+// distinct table entries, rows of a wave are sequential), the 4 tables of a block are summed in order into
+// partial[block][(2ns-1)*h + h] and attn_rel_reduce_kernel sums the blocks in order.  (The plain kernel's global atomics took
+// 6 ms per call on the temporal attention: 69 M atomics onto 504 addresses.)
+__global__ __launch_bounds__(256) void attn_softmax_bwd_tbl_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                                   float* __restrict__ dsim, float* __restrict__ partial,
+                                                                   size_t rows, int n, int h, int E, int ns, int causal, int want_rel,
+                                                                   int want_null) {
+    extern __shared__ float tbl[];                       // [4 waves][T], T = (2ns-1)*h + h
+    const int T = (2 * ns - 1) * h + h;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, M = E + ns;
+    float* mine = tbl + (size_t)wv * T;
+    for (int e = lane; e < T; e += 64) mine[e] = 0.f;
+    for (size_t r = blockIdx.x * (size_t)4 + wv; r < rows; r += (size_t)gridDim.x * 4) {
+        const int hh = (int)(r % h), i = (int)((r / h) % n);
+        float s = 0.f;
+        for (int j = lane; j < M; j += 64) s += p[r * M + j] * dp[r * M + j];
+        s = wave_sum(s);
+        for (int j = lane; j < M; j += 64) {
+            const float d = p[r * M + j] * (dp[r * M + j] - s);      // zero where masked (p == 0)
+            dsim[r * M + j] = d;
+            if (j >= E) {
+                const int jj = j - E;
+                if (want_rel && !(causal && jj > i)) mine[(i - jj + ns - 1) * h + hh] += d;     // distinct entries within a row
+            } else if (j == E - 1 && want_null) mine[(2 * ns - 1) * h + hh] += d;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T; e += 256)
+        partial[(size_t)blockIdx.x * T + e] = ((tbl[e] + tbl[T + e]) + tbl[2 * T + e]) + tbl[3 * T + e];
+}
+__global__ __launch_bounds__(256) void attn_rel_reduce_kernel(const float* __restrict__ partial, float* __restrict__ drel,
+                                                              float* __restrict__ dnull, int nblk, int relElems, int h) {
+    const int e = blockIdx.x * 256 + threadIdx.x, T = relElems + h;
+    if (e >= T) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * T + e];
+    if (e < relElems) { if (drel) drel[e] = s; }
+    else if (dnull) dnull[e - relElems] = s;
+}
+
+extern "C" size_t diqt_attn_softmax_bwd_workspace_bytes(int G, int n, int h, int n_extra, int n_self) {
+    const size_t T = (size_t)(2 * n_self - 1) * h + h;
+    if (T * 4 * sizeof(float) > 48 * 1024) return 0;              // table too large for LDS: the atomic kernel is used
+    return (size_t)1024 * T * sizeof(float);
+}
+
+extern "C" int diqt_attn_softmax_bwd_ws(const float* p, const float* dp, float* dsim, float* drel, float* dnull_bias,
+                                        void* workspace, size_t workspace_bytes, int G, int n, int h, int n_extra, int n_self,
+                                        int causal, void* stream) {
+    DIQT_REQUIRE(p && dp && dsim, DIQT_E_ALIGN, "attn_softmax_bwd: null pointer");
+    DIQT_REQUIRE(G > 0 && n > 0 && h > 0 && n_extra >= 0 && n_self >= 0 && n_extra + n_self > 0, DIQT_E_SHAPE, "attn_softmax_bwd: bad shape");
+    const size_t rows = (size_t)G * n * h;
+    const size_t need = diqt_attn_softmax_bwd_workspace_bytes(G, n, h, n_extra, n_self);
+    if (!(drel || dnull_bias) || need == 0 || !workspace || workspace_bytes < need)
+        return diqt_attn_softmax_bwd(p, dp, dsim, drel, dnull_bias, G, n, h, n_extra, n_self, causal, stream);
+    const int T = (2 * n_self - 1) * h + h;
+    const unsigned nblk = grid_for(rows, 4, 1024);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(attn_softmax_bwd_tbl_kernel, dim3(nblk), dim3(256), (size_t)4 * T * sizeof(float), STREAM, p, dp, dsim, partial,
+                       rows, n, h, n_extra, n_self, causal, drel ? 1 : 0, dnull_bias ? 1 : 0);
+    int rc = check_launch("attn_softmax_bwd(table)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_rel_reduce_kernel, dim3((T + 255) / 256), dim3(256), 0, STREAM, partial, drel, dnull_bias, (int)nblk,
+                       T - h, h);
+    return check_launch("attn_softmax_bwd(reduce)");
+}
+
+extern "C" int diqt_attn_softmax_bwd(const float* p, const float* dp, float* dsim, float* drel, float* dnull_bias, int G,
                                      int n, int h, int n_extra, int n_self, int causal, void* stream) {
     DIQT_REQUIRE(p && dp && dsim, DIQT_E_ALIGN, "attn_softmax_bwd: null pointer");
     DIQT_REQUIRE(G > 0 && n > 0 && h > 0 && n_extra >= 0 && n_self >= 0 && n_extra + n_self > 0, DIQT_E_SHAPE, "attn_softmax_bwd: bad shape");

@@ -866,7 +866,10 @@ class _AttnSoftmaxFn(Function):
         dsim = torch.empty_like(p)
         drel = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=p.device) if has_rel else None
         dnull = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=p.device) if has_null else None
-        _lib.call("diqt_attn_softmax_bwd", p, dp.contiguous(), dsim, drel, dnull, G, n, h, n_extra, n_self, causal, _stream())
+        nws = _lib.query("diqt_attn_softmax_bwd_workspace_bytes", G, n, h, n_extra, n_self)
+        ws = _workspace(nws, p.device) if nws else None
+        _lib.call("diqt_attn_softmax_bwd_ws", p, dp.contiguous(), dsim, drel, dnull, ws, nws, G, n, h, n_extra, n_self, causal,
+                  _stream())
         return dsim, drel, dnull, None, None, None, None, None
 
 

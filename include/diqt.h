@@ -307,6 +307,12 @@ int diqt_attn_softmax_fwd(const float* sim, const float* rel, const float* null_
                           int G, int n, int h, int n_extra, int n_self, int causal, void* stream);
 int diqt_attn_softmax_bwd(const float* p, const float* dp, float* dsim, float* drel, float* dnull_bias,
                           int G, int n, int h, int n_extra, int n_self, int causal, void* stream);
+/* Same gradients with the relative-bias / null-bias sums reduced in a fixed order through `workspace`
+ * (diqt_attn_softmax_bwd_workspace_bytes; 0 = table too large, the call falls back to the atomic kernel). */
+size_t diqt_attn_softmax_bwd_workspace_bytes(int G, int n, int h, int n_extra, int n_self);
+int diqt_attn_softmax_bwd_ws(const float* p, const float* dp, float* dsim, float* drel, float* dnull_bias,
+                             void* workspace, size_t workspace_bytes, int G, int n, int h, int n_extra, int n_self,
+                             int causal, void* stream);
 /* Fused multi-query attention forward for the sampling path (imagen_video.py:410-525 Attention.forward): q[G][n][h][d],
  * kv[G][n_extra + n_self][2d] (k | v per key row; extra keys first, learned null key last of them), optional relative
  * position table rel[2n-1][h] on the self keys with null_bias[h] on the null key, optional causal mask ->

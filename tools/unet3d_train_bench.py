@@ -1,0 +1,22 @@
+"""Family-B (Unet3D) fwd+bwd timing.  python tools/unet3d_train_bench.py [dim] [size] [batch]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffusioniqt_amd import ops, _lib
+from diffusioniqt_amd.imagen_video import Unet3D
+_lib.load()
+dim, S, B = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 32, 8)
+torch.manual_seed(0)
+unet = Unet3D(dim=dim, dim_mults=(1, 2, 4), channels=1, cond_on_text=False, text_embed_dim=None, lowres_cond=True,
+              layer_attns=(False, False, True), layer_cross_attns=False, attend_at_middle=True, num_resnet_blocks=2,
+              attn_pool_text=False).cuda().train()
+x = torch.randn(B, 1, S, S, S, device="cuda"); lr = torch.randn_like(x)
+t = torch.randn(B, device="cuda") * 0.5; lt = torch.full((B,), 0.2, device="cuda")
+def step():
+    unet.zero_grad(set_to_none=True)
+    unet(x, t, lowres_cond_img=lr, lowres_noise_times=lt).square().mean().backward()
+for _ in range(3): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+print(f"Unet3D dim={dim} {S}^3 B={B} fwd+bwd: {dt * 1e3:.2f} ms")

@@ -74,6 +74,8 @@ PROTOTYPES = {
     "diqt_attn_softmax_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "diqt_attn_softmax_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "diqt_bgemm": (I, [P, P, P, I, I, I, I, I, I, L, L, L, I, I, I, F, F, P]),
+    "diqt_bgemm_workspace_bytes": (Z, [I, I, I, I]),
+    "diqt_bgemm_ws": (I, [P, P, P, P, Z, I, I, I, I, I, I, L, L, L, I, I, I, F, F, P]),
     "diqt_multi_accumulate": (I, [P, P, I, I, P]),
     "diqt_attn_softmax_bwd_workspace_bytes": (Z, [I, I, I, I, I]),
     "diqt_attn_softmax_bwd_ws": (I, [P, P, P, P, P, P, Z, I, I, I, I, I, I, P]),

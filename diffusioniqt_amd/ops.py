@@ -662,8 +662,10 @@ def softmax(x, dim, scale=1.0):
 
 
 def _bgemm_strided(A, Bm, C, g, M, N, K, tA, tB, sA, lda, sB, ldb, sC, ldc, alpha, oA=0, oB=0, oC=0):
-    _lib.call("diqt_bgemm", A.data_ptr() + 4 * oA, Bm.data_ptr() + 4 * oB, C.data_ptr() + 4 * oC, g, M, N, K, int(tA), int(tB),
-              sA, sB, sC, lda, ldb, ldc, float(alpha), 0.0, _stream())
+    nws = _lib.query("diqt_bgemm_workspace_bytes", g, M, N, K)
+    ws = _workspace(nws, A.device) if nws else None
+    _lib.call("diqt_bgemm_ws", A.data_ptr() + 4 * oA, Bm.data_ptr() + 4 * oB, C.data_ptr() + 4 * oC, ws, nws, g, M, N, K, int(tA),
+              int(tB), sA, sB, sC, lda, ldb, ldc, float(alpha), 0.0, _stream())
 
 
 class _BmmStridedFn(Function):
@@ -716,7 +718,9 @@ def _bgemm_raw(A, Bm, tA, tB, alpha=1.0):
     M, K = (A.shape[2], A.shape[1]) if tA else (A.shape[1], A.shape[2])
     N = Bm.shape[1] if tB else Bm.shape[2]
     C = torch.empty((g, M, N), dtype=torch.float32, device=A.device)
-    _lib.call("diqt_bgemm", A, Bm, C, g, M, N, K, int(tA), int(tB), A.shape[1] * A.shape[2], Bm.shape[1] * Bm.shape[2],
+    nws = _lib.query("diqt_bgemm_workspace_bytes", g, M, N, K)
+    ws = _workspace(nws, A.device) if nws else None
+    _lib.call("diqt_bgemm_ws", A, Bm, C, ws, nws, g, M, N, K, int(tA), int(tB), A.shape[1] * A.shape[2], Bm.shape[1] * Bm.shape[2],
               M * N, A.shape[2], Bm.shape[2], N, float(alpha), 0.0, _stream())
     return C
 

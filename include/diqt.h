@@ -324,6 +324,13 @@ int diqt_mqa_attention_fwd(const float* q, const float* kv, const float* rel, co
 int diqt_bgemm(const float* A, const float* Bm, float* C, int batch, int M, int N, int K,
                int transA, int transB, long long strideA, long long strideB, long long strideC,
                int lda, int ldb, int ldc, float alpha, float beta, void* stream);
+/* Same GEMM with a caller-owned workspace: problems with few output tiles and a long K (dK / dV of the attentions, 1- and
+ * 5-row products) are split along K into slabs that a second kernel sums in a fixed order.
+ * diqt_bgemm_workspace_bytes() returns 0 when the shape is not split.                                              */
+size_t diqt_bgemm_workspace_bytes(int batch, int M, int N, int K);
+int diqt_bgemm_ws(const float* A, const float* Bm, float* C, void* workspace, size_t workspace_bytes, int batch, int M, int N,
+                  int K, int transA, int transB, long long strideA, long long strideB, long long strideC, int lda, int ldb,
+                  int ldc, float alpha, float beta, void* stream);
 
 #ifdef __cplusplus
 }

@@ -356,7 +356,8 @@ def test_diffusion_steps_loss_adam(ops):
     close(ed, e + (wr.detach() - e) * 0.25, tol=1e-5, what="ema")
 
 
-@pytest.mark.parametrize("g_,M,N,K", [(2, 300, 70, 45), (3, 129, 33, 64), (1, 1024, 2053, 64), (2, 513, 64, 2049), (4, 256, 64, 33)])
+@pytest.mark.parametrize("g_,M,N,K", [(2, 300, 70, 45), (3, 129, 33, 64), (1, 1024, 2053, 64), (2, 513, 64, 2049), (4, 256, 64, 33),
+                                      (2, 5, 64, 2048), (1, 1, 64, 5000), (3, 33, 64, 256), (2, 200, 64, 4100), (2, 64, 70, 1300)])
 def test_bgemm_large_tiles_all_layouts(ops, g_, M, N, K):
     """128x64-tile batched GEMM (attention QK^T / PV shapes, odd extents, 16-byte aligned and unaligned leading dims)."""
     gen = torch.Generator().manual_seed(M + N + K)

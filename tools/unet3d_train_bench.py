@@ -20,3 +20,28 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print(f"Unet3D dim={dim} {S}^3 B={B} fwd+bwd: {dt * 1e3:.2f} ms")
+
+if os.environ.get("BGEMM_SHAPES") == "1":
+    import collections
+    from diffusioniqt_amd import _lib as L
+    real_call = L.call
+    stats = collections.OrderedDict()
+    def spy(name, *a):
+        if name == "diqt_bgemm":
+            g, M, N, K, tA, tB = a[3:9]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); real_call(name, *a); e.record()
+            stats.setdefault((g, M, N, K, tA, tB), []).append((s, e))
+            return
+        return real_call(name, *a)
+    L.call = spy
+    ops._lib.call = spy
+    step()
+    torch.cuda.synchronize()
+    tot = 0
+    print("batch      M      N      K  tA tB  calls   us/call   TFLOP/s")
+    for k, evs in sorted(stats.items(), key=lambda kv: -sum(s.elapsed_time(e) for s, e in kv[1]))[:22]:
+        ms = sum(s.elapsed_time(e) for s, e in evs); tot += ms
+        g, M, N, K = k[:4]
+        print(f"{g:5d} {M:6d} {N:6d} {K:6d}  {k[4]}  {k[5]}  {len(evs):5d} {1e3 * ms / len(evs):9.1f} {2.0 * g * M * N * K * len(evs) / ms / 1e9:9.1f}")
+    print("bgemm (python-called) total ms:", tot)

@@ -942,6 +942,7 @@ struct BwGeom2 {
     int tapGroups, coBlocks;     // grid.x = nChunks * coBlocks * tapGroups
     int tilesPerSplit, MT;
     int lTW, lTH;
+    int maxtA;                   // mode A: taps per SIMD (7 for 3x3x3; 3 for <= 12-tap filters such as (1,3,3))
 };
 
 template <bool VEC4, int NRX, int NRY, int MAXT, bool SPLIT_CO, int NTHR>
@@ -1563,7 +1564,10 @@ static bool bw2_plan(const ConvGeom& g, BwGeom2& b2, bool& splitCo, int& ksplit,
     b2.g = g;
     b2.lTW = ilog2(g.TW); b2.lTH = ilog2(g.TH);
     if ((1 << b2.lTW) != g.TW || (1 << b2.lTH) != g.TH) return false;
-    const int COB = splitCo ? 128 : 32, TG = splitCo ? BW2_MAXT_B : 4 * BW2_MAXT_A;
+    // the MFMAs of a step are issued for every tap slot of a wave, used or not: filters with <= 12 taps ((1,3,3): 9) take
+    // the 3-taps-per-SIMD instantiation instead of idling 4 of 7 slots
+    b2.maxtA = (!splitCo && T <= 12) ? 3 : BW2_MAXT_A;
+    const int COB = splitCo ? 128 : 32, TG = splitCo ? BW2_MAXT_B : 4 * b2.maxtA;
     b2.tapGroups = cdiv(T, TG);
     b2.coBlocks = cdiv(g.CoutPad, COB);
     b2.MT = g.B * g.tilesD * g.tilesH * g.tilesW;
@@ -1742,7 +1746,9 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     if (bw2_plan(g, b2, splitCo, ks2, lds2)) {
         void (*k2)(const float*, const float*, float*, float*, BwGeom2) =
             splitCo ? (vec4 ? conv_bwd_weight2_kernel<true, 8, 16, BW2_MAXT_B, true, 256> : conv_bwd_weight2_kernel<false, 8, 16, BW2_MAXT_B, true, 256>)
-                    : (vec4 ? conv_bwd_weight2_kernel<true, 7, 2, BW2_MAXT_A, false, 512> : conv_bwd_weight2_kernel<false, 7, 2, BW2_MAXT_A, false, 512>);
+                    : (b2.maxtA == 3
+                           ? (vec4 ? conv_bwd_weight2_kernel<true, 7, 2, 3, false, 512> : conv_bwd_weight2_kernel<false, 7, 2, 3, false, 512>)
+                           : (vec4 ? conv_bwd_weight2_kernel<true, 7, 2, BW2_MAXT_A, false, 512> : conv_bwd_weight2_kernel<false, 7, 2, BW2_MAXT_A, false, 512>));
         if (lds2 > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_bwd_weight: hipFuncSetAttribute: %s", hipGetErrorString(e));

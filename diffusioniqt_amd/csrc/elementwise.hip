@@ -1731,14 +1731,18 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_tbl_kernel(const float* 
     for (int e = threadIdx.x; e < T; e += 256)
         partial[(size_t)blockIdx.x * T + e] = ((tbl[e] + tbl[T + e]) + tbl[2 * T + e]) + tbl[3 * T + e];
 }
+// one wave per table entry: lanes stride over the block partials, fixed-order wave reduction
 __global__ __launch_bounds__(256) void attn_rel_reduce_kernel(const float* __restrict__ partial, float* __restrict__ drel,
                                                               float* __restrict__ dnull, int nblk, int relElems, int h) {
-    const int e = blockIdx.x * 256 + threadIdx.x, T = relElems + h;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, T = relElems + h;
     if (e >= T) return;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * T + e];
-    if (e < relElems) { if (drel) drel[e] = s; }
-    else if (dnull) dnull[e - relElems] = s;
+    for (int b = lane; b < nblk; b += 64) s += partial[(size_t)b * T + e];
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (e < relElems) { if (drel) drel[e] = s; }
+        else if (dnull) dnull[e - relElems] = s;
+    }
 }
 
 extern "C" size_t diqt_attn_softmax_bwd_workspace_bytes(int G, int n, int h, int n_extra, int n_self) {
@@ -1763,7 +1767,7 @@ extern "C" int diqt_attn_softmax_bwd_ws(const float* p, const float* dp, float* 
                        rows, n, h, n_extra, n_self, causal, drel ? 1 : 0, dnull_bias ? 1 : 0);
     int rc = check_launch("attn_softmax_bwd(table)");
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_rel_reduce_kernel, dim3((T + 255) / 256), dim3(256), 0, STREAM, partial, drel, dnull_bias, (int)nblk,
+    hipLaunchKernelGGL(attn_rel_reduce_kernel, dim3((T + 3) / 4), dim3(256), 0, STREAM, partial, drel, dnull_bias, (int)nblk,
                        T - h, h);
     return check_launch("attn_softmax_bwd(reduce)");
 }

@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-family-b", action="store_true")
     args = ap.parse_args()
 
     from diffusioniqt_amd import distributed as D, ops, _lib
@@ -183,6 +184,33 @@ def main():
                              heun_steps_per_s=n_edm / dt, patch_steps_per_s=world * B * n_edm / dt,
                              patch_evals_per_s=world * B * (2 * n_edm - 1) / dt)
 
+    # ---------------- Family B: pseudo-3D Unet3D, dim 64, mults (1,2,4), mid + last-level attention, 32^3,
+    #                  same batch: one eval (sampling path: fused MQA attention) and one fwd+bwd; reported beside the headline ----
+    if args.mode == "both" and not args.no_family_b:
+        from diffusioniqt_amd.imagen_video import Unet3D
+        torch.manual_seed(43)
+        u3 = Unet3D(dim=64, dim_mults=(1, 2, 4), channels=1, cond_on_text=False, text_embed_dim=None, lowres_cond=True,
+                    layer_attns=(False, False, True), layer_cross_attns=False, attend_at_middle=True, num_resnet_blocks=2,
+                    attn_pool_text=False).to(device)
+        tb = torch.randn(B, device=device) * 0.5
+        ltb = torch.full((B,), 0.2, device=device)
+
+        def u3_eval():
+            with torch.no_grad():
+                u3(hr, tb, lowres_cond_img=lr, lowres_noise_times=ltb)
+
+        def u3_train():
+            u3.zero_grad(set_to_none=True)
+            u3(hr, tb, lowres_cond_img=lr, lowres_noise_times=ltb).square().mean().backward()
+
+        u3.eval()
+        dte = timed(u3_eval, 2, 4) / 4
+        u3.train()
+        dtt = timed(u3_train, 1, 2) / 2
+        result["unet3d"] = dict(eval_ms=1e3 * dte, eval_patches_per_s=world * B / dte, fwd_bwd_ms=1e3 * dtt,
+                                fwd_bwd_patches_per_s=world * B / dtt)
+        del u3
+
     # ---------------- training: K micro-steps through ImagenTrainer.forward ----------------
     if args.mode in ("train", "both"):
         trainer.training = True
@@ -253,6 +281,9 @@ def main():
             out["train"]["note"] = "ImagenTrainer.forward micro-step: fwd+bwd (558 GFLOP/patch), grad all-reduce + fused Adam every 4th, EMA"
         if "sample" in result:
             out["sample_steps_per_s"] = round(1e3 / result["sample"]["ms_per_step"], 3)
+        if "unet3d" in result:
+            out["unet3d"] = {k: round(v, 3) for k, v in result["unet3d"].items()}
+            out["unet3d"]["note"] = "Family B: Unet3D dim 64, mults (1,2,4), 2 resnet blocks, attention at the last level + middle, 32^3 (190 GFLOP/patch/eval)"
         if "edm" in result:
             out["edm"] = {k: round(v, 3) for k, v in result["edm"].items()}
             out["edm"]["note"] = "ElucidatedImagen.sample (stochastic Heun, 2 U-Net evals per step except the last) driving the same C2 U-Net"

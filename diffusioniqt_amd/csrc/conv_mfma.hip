@@ -42,6 +42,7 @@ struct ConvGeom {
     int nNt, nChunks, CoutPad;
     int HD, HH, HWd;            // halo extents
     unsigned xBytes, yBytes;    // tensor extents for the buffer descriptors (BUF kernels; 0 when >= 1 GiB)
+    float* stats;               // optional per-tile column sums of the output: [B][tiles per batch][2 (sum, sum of squares)][Cout]
     int tilesPerWg;             // forward kernel: consecutive tiles per workgroup
     int stagger;                // experiment: first-round workgroups sleep (slot % stagger) x ~6.4k cycles before starting
     int chunksPerSplit;         // forward split-K over input-channel chunks (grid.y slices; == nChunks when unsplit)
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
         const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
         const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
         const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
+        float cs0 = 0.f, cq0 = 0.f, cs1 = 0.f, cq1 = 0.f;      // column sums for the consumer's GroupNorm / SE pooling
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const unsigned off = (unsigned)out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
@@ -312,6 +314,25 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
             }
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+            if (g.stats && off != BUF_OOB) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
+        }
+        if (g.stats) {             // block-uniform: fixed-order combine of lane halves, then of the 4 waves through LDS
+            cs0 += __shfl_xor(cs0, 32, 64); cq0 += __shfl_xor(cq0, 32, 64);
+            cs1 += __shfl_xor(cs1, 32, 64); cq1 += __shfl_xor(cq1, 32, 64);
+            float* red = halo;     // every wave passed the last tap barrier: the halo image is dead
+            __syncthreads();
+            if (h == 0) {
+                red[(wave * 4 + 0) * 32 + l31] = cs0; red[(wave * 4 + 1) * 32 + l31] = cq0;
+                red[(wave * 4 + 2) * 32 + l31] = cs1; red[(wave * 4 + 3) * 32 + l31] = cq1;
+            }
+            __syncthreads();
+            if (tid < 128) {       // q = tid >> 5: 0 sum(co0) 1 sumsq(co0) 2 sum(co1) 3 sumsq(co1)
+                const int q = tid >> 5, l = tid & 31;
+                const float v = ((red[(0 * 4 + q) * 32 + l] + red[(1 * 4 + q) * 32 + l]) + red[(2 * 4 + q) * 32 + l]) + red[(3 * 4 + q) * 32 + l];
+                const int co = n0 + (q >> 1) * 32 + l;
+                const int tpb = g.tilesD * g.tilesH * g.tilesW, tIn = (tz * g.tilesH + ty) * g.tilesW + tx;
+                if (co < g.Cout) g.stats[(((size_t)b * tpb + tIn) * 2 + (q & 1)) * g.Cout + co] = v;
+            }
         }
     } else
 #pragma unroll
@@ -1303,7 +1324,7 @@ static int make_geom(ConvGeom& g, int B, int D, int H, int W, int Cin, int Cout,
     choose_tile(g.Do, g.Ho, g.Wo, kd, kh, kw, g.TD, g.TH, g.TW);
     g.tilesD = cdiv(g.Do, g.TD); g.tilesH = cdiv(g.Ho, g.TH); g.tilesW = cdiv(g.Wo, g.TW);
     g.nNt = cdiv(Cout, NT); g.CoutPad = g.nNt * NT; g.nChunks = cdiv(Cin, CK);
-    g.chunksPerSplit = g.nChunks; g.slabStride = 0; g.xBytes = 0; g.yBytes = 0; g.tilesPerWg = 1;
+    g.chunksPerSplit = g.nChunks; g.slabStride = 0; g.xBytes = 0; g.yBytes = 0; g.tilesPerWg = 1; g.stats = nullptr;
     { static const int stg = [] { const char* e = getenv("DIQT_CONV_STAGGER"); return e ? atoi(e) : 0; }(); g.stagger = stg; }
     g.HD = g.TD + kd - 1; g.HH = g.TH + kh - 1; g.HWd = g.TW + kw - 1;
     const long long nwg = (long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
@@ -1404,13 +1425,41 @@ extern "C" size_t diqt_conv3d_fwd_workspace_bytes(int B, int D, int H, int W, in
 
 static int conv3d_fwd_impl(const float* x, const float* packed, const float* bias, const float* residual,
                            float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                           int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
+                           int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats);
 
 extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
                                float* y, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
                                int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
     return conv3d_fwd_impl(x, packed, bias, residual, y, nullptr, 0, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph,
-                           epw, stream);
+                           epw, stream, nullptr);
+}
+
+// per-tile output statistics are produced by the buffer-path kernel of an unsplit launch; returns the number of tiles per batch
+// entry (the `nblk` of the [B][nblk][2][Cout] partial layout) or 0 when this shape would take another path
+extern "C" int diqt_conv3d_fwd_stats_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
+                                            int pw, int epd, int eph, int epw) {
+    static const bool off = [] { const char* e = getenv("DIQT_CONV_NOSTATS"); return e && e[0] == '1'; }();
+    static const bool persist_ok = [] { const char* e = getenv("DIQT_CONV_PERSIST"); return e && e[0] == '1'; }();
+    static const bool nobuf = [] { const char* e = getenv("DIQT_CONV_NOBUF"); return e && e[0] == '1'; }();
+    ConvGeom g;
+    if (off || persist_ok || nobuf || make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return 0;
+    if (kd * kh * kw == 1) return 0;                                   // flattened 1x1x1 tiles cross batch entries
+    if (Cin % 4 != 0 || smallcin_pad(Cin, kd * kh * kw) || fwd_ksplit(g) > 1) return 0;
+    const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
+    const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
+    if (xb >= (1ull << 30) || yb >= (1ull << 30)) return 0;
+    const size_t lds = ((size_t)g.HD * g.HH * g.HWd * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int);
+    if (lds > 160 * 1024) return 0;
+    return g.tilesD * g.tilesH * g.tilesW;
+}
+
+extern "C" int diqt_conv3d_fwd_ex(const float* x, const float* packed, const float* bias, const float* residual, float* y,
+                                  float* stats, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin,
+                                  int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
+    DIQT_REQUIRE(!stats || diqt_conv3d_fwd_stats_blocks(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw) > 0,
+                 DIQT_E_UNSUPPORTED, "conv3d_fwd_ex: this shape does not produce output statistics (diqt_conv3d_fwd_stats_blocks == 0)");
+    return conv3d_fwd_impl(x, packed, bias, residual, y, workspace, workspace_bytes, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw,
+                           epd, eph, epw, stream, stats);
 }
 
 extern "C" int diqt_conv3d_fwd_ws(const float* x, const float* packed, const float* bias, const float* residual,
@@ -1418,12 +1467,12 @@ extern "C" int diqt_conv3d_fwd_ws(const float* x, const float* packed, const flo
                                   int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw,
                                   void* stream) {
     return conv3d_fwd_impl(x, packed, bias, residual, y, workspace, workspace_bytes, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph,
-                           pw, epd, eph, epw, stream);
+                           pw, epd, eph, epw, stream, nullptr);
 }
 
 static int conv3d_fwd_impl(const float* x, const float* packed, const float* bias, const float* residual,
                            float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                           int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
+                           int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats) {
     DIQT_REQUIRE(x && packed && y, DIQT_E_ALIGN, "conv3d_fwd: null pointer");
     ConvGeom g;
     int rc = make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
@@ -1527,6 +1576,8 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
                            residual, y, n, g.Cout, ks);
         return check_launch("conv3d_fwd(split-K reduce)");
     }
+    DIQT_REQUIRE(!stats || buf, DIQT_E_UNSUPPORTED, "conv3d_fwd: output statistics need the buffer-path kernel");
+    g.stats = stats;
     hipLaunchKernelGGL(kern, dim3(gridx), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
     return check_launch("conv3d_fwd");
 }

@@ -1287,6 +1287,34 @@ extern "C" int diqt_groupnorm_stats(const float* x, float* mean, float* rstd, vo
     return check_launch("groupnorm_stats/final");
 }
 
+// GroupNorm statistics / channel means from per-tile column sums that a producer kernel (the conv epilogue) already wrote:
+// partial[b][blk][2 (sum, sum of squares)][C]
+extern "C" int diqt_groupnorm_stats_from_partials(const float* partials, float* mean, float* rstd, int B, int nblk, int rows,
+                                                  int C, int G, float eps, void* stream) {
+    DIQT_REQUIRE(partials && mean && rstd, DIQT_E_ALIGN, "groupnorm_stats_from_partials: null pointer");
+    DIQT_REQUIRE(B > 0 && nblk > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "groupnorm_stats_from_partials: bad shape");
+    hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B * G), dim3(64), 0, STREAM, partials, mean, rstd, B, C, G, nblk,
+                       (double)rows * (C / G), eps);
+    return check_launch("groupnorm_stats_from_partials");
+}
+__global__ __launch_bounds__(256) void mean_from_stat_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                      int nblk, int C, int total, float alpha) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wave per (b, c)
+    if (i >= total) return;
+    const int b = i / C, c = i % C;
+    float s = 0.f;
+    for (int k = lane; k < nblk; k += 64) s += partial[(((size_t)b * nblk + k) * 2) * C + c];
+    s = wave_sum(s);
+    if (lane == 0) out[i] = alpha * s;
+}
+extern "C" int diqt_channel_mean_from_partials(const float* partials, float* pooled, int B, int nblk, int rows, int C, void* stream) {
+    DIQT_REQUIRE(partials && pooled, DIQT_E_ALIGN, "channel_mean_from_partials: null pointer");
+    DIQT_REQUIRE(B > 0 && nblk > 0 && rows > 0 && C > 0, DIQT_E_SHAPE, "channel_mean_from_partials: bad shape");
+    hipLaunchKernelGGL(mean_from_stat_partials_kernel, dim3((B * C + 3) / 4), dim3(256), 0, STREAM, partials, pooled, nblk, C, B * C,
+                       1.f / (float)rows);
+    return check_launch("channel_mean_from_partials");
+}
+
 // grid.x for the vectorised GN apply kernels: a multiple of C / gcd(C, 1024) so every thread's channel quad is loop-invariant
 static unsigned gn_grid(size_t per, int C, int B) {
     int a = C, b = 1024;

@@ -188,11 +188,11 @@ class GaussianDiffusionContinuousTimes(nn.Module):
 class Conv3d(nn.Conv3d):
     """nn.Conv3d parameters (OIDHW) + the MFMA implicit-GEMM kernel; grouped/strided -> direct kernel."""
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, want_stats=False):
         if self.groups != 1 or tuple(self.stride) != (1, 1, 1):
             y = ops.conv3d_direct(x, self.weight, self.bias, self.stride, self.padding, self.groups)
             return y if residual is None else ops.add(y, residual)
-        return ops.conv3d(x, self.weight, self.bias, self.padding, residual)
+        return ops.conv3d(x, self.weight, self.bias, self.padding, residual, want_stats=want_stats)
 
 
 class Linear(nn.Linear):
@@ -308,7 +308,8 @@ class Block(nn.Module):
         self.factor = factor
         self.project = Conv3d(dim, dim_out, 3) if boundary else Conv3d(dim, dim_out, 3, padding=1)
 
-    def forward(self, x, scale_shift=None, residual=None):
+    def forward(self, x, scale_shift=None, residual=None, emit_stats=False):
+        """``emit_stats``: the conv epilogue also writes per-tile column sums of its output for the next GroupNorm / SE pool."""
         gn = self.groupnorm
         if isinstance(gn, nn.GroupNorm):
             x = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps)
@@ -317,7 +318,7 @@ class Block(nn.Module):
             x = self.activation(x)
         if self.boundary:
             x = boundary_pad(x, self.factor)
-        return self.project(x, residual=residual)
+        return self.project(x, residual=residual, want_stats=emit_stats)
 
 
 class SE3D(nn.Module):
@@ -363,10 +364,10 @@ class ResnetBlock(nn.Module):
         scale_shift = None
         if exists(self.time_mlp) and exists(time_emb):      # [B, 2C]: scale | shift
             scale_shift = self.time_mlp[1](time_emb.mish()) if isinstance(time_emb, TimeCond) else self.time_mlp(time_emb)
-        h = self.block1(x)
+        h = self.block1(x, emit_stats=True)                  # block2's GroupNorm statistics come from this conv's epilogue
         res = self.res_conv(x)
         if isinstance(self.se, SE3D):
-            h = self.block2(h, scale_shift=scale_shift)
+            h = self.block2(h, scale_shift=scale_shift, emit_stats=True)     # ... and the SE pooling from this one's
             return self.se(h, residual=res)
         return self.block2(h, scale_shift=scale_shift, residual=res)   # residual add fused in the conv epilogue
 

@@ -110,7 +110,16 @@ def _packed(weight5, mode):
     return packed
 
 
-def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0)):
+class ColStats:
+    """Per-tile column sums (sum, sum of squares) of a conv output, written by the conv epilogue: [B, nblk, 2, C].
+    Attached to the output tensor as ``_diqt_stats`` for the consumer's GroupNorm statistics / SE pooling."""
+    __slots__ = ("partials", "nblk", "rows")
+
+    def __init__(self, partials, nblk, rows):
+        self.partials, self.nblk, self.rows = partials, nblk, rows
+
+
+def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0), stats_out=None):
     B, D, H, W, Cin = x5.shape
     kd, kh, kw = k
     pd, ph, pw = pad
@@ -122,7 +131,13 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0)):
         s.record()
     n = _lib.query("diqt_conv3d_fwd_workspace_bytes", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
     ws = _workspace(n, x5.device) if n else None
-    _lib.call("diqt_conv3d_fwd_ws", x5, packed, bias, residual, y, ws, n, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw,
+    stats = None
+    if stats_out is not None:
+        nblk = _lib.query("diqt_conv3d_fwd_stats_blocks", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
+        if nblk > 0:
+            stats = torch.empty((B, nblk, 2, Cout), dtype=torch.float32, device=x5.device)
+            stats_out.append(ColStats(stats, nblk, Do * Ho * Wo))
+    _lib.call("diqt_conv3d_fwd_ex", x5, packed, bias, residual, y, stats, ws, n, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw,
               epd, eph, epw, _stream())
     if TIMER.enabled:
         e.record()
@@ -133,11 +148,11 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0)):
 
 class _Conv3dFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, residual, epad=(0, 0, 0)):
+    def forward(ctx, x, weight, bias, pad, residual, epad=(0, 0, 0), stats_out=None):
         _chk(x, weight, bias, residual)
         Cout, Cin, kd, kh, kw = weight.shape
         assert x.dim() == 5 and x.shape[-1] == Cin, f"conv3d: x {tuple(x.shape)} vs weight {tuple(weight.shape)}"
-        y = _conv_fwd_raw(x, _packed(weight, 0), bias, residual, Cout, (kd, kh, kw), pad, epad)
+        y = _conv_fwd_raw(x, _packed(weight, 0), bias, residual, Cout, (kd, kh, kw), pad, epad, stats_out)
         ctx.save_for_backward(x, weight)
         ctx.pad = pad
         ctx.epad = epad
@@ -173,10 +188,10 @@ class _Conv3dFn(Function):
                 Do, Ho, Wo = dy.shape[1:4]
                 TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_bwd_weight_kernel",
                                       (B, D, H, W, Cin, Cout, kd, kh, kw)))
-        return dx, dw, db, None, (dy if ctx.has_res else None), None
+        return dx, dw, db, None, (dy if ctx.has_res else None), None, None
 
 
-def conv3d(x, weight, bias=None, padding=(0, 0, 0), residual=None, extra_pad=(0, 0, 0)):
+def conv3d(x, weight, bias=None, padding=(0, 0, 0), residual=None, extra_pad=(0, 0, 0), want_stats=False):
     """Stride-1 conv on channels-last x[B,D,H,W,Cin] with an OIDHW weight (MFMA implicit GEMM).
     Filters whose halo tile cannot fit the 160 KiB LDS (e.g. 15^3 cross-embed taps) take the direct kernel."""
     if isinstance(padding, int):
@@ -188,7 +203,13 @@ def conv3d(x, weight, bias=None, padding=(0, 0, 0), residual=None, extra_pad=(0,
     if _lib.query("diqt_conv3d_lds_bytes", D, H, W, kd, kh, kw, *padding, *extra_pad) > 160 * 1024:
         y = _ConvDirectFn.apply(x, weight, bias, (1, 1, 1), padding, 1, extra_pad)
         return y if residual is None else add(y, residual)
-    return _Conv3dFn.apply(x, weight, bias, padding, residual, extra_pad)
+    if not want_stats:
+        return _Conv3dFn.apply(x, weight, bias, padding, residual, extra_pad)
+    holder = []
+    y = _Conv3dFn.apply(x, weight, bias, padding, residual, extra_pad, holder)
+    if holder:
+        y._diqt_stats = holder[0]           # consumed by groupnorm_act / se_gate_residual on this exact tensor
+    return y
 
 
 class _LinearSmallFn(Function):
@@ -273,15 +294,19 @@ def conv3d_direct(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), gro
 # --------------------------------------------------------------------------------------------
 class _GnActFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, groups, act, eps):
+    def forward(ctx, x, gamma, beta, ss, groups, act, eps, pre=None):
         _chk(x, gamma, beta, ss)
         B, C = x.shape[0], x.shape[-1]
         rows = x.numel() // (B * C)
         mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        ws, n = _reduce_ws(B, C, x.device)
         s = _stream()
-        _lib.call("diqt_groupnorm_stats", x, mean, rstd, ws, n, B, rows, C, groups, float(eps), s)
+        if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
+            # the producing conv's epilogue already summed x and x^2 per tile: no pass over x for the statistics
+            _lib.call("diqt_groupnorm_stats_from_partials", pre.partials, mean, rstd, B, pre.nblk, rows, C, groups, float(eps), s)
+        else:
+            ws, n = _reduce_ws(B, C, x.device)
+            _lib.call("diqt_groupnorm_stats", x, mean, rstd, ws, n, B, rows, C, groups, float(eps), s)
         y = torch.empty_like(x)
         scale = shift = None
         cs = 0
@@ -311,12 +336,12 @@ class _GnActFn(Function):
         ws, n = _reduce_ws(B, C, x.device)
         _lib.call("diqt_gn_act_bwd", x, dy, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta, dscale,
                   dshift, ws, n, B, rows, C, groups, act, _stream())
-        return dx, dgamma, dbeta, dss, None, None, None
+        return dx, dgamma, dbeta, dss, None, None, None, None
 
 
 def groupnorm_act(x, gamma, beta, scale_shift=None, groups=8, act=ACT_MISH, eps=1e-5):
     """act(GN(x) * (scale+1) + shift) with scale_shift = one [B, 2C] embedding (scale first)."""
-    return _GnActFn.apply(x, gamma, beta, scale_shift, groups, act, eps)
+    return _GnActFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None))
 
 
 class _ActFn(Function):
@@ -408,7 +433,7 @@ def learned_sinusoidal(t, w):
 # --------------------------------------------------------------------------------------------
 class _SEResidualFn(Function):
     @staticmethod
-    def forward(ctx, h, w1, w2, res):
+    def forward(ctx, h, w1, w2, res, pre=None):
         _chk(h, w1, w2, res)
         B, C = h.shape[0], h.shape[-1]
         rows = h.numel() // (B * C)
@@ -416,8 +441,11 @@ class _SEResidualFn(Function):
         dev = h.device
         s = _stream()
         pooled = torch.empty((B, C), dtype=torch.float32, device=dev)
-        ws, n = _reduce_ws(B, C, dev)
-        _lib.call("diqt_channel_mean", h, pooled, ws, n, B, rows, C, s)
+        if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
+            _lib.call("diqt_channel_mean_from_partials", pre.partials, pooled, B, pre.nblk, rows, C, s)
+        else:
+            ws, n = _reduce_ws(B, C, dev)
+            _lib.call("diqt_channel_mean", h, pooled, ws, n, B, rows, C, s)
         hidden = torch.empty((B, Cr), dtype=torch.float32, device=dev)
         gate = torch.empty((B, C), dtype=torch.float32, device=dev)
         _lib.call("diqt_se_mlp_fwd", pooled, w1, w2, hidden, gate, B, C, Cr, s)
@@ -445,12 +473,12 @@ class _SEResidualFn(Function):
         _lib.call("diqt_se_mlp_bwd", pooled, w1, w2, hidden, gate, dgate, dpooled, dw1, dw2, scratch, B, C, Cr, s)
         dh = torch.empty_like(h)
         _lib.call("diqt_gate_residual_fwd", dy, gate, None, dpooled, 1.0 / rows, dh, B, rows, C, s)
-        return dh, dw1, dw2, (dy if ctx.has_res else None)
+        return dh, dw1, dw2, (dy if ctx.has_res else None), None
 
 
 def se_gate_residual(h, w1, w2, res=None):
     """h * sigmoid(relu(mean(h) w1^T) w2^T) + res."""
-    return _SEResidualFn.apply(h, w1, w2, res)
+    return _SEResidualFn.apply(h, w1, w2, res, getattr(h, "_diqt_stats", None))
 
 
 class _AddFn(Function):

@@ -72,6 +72,20 @@ int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, cons
                     float* y, int B, int D, int H, int W, int Cin, int Cout,
                     int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
 
+/* Forward conv that also emits per-tile column sums of its OUTPUT for the consumer's GroupNorm statistics / SE pooling
+ * (Block -> Block and Block -> SE3D inside ResnetBlock, imagen_pytorch3D.py:568-632): stats[B][nblk][2][Cout] =
+ * (sum, sum of squares) over the valid voxels of each output tile, nblk = diqt_conv3d_fwd_stats_blocks(...) (0: this shape
+ * takes a path without statistics and `stats` must be NULL).  Saves one full read of the tensor per consumer.            */
+int diqt_conv3d_fwd_stats_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                 int epd, int eph, int epw);
+int diqt_conv3d_fwd_ex(const float* x, const float* packed, const float* bias, const float* residual, float* y, float* stats,
+                       void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                       int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
+/* consumers of such partials */
+int diqt_groupnorm_stats_from_partials(const float* partials, float* mean, float* rstd, int B, int nblk, int rows_per_batch,
+                                       int C, int G, float eps, void* stream);
+int diqt_channel_mean_from_partials(const float* partials, float* pooled, int B, int nblk, int rows_per_batch, int C, void* stream);
+
 /* Same operator with a caller-owned workspace: launches too small to fill the chip (8^3 / 16^3 levels) slice the
  * input-channel chunks over grid.y into output slabs and a second kernel sums them (+ bias + residual) in a fixed
  * order.  diqt_conv3d_fwd_workspace_bytes() returns 0 when the shape is not split.                              */

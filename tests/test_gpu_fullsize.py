@@ -104,3 +104,33 @@ def test_backward_is_run_to_run_deterministic(c2):
     bad = [n for n in grads[0] if not torch.equal(grads[0][n], grads[1][n])]
     assert not bad, f"non-deterministic gradients: {bad[:5]}"
     assert all(torch.isfinite(g).all() for g in grads[0].values())
+
+
+def test_c2_sampling_and_training_flow_full_size():
+    """BASELINE config 2 end to end: a 32-step ancestral sample of 8 patches and 8 ImagenTrainer micro-steps (two optimiser
+    steps at gradient_accumulation_steps = 4).  Finite everywhere, sample respects the floor, weights move only on sync steps."""
+    from bench import unet_kwargs
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256, Imagen, NullUnet
+    from diffusioniqt_amd.trainer import ImagenTrainer
+    torch.manual_seed(42)
+    configs = {'Data': {'norm': 'z-score'}, 'Train': {'batch_sample': False, 'patch_size_sub': 32, 'pred_obj': 'x_start'}, 'Eval': {'repeat': 1}}
+    mb = (0. - 271.64814106698583) / 377.117173547721
+    imagen = Imagen(unets=(NullUnet(), SRUnet256(**unet_kwargs(32))), configs=configs, min_bound=mb, image_sizes=(32, 32), channels=1,
+                    pred_objectives='x_start', timesteps=32, dynamic_thresholding=False, p2_loss_weight_gamma=0.0,
+                    cond_drop_prob=0.0).to(DEV)
+    trainer = ImagenTrainer(configs=configs, imagen=imagen, gradient_accumulation_steps=4, verbose=False)
+    g = torch.Generator().manual_seed(1)
+    hr = torch.randn(8, 1, 32, 32, 32, generator=g).to(DEV)
+    lr = torch.randn(8, 1, 32, 32, 32, generator=g).to(DEV)
+    w = imagen.unets[1].final_conv.weight
+    snaps, losses = [w.detach().clone()], []
+    for _ in range(8):
+        loss, pred, x_noisy, _ = trainer.forward(hr, lowres_img=lr, unet_number=2, max_batch_size=8)
+        losses.append(loss)
+        snaps.append(w.detach().clone())
+    assert all(np.isfinite(l) for l in losses)
+    changed = [not torch.equal(a, b) for a, b in zip(snaps[:-1], snaps[1:])]
+    assert changed == [False, False, False, True, False, False, False, True], changed       # Adam on every 4th micro-step
+    img, noisy, x0 = trainer.sample(batch_size=8, start_image_or_video=lr, start_at_unet_number=2, use_tqdm=False)
+    assert img.shape == (8, 1, 32, 32, 32) and torch.isfinite(img).all() and img.min().item() >= mb - 1e-6
+    assert len(noisy) == 33 and len(x0) == 33 and all(np.isfinite(a).all() for a in noisy)

@@ -1693,6 +1693,54 @@ __global__ __launch_bounds__(256) void pw_reduce_kernel(const float* __restrict_
     }
 }
 
+// ---- <= 4 input channels (init convs, Family-B cross-embed): dW through an explicit im2col + split-K GEMM.  col[v][k], k = tap*CINP+ci
+//      (the tap-packed K of conv_fwd_smallcin_kernel), then dW'[k][co] = sum_v col[v][k] dY[v][co]. ----
+__global__ __launch_bounds__(256) void im2col_smallcin_kernel(const float* __restrict__ x, float* __restrict__ col, ConvGeom g,
+                                                              int CINP, int Kp, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % Kp);
+        size_t v = i / Kp;
+        const int ow = (int)(v % g.Wo); v /= g.Wo;
+        const int oh = (int)(v % g.Ho); v /= g.Ho;
+        const int od = (int)(v % g.Do);
+        const int b = (int)(v / g.Do);
+        const int tap = k / CINP, ci = k % CINP;
+        const int kx = tap % g.kw, ky = (tap / g.kw) % g.kh, kz = tap / (g.kw * g.kh);
+        const int iz = od + kz - g.pd, iy = oh + ky - g.ph, ix = ow + kx - g.pw;
+        float val = 0.f;
+        if (ci < g.Cin && iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+            val = x[((((size_t)b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin + ci];
+        col[i] = val;
+    }
+}
+// dw[co][ci][tap] = sum_s slab[s][k = tap*CINP+ci][co]
+__global__ __launch_bounds__(256) void smallcin_dw_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cout,
+                                                                 int Cin, int T, int CINP, int Kp, int ks) {
+    const int total = Cout * Cin * T;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int tap = i % T, ci = (i / T) % Cin, co = i / (T * Cin);
+        const size_t src = (size_t)(tap * CINP + ci) * Cout + co;
+        float s = 0.f;
+        for (int k = 0; k < ks; ++k) s += slabs[(size_t)k * Kp * Cout + src];
+        dw[i] = s;
+    }
+}
+struct ScPlan { bool ok; int CINP, Kp, ks; long long V; };
+static ScPlan sc_plan(const ConvGeom& g) {
+    ScPlan p{};
+    const int T = g.kd * g.kh * g.kw;
+    p.CINP = smallcin_pad(g.Cin, T);
+    p.V = (long long)g.B * g.Do * g.Ho * g.Wo;
+    p.ok = p.CINP > 0 && p.V >= 4096 && p.V < (1ll << 31);
+    if (!p.ok) return p;
+    p.Kp = T * p.CINP;
+    const int tiles = cdiv(p.Kp, p.Kp > 64 ? 128 : 64) * cdiv(g.Cout, 64);
+    int ks = 1;
+    while (ks * 2 * tiles <= 256 && p.V % (ks * 2) == 0 && p.V / (ks * 2) >= 256) ks *= 2;
+    p.ks = ks;
+    return p;
+}
+
 extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd,
                                                          int kh, int kw, int pd, int ph, int pw, int epd, int eph,
                                                          int epw) {
@@ -1715,6 +1763,11 @@ extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, in
     if (Cout == 1 && kd * kh * kw == 1) {
         const size_t red = diqt_reduce_workspace_bytes(1, Cin);
         if (red > need) need = red;
+    }
+    const ScPlan sp = sc_plan(bg.g);
+    if (sp.ok) {
+        const size_t sc = ((size_t)sp.V * sp.Kp + (size_t)sp.ks * sp.Kp * Cout) * sizeof(float);
+        if (sc > need) need = sc;
     }
     return need > colsum ? need : colsum;
 }
@@ -1747,6 +1800,35 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
             rc = check_launch("colsum_stage1");
             if (rc) return rc;
             hipLaunchKernelGGL(colsum_stage2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, dbias, (int)nblk, 1);
+            rc = check_launch("colsum_stage2");
+        }
+        return rc;
+    }
+    const ScPlan sp = sc_plan(g);
+    if (sp.ok) {
+        float* col = static_cast<float*>(workspace);
+        float* slabs = col + (size_t)sp.V * sp.Kp;
+        const size_t total = (size_t)sp.V * sp.Kp;
+        hipLaunchKernelGGL(im2col_smallcin_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, col, g,
+                           sp.CINP, sp.Kp, total);
+        rc = check_launch("conv3d_bwd_weight(im2col)");
+        if (rc) return rc;
+        const long long kslice = sp.V / sp.ks;
+        rc = diqt_bgemm(col, dy, slabs, sp.ks, sp.Kp, Cout, (int)kslice, 1, 0, kslice * sp.Kp, kslice * Cout, (long long)sp.Kp * Cout,
+                        sp.Kp, Cout, Cout, 1.f, 0.f, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(smallcin_dw_reduce_kernel, dim3(grid_for((size_t)Cout * Cin * T, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
+                           slabs, dw, Cout, Cin, T, sp.CINP, sp.Kp, sp.ks);
+        rc = check_launch("conv3d_bwd_weight(small Cin reduce)");
+        if (rc) return rc;
+        if (dbias) {
+            const size_t rows = (size_t)sp.V;
+            unsigned nblk = (unsigned)((rows + 15) / 16);
+            if (nblk > 1024) nblk = 1024;
+            hipLaunchKernelGGL(colsum_stage1_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), (hipStream_t)stream, dy, col, rows, Cout);
+            rc = check_launch("colsum_stage1");
+            if (rc) return rc;
+            hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(Cout, 4)), dim3(256), 0, (hipStream_t)stream, col, dbias, (int)nblk, Cout);
             rc = check_launch("colsum_stage2");
         }
         return rc;

@@ -60,6 +60,8 @@ CONV_CASES = [
     (1, (8, 8, 8), 3, 70, (3, 3, 3), (1, 1, 1)),           # Cin = 3 padded to 4, two N tiles
     (2, (8, 8, 8), 24, 2, (3, 3, 3), (1, 1, 1)),           # Cout = 2: the backward-data pass is a tap-packed conv
     (1, (6, 8, 8), 4, 8, (1, 7, 7), (0, 3, 3)),            # Cin = 4 (1,7,7)
+    (2, (16, 16, 16), 2, 24, (3, 3, 3), (1, 1, 1)),        # Cin = 2 with >= 4096 voxels: dW through im2col + split-K GEMM (K' = 54)
+    (1, (4, 32, 32), 3, 20, (1, 7, 7), (0, 3, 3)),         # ... Cin = 3 padded to 4, K' = 196 (128-row tiles)
     (2, (16, 16, 16), 128, 64, (1, 1, 1), (0, 0, 0)),      # 1x1x1 with many voxels: dW through the split-K GEMM (x on the M side)
     (1, (16, 16, 16), 64, 192, (1, 1, 1), (0, 0, 0)),      # ... dY on the M side
     (2, (8, 16, 16), 72, 40, (1, 1, 1), (0, 0, 0)),        # ... channel counts that are not multiples of the tile

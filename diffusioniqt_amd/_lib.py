@@ -36,6 +36,8 @@ PROTOTYPES = {
     "diqt_conv3d_direct_fwd": (I, [P, P, P, P] + [I] * 19 + [P]),
     "diqt_conv3d_direct_bwd_data": (I, [P, P, P] + [I] * 19 + [P]),
     "diqt_conv3d_direct_bwd_weight": (I, [P, P, P, P] + [I] * 19 + [P]),
+    "diqt_conv3d_direct_bwd_weight_workspace_bytes": (Z, [I] * 19),
+    "diqt_conv3d_direct_bwd_weight_ws": (I, [P, P, P, P, P, Z] + [I] * 19 + [P]),
     "diqt_reduce_workspace_bytes": (Z, [I, I]),
     "diqt_groupnorm_stats": (I, [P, P, P, P, Z, I, I, I, I, F, P]),
     "diqt_gn_act_fwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),

@@ -79,10 +79,12 @@ __global__ __launch_bounds__(256) void direct_bwd_data_kernel(const float* __res
     }
 }
 
-// grid.x: weight elements (co fastest) ; grid.y: voxel slices ; atomics into zeroed dw / dbias
+// grid.x: weight elements (co fastest) ; grid.y: voxel slices.  part == NULL: atomics into zeroed dw / dbias (no workspace);
+// otherwise every slice writes part[slice][nW (+ Cout bias sums)] and direct_dw_reduce_kernel sums the slices in a fixed order.
+// Voxel coordinates are advanced incrementally (no div/mod per voxel).
 __global__ __launch_bounds__(256) void direct_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                 float* __restrict__ dw, float* __restrict__ dbias,
-                                                                DGeom g) {
+                                                                float* __restrict__ part, DGeom g) {
     const int cig = g.Cin / g.groups, cog = g.Cout / g.groups, T = g.kd * g.kh * g.kw;
     const size_t nW = (size_t)g.Cout * cig * T;
     const size_t widx = blockIdx.x * (size_t)256 + threadIdx.x;
@@ -100,20 +102,37 @@ __global__ __launch_bounds__(256) void direct_bwd_weight_kernel(const float* __r
     size_t v1 = v0 + per;
     if (v1 > nvox) v1 = nvox;
     float acc = 0.f, bacc = 0.f;
+    size_t q = v0;
+    int ow = (int)(q % g.Wo); q /= g.Wo;
+    int oh = (int)(q % g.Ho); q /= g.Ho;
+    int od = (int)(q % g.Do);
+    int b = (int)(q / g.Do);
     for (size_t v = v0; v < v1; ++v) {
-        size_t q = v;
-        const int ow = (int)(q % g.Wo); q /= g.Wo;
-        const int oh = (int)(q % g.Ho); q /= g.Ho;
-        const int od = (int)(q % g.Do);
-        const int b = (int)(q / g.Do);
         const float d = dy[v * g.Cout + co];
         if (tap == 0 && cl == 0) bacc += d;
         const int iz = od * g.sd - g.pd + kz, iy = oh * g.sh - g.ph + ky, ix = ow * g.sw - g.pw + kx;
-        if (iz < 0 || iz >= g.D || iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) continue;
-        acc += d * x[((((size_t)b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin + ci];
+        if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+            acc = fmaf(d, x[((((size_t)b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin + ci], acc);
+        if (++ow == g.Wo) { ow = 0; if (++oh == g.Ho) { oh = 0; if (++od == g.Do) { od = 0; ++b; } } }
     }
-    atomicAdd(dw + ((size_t)co * cig + cl) * T + tap, acc);
-    if (dbias && tap == 0 && cl == 0) atomicAdd(dbias + co, bacc);
+    const size_t dst = ((size_t)co * cig + cl) * T + tap;
+    if (part) {
+        float* ps = part + (size_t)blockIdx.y * (nW + g.Cout);
+        ps[dst] = acc;
+        if (tap == 0 && cl == 0) ps[nW + co] = bacc;
+    } else {
+        atomicAdd(dw + dst, acc);
+        if (dbias && tap == 0 && cl == 0) atomicAdd(dbias + co, bacc);
+    }
+}
+__global__ __launch_bounds__(256) void direct_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, size_t nW, int Cout, int slices) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i >= nW + Cout) return;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += part[(size_t)k * (nW + Cout) + i];
+    if (i < nW) dw[i] = s;
+    else if (dbias) dbias[i - nW] = s;
 }
 
 static int dgeom(DGeom& g, int B, int D, int H, int W, int Cin, int Cout, int groups, int kd, int kh, int kw, int sd,
@@ -153,22 +172,54 @@ extern "C" int diqt_conv3d_direct_bwd_data(const float* dy, const float* w, floa
     hipLaunchKernelGGL(direct_bwd_data_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream, dy, w, dx, g);
     return check_launch("conv3d_direct_bwd_data");
 }
-extern "C" int diqt_conv3d_direct_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int D,
-                                             int H, int W, int Cin, int Cout, int groups, int kd, int kh, int kw,
-                                             int sd, int sh, int sw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
+static unsigned direct_slices(size_t nvox) {
+    unsigned slices = (unsigned)((nvox + 255) / 256);
+    if (slices > 256) slices = 256;
+    return slices < 1 ? 1 : slices;
+}
+extern "C" size_t diqt_conv3d_direct_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int groups, int kd,
+                                                                int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                                                                int epd, int eph, int epw) {
+    DGeom g;
+    if (dgeom(g, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw, epd, eph, epw)) return 0;
+    const size_t nW = (size_t)Cout * (Cin / groups) * kd * kh * kw;
+    return (size_t)direct_slices((size_t)g.B * g.Do * g.Ho * g.Wo) * (nW + Cout) * sizeof(float);
+}
+static int direct_bwd_weight_impl(const float* x, const float* dy, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                                  int B, int D, int H, int W, int Cin, int Cout, int groups, int kd, int kh, int kw, int sd, int sh,
+                                  int sw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
     DIQT_REQUIRE(x && dy && dw, DIQT_E_ALIGN, "conv3d_direct_bwd_weight: null pointer");
     DGeom g;
     int rc = dgeom(g, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw, epd, eph, epw);
     if (rc) return rc;
     const size_t nW = (size_t)Cout * (Cin / groups) * kd * kh * kw;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dw, 0, nW * sizeof(float), s);
-    if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
-    DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_direct_bwd_weight: memset: %s", hipGetErrorString(e));
     const size_t nvox = (size_t)g.B * g.Do * g.Ho * g.Wo;
-    unsigned slices = (unsigned)((nvox + 255) / 256);
-    if (slices > 256) slices = 256;
-    if (slices < 1) slices = 1;
-    hipLaunchKernelGGL(direct_bwd_weight_kernel, dim3((unsigned)((nW + 255) / 256), slices), dim3(256), 0, s, x, dy, dw, dbias, g);
-    return check_launch("conv3d_direct_bwd_weight");
+    const unsigned slices = direct_slices(nvox);
+    float* part = nullptr;
+    if (workspace && workspace_bytes >= (size_t)slices * (nW + Cout) * sizeof(float)) part = static_cast<float*>(workspace);
+    if (!part) {
+        hipError_t e = hipMemsetAsync(dw, 0, nW * sizeof(float), s);
+        if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
+        DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_direct_bwd_weight: memset: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(direct_bwd_weight_kernel, dim3((unsigned)((nW + 255) / 256), slices), dim3(256), 0, s, x, dy, dw, dbias, part, g);
+    rc = check_launch("conv3d_direct_bwd_weight");
+    if (rc || !part) return rc;
+    hipLaunchKernelGGL(direct_dw_reduce_kernel, dim3((unsigned)((nW + Cout + 255) / 256)), dim3(256), 0, s, part, dw, dbias, nW, Cout,
+                       (int)slices);
+    return check_launch("conv3d_direct_bwd_weight(reduce)");
+}
+extern "C" int diqt_conv3d_direct_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int D,
+                                             int H, int W, int Cin, int Cout, int groups, int kd, int kh, int kw,
+                                             int sd, int sh, int sw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
+    return direct_bwd_weight_impl(x, dy, dw, dbias, nullptr, 0, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw, pd, ph, pw, epd,
+                                  eph, epw, stream);
+}
+extern "C" int diqt_conv3d_direct_bwd_weight_ws(const float* x, const float* dy, float* dw, float* dbias, void* workspace,
+                                                size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout, int groups,
+                                                int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int epd,
+                                                int eph, int epw, void* stream) {
+    return direct_bwd_weight_impl(x, dy, dw, dbias, workspace, workspace_bytes, B, D, H, W, Cin, Cout, groups, kd, kh, kw, sd, sh, sw,
+                                  pd, ph, pw, epd, eph, epw, stream);
 }

@@ -280,7 +280,9 @@ class _ConvDirectFn(Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            _lib.call("diqt_conv3d_direct_bwd_weight", x, dy, dw, db, *ctx.geom, _stream())
+            nws = _lib.query("diqt_conv3d_direct_bwd_weight_workspace_bytes", *ctx.geom)
+            ws = _workspace(nws, x.device) if nws else None
+            _lib.call("diqt_conv3d_direct_bwd_weight_ws", x, dy, dw, db, ws, nws, *ctx.geom, _stream())
         return dx, dw, db, None, None, None, None
 
 

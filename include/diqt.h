@@ -124,6 +124,13 @@ int diqt_conv3d_direct_bwd_weight(const float* x, const float* dy, float* dw, fl
                                   int B, int D, int H, int W, int Cin, int Cout, int groups,
                                   int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
                                   int epd, int eph, int epw, void* stream);
+/* Same gradients reduced over the voxel slices in a fixed order through `workspace` (no atomics: bit-reproducible). */
+size_t diqt_conv3d_direct_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int groups, int kd, int kh,
+                                                     int kw, int sd, int sh, int sw, int pd, int ph, int pw, int epd, int eph, int epw);
+int diqt_conv3d_direct_bwd_weight_ws(const float* x, const float* dy, float* dw, float* dbias, void* workspace,
+                                     size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout, int groups,
+                                     int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, int epd, int eph,
+                                     int epw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm + (scale+1)*x+shift + activation  — Block.forward imagen_pytorch3D.py:555-562,

@@ -91,6 +91,12 @@ PROTOTYPES = {
     "diqt_patch_scatter": (I, [P, P, P, P, I, I, I, I, I, P]),
     "diqt_background_reset": (I, [P, P, Z, F, F, F, P]),
     "diqt_min_value": (I, [P, Z, P, P, P]),
+    "diqt_patch_pair_crop_workspace_bytes": (Z, [I, I]),
+    "diqt_patch_pair_crop": (I, [P, P, P, P, P, P, Z, I, I, I, I, I, I, I, F, F, P]),
+    "diqt_minmax": (I, [P, Z, P, P, P]),
+    "diqt_psnr": (I, [P, P, Z, P, F, P, P, P]),
+    "diqt_ssim3d_workspace_bytes": (Z, [I, I, I, I, I]),
+    "diqt_ssim3d": (I, [P, P, I, I, I, I, P, I, P, F, F, F, P, Z, P, P]),
     "diqt_abs_quantile": (I, [P, P, I, Z, ctypes.c_uint, F, P]),
     "diqt_dynamic_threshold": (I, [P, P, P, I, Z, P]),
     "diqt_mask_blend": (I, [P, P, P, P, Z, P]),

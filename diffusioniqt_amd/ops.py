@@ -1151,3 +1151,49 @@ def min_value(x):
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     _lib.call("diqt_min_value", x, x.numel(), ws, out, _stream())
     return out
+
+
+def patch_pair_crop(lr_vols, hr_vols, sel, P, mode, mean, std):
+    """data.py:119-132: crop + normalise ``sel[n] = (volume, i0, j0, k0)`` patch pairs out of the HBM-resident [V,D,H,W]
+    volume stacks in one launch.  Returns (lr [n,P,P,P], hr [n,P,P,P])."""
+    _chk(lr_vols, hr_vols)
+    V, D, H, W = lr_vols.shape
+    n = sel.shape[0]
+    lr = torch.empty(n, P, P, P, device=lr_vols.device, dtype=torch.float32)
+    hr = torch.empty_like(lr)
+    nws = _lib.query("diqt_patch_pair_crop_workspace_bytes", n, P) if mode == 1 else 0
+    ws = _workspace(nws, lr_vols.device) if nws else None
+    _lib.call("diqt_patch_pair_crop", lr_vols, hr_vols, sel, lr, hr, ws, nws, n, V, D, H, W, P, int(mode), float(mean), float(std),
+              _stream())
+    return lr, hr
+
+
+def minmax(x):
+    """Device [2] tensor {min, max} of x (no host sync)."""
+    _chk(x)
+    out = torch.empty(2, device=x.device, dtype=torch.float32)
+    _lib.call("diqt_minmax", x, x.numel(), _workspace(8192, x.device), out, _stream())
+    return out
+
+
+def psnr(pred, target, stats=None, data_range=1.0):
+    """Device [2] tensor {mse, PSNR}; ``stats`` = device [4] {pred min, max, target min, max} for min-max normalisation."""
+    _chk(pred, target)
+    out = torch.empty(2, device=pred.device, dtype=torch.float32)
+    _lib.call("diqt_psnr", pred, target, pred.numel(), stats, float(data_range), _workspace(8192, pred.device), out, _stream())
+    return out
+
+
+def ssim3d(pred, target, taps, stats=None, data_range=1.0, k1=0.01, k2=0.03):
+    """pred/target: contiguous [N, D, H, W]; taps: host float32 numpy array (odd length <= 11).  Device [1] tensor."""
+    import ctypes
+    _chk(pred, target)
+    N, D, H, W = pred.shape
+    K = int(taps.shape[0])
+    nws = _lib.query("diqt_ssim3d_workspace_bytes", N, D, H, W, K)
+    if nws == 0:
+        raise RuntimeError(f"ssim3d: volume {D}x{H}x{W} smaller than the {K}-tap filter")
+    out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    _lib.call("diqt_ssim3d", pred, target, N, D, H, W, taps.ctypes.data_as(ctypes.c_void_p), K, stats, float(data_range), float(k1),
+              float(k2), _workspace(nws, pred.device), nws, out, _stream())
+    return out

@@ -537,8 +537,8 @@ class ImagenTrainer(nn.Module):
                     else:
                         pred_merge, hr_merge = pred, hr_data
                     if self.configs['Train']['pred_obj'] == 'x_start':
-                        ssims.append(np.asarray(SSIM(pred_merge.cpu(), hr_merge.cpu())))
-                        psnrs.append(np.asarray(PSNR(pred_merge.cpu(), hr_merge.cpu())))
+                        ssims.append(np.asarray(SSIM(pred_merge, hr_merge).cpu()))         # on the device; scalars come back
+                        psnrs.append(np.asarray(PSNR(pred_merge, hr_merge).cpu()))
                     if r < 2:
                         preds.append(pred.cpu().numpy())
                         condi1.append(x_noisy.cpu().numpy())

@@ -305,6 +305,27 @@ int diqt_background_reset(float* pred, const float* vol, size_t n, float mean, f
 /* out[0] = min(x[0..n)); workspace: 1024 floats */
 int diqt_min_value(const float* x, size_t n, float* workspace_1024, float* out, void* stream);
 
+/* ---- training data path + validation metrics on the device ----------------------------------------------
+ * data.py:88-137 supervisedIQT.__getitem__: crop a P^3 patch pair out of HBM-resident [V][D][H][W] low-res / high-res volume
+ * stacks at sel[n] = {volume, i0, j0, k0} and normalise it: mode 0 (v - mean) / std, mode 1 2*((v - min)/(max - min) - 0.5)
+ * with the patch's own extrema (data.py:82-86).  Outputs are [n][P][P][P].  The workspace is only read in mode 1. */
+size_t diqt_patch_pair_crop_workspace_bytes(int n_patches, int P);
+int diqt_patch_pair_crop(const float* lr_vols, const float* hr_vols, const int* sel, float* lr_out, float* hr_out, void* workspace,
+                         size_t workspace_bytes, int n_patches, int V, int D, int H, int W, int P, int mode, float mean, float stdv,
+                         void* stream);
+/* out2 = {min, max} of x[0..n).  workspace: 8 KiB. */
+int diqt_minmax(const float* x, size_t n, void* workspace_8k, float* out2, void* stream);
+/* metrics.py:19-23 PSNR -> torchmetrics 0.9.0 peak_signal_noise_ratio(data_range): out2 = {mse, 10 log10(range^2 / mse)} of
+ * the tensors after the optional min-max normalisation stats4 = {pred min, pred max, target min, target max} (device, or NULL). */
+int diqt_psnr(const float* pred, const float* target, size_t n, const float* stats4, float data_range, void* workspace_8k,
+              float* out2, void* stream);
+/* metrics.py:25-31 SSIM -> torchmetrics 0.9.0 StructuralSimilarityIndexMeasure on N volumes [D][H][W] (N = batch * channels):
+ * K-tap separable Gaussian (taps: HOST pointer, K odd <= 11), constants (k1 range)^2 / (k2 range)^2, mean of the SSIM map over
+ * the windows that survive torchmetrics' reflect-pad + crop (= the windows fully inside the volume).  out[0] = SSIM. */
+size_t diqt_ssim3d_workspace_bytes(int N, int D, int H, int W, int K);
+int diqt_ssim3d(const float* pred, const float* target, int N, int D, int H, int W, const float* taps, int K, const float* stats4,
+                float data_range, float k1, float k2, void* workspace, size_t workspace_bytes, float* out, void* stream);
+
 /* Gradient accumulation (accelerate's accumulate()/DDP no_sync, trainer.py:300,1118): the per-parameter gradients of one
  * micro-step are added into the flat gradient arena in ONE launch.  table[t] = {src device pointer, dst element offset,
  * element count} (3 x int64, device memory); every tensor gets `blocks_per_tensor` workgroups.                    */

@@ -234,3 +234,58 @@ def test_edm_drives_the_true_conv3d_unet_superset():
         ref = OB.edm_sample(fn, (1, 1, 8, 8, 8), noise[1], noise[2:], dict(OB.EDM_DEFAULTS, num_sample_steps=3))
     err = (img.cpu() - ref).abs()
     assert err.max().item() <= 5e-3 and (err > 2e-4).float().mean().item() < 0.03, err.max().item()
+
+
+def named_unet(g, keys, shapes, kwargs, seed):
+    from diffusioniqt_amd.imagen_video import Unet3D
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(str(g[kwargs])).items()}
+    unet = Unet3D(**kw)
+    assert list(unet.state_dict().keys()) == [str(k) for k in g[keys]]
+    assert [tuple(v.shape) for v in unet.state_dict().values()] == [tuple(json.loads(str(s))) for s in g[shapes]]
+    unet.load_state_dict(O.hash_fill_state_dict(unet.state_dict(), seed))
+    return unet, kw
+
+
+def sample_err(img, ref):
+    err = (img.detach().cpu() - ref).abs()
+    return err.max().item(), (err > 2e-4).float().mean().item()
+
+
+def test_c1_exact_config_matches_reference_golden():
+    """BASELINE.json configs[0] exactly: Unet3D dim 32 / 16^3 / 10 EDM steps (19 evals, dynamic thresholding
+    at the reference default), same weights and noise draws as the reference run that made tests/golden/edm_c1.npz."""
+    from diffusioniqt_amd.imagen_video import Unet3D
+    from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
+    g = load_golden('edm_c1')
+    sr, kw = named_unet(g, 'keys', 'shapes', 'kwargs_sr', 21)
+    assert sum(p.numel() for p in sr.parameters()) == int(g['n_params']) == 4712921
+    base = Unet3D(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(str(g['kwargs_base'])).items()})
+    elu = ElucidatedImagen(unets=(base, sr), image_sizes=(16, 16), channels=1, condition_on_text=False, auto_normalize_img=False,
+                           cond_drop_prob=0.0, num_sample_steps=10).to(DEV)
+    img = elu.sample(batch_size=1, video_frames=16, start_image_or_video=T(g['lowres']).to(DEV), start_at_unet_number=2,
+                     use_tqdm=False, noise=list(T(g['draws'])))
+    assert tuple(img.shape) == (1, 1, 16, 16, 16)
+    mx, frac = sample_err(img, T(g['img']))
+    assert mx <= 5e-3 and frac < 0.03, (mx, frac)
+
+
+def test_c5_cascade_layouts_match_reference_golden():
+    """BASELINE.json configs[4] layouts at 8^3 -> 16^3: full two-stage cascade (temporal_downsample_factor (2,1), nearest
+    resize between the stages) and start_at_unet_number=2 from an 8^3 volume; fixtures from the real reference."""
+    from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
+    g = load_golden('edm_cascade')
+    u1, _ = named_unet(g, 'keys1', 'shapes1', 'kwargs1', 22)
+    u2, _ = named_unet(g, 'keys2', 'shapes2', 'kwargs2', 23)
+    elu = ElucidatedImagen(unets=(u1, u2), image_sizes=(8, 16), channels=1, condition_on_text=False, auto_normalize_img=False,
+                           cond_drop_prob=0.0, num_sample_steps=3, temporal_downsample_factor=(2, 1)).to(DEV)
+    outs = elu.sample(batch_size=1, video_frames=16, return_all_unet_outputs=True, use_tqdm=False,
+                      noise=list(T(g['draws1'])) + list(T(g['draws2'])))
+    assert tuple(outs[0].shape) == (1, 1, 8, 8, 8) and tuple(outs[1].shape) == (1, 1, 16, 16, 16)
+    mx, frac = sample_err(outs[0], T(g['stage1']))
+    assert mx <= 5e-3 and frac < 0.03, ("stage1", mx, frac)
+    mx, frac = sample_err(outs[1], T(g['stage2']))
+    assert mx <= 1e-2 and frac < 0.05, ("stage2", mx, frac)         # stage 2 is conditioned on stage 1's own round-off
+    img = elu.sample(batch_size=1, video_frames=16, start_image_or_video=T(g['lowres']).to(DEV), start_at_unet_number=2,
+                     use_tqdm=False, noise=list(T(g['draws3'])))
+    mx, frac = sample_err(img, T(g['img_from2']))
+    assert mx <= 5e-3 and frac < 0.03, ("from2", mx, frac)

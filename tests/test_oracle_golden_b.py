@@ -89,3 +89,52 @@ def test_edm_training_loss_and_grads():
         if k.startswith('grad:'):
             ref, got = T(g[k]), sdg[k[5:]].grad
             assert (got - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-7, k
+
+
+def build_named(g, keys, shapes, kwargs, seed):
+    ks = [str(k) for k in g[keys]]
+    shp = [tuple(json.loads(str(s))) for s in g[shapes]]
+    sd = O.hash_fill_state_dict({k: torch.zeros(s) for k, s in zip(ks, shp)}, seed)
+    return sd, OB.unet3d_config(**json.loads(str(g[kwargs])))
+
+
+def oracle_stage(sd, cfg, shape, draws, steps, lowres=None, level=0.2, dynamic=True):
+    """One cascade stage of ElucidatedImagen.sample (elucidated_imagen.py:633-690): optional low-res conditioning noised at
+    the RAW sampling level, then the stochastic Heun loop; ``draws`` = [lowres noise]? + [init] + one per step."""
+    draws = list(draws)
+    hp = dict(OB.EDM_DEFAULTS, num_sample_steps=steps)
+    kw = {}
+    if lowres is not None:
+        lt = torch.full((shape[0],), level)
+        kw = dict(lowres_cond_img=OB.lowres_q_sample(lowres, lt, draws.pop(0)), lowres_noise_times=lt)
+    fn = lambda x, cn: OB.unet3d_forward(sd, cfg, x, cn, **kw)
+    with torch.no_grad():
+        return OB.edm_sample(fn, shape, draws[0], draws[1:], hp, dynamic=dynamic, percentile=0.95)   # reference defaults (:62-63)
+
+
+def test_c1_exact_config_ten_step_sample():
+    """BASELINE.json configs[0]: Unet3D dim 32, 16^3, 10 EDM steps = 19 U-Net evals, 4 712 921 parameters."""
+    g = load_golden('edm_c1')
+    sd, cfg = build_named(g, 'keys', 'shapes', 'kwargs_sr', 21)
+    assert sum(v.numel() for k, v in sd.items()) >= int(g['n_params'])
+    img = oracle_stage(sd, cfg, (1, 1, 16, 16, 16), list(T(g['draws'])), 10, lowres=T(g['lowres']))
+    ref = T(g['img'])
+    assert (img - ref).abs().max().item() <= 2e-3 and (img - ref).abs().mean().item() <= 2e-5, (img - ref).abs().max()
+
+
+def test_c5_cascade_layouts():
+    """BASELINE.json configs[4] layouts at 8^3 -> 16^3: (i) full generative cascade with
+    temporal_downsample_factor (2,1): stage 1 at 8 frames, nearest resize to 16 frames x 16 x 16 (imagen_video.py:137-158) as
+    the conditioning of stage 2; (ii) start_at_unet_number=2 from an 8^3 volume."""
+    import torch.nn.functional as F
+    g = load_golden('edm_cascade')
+    sd1, cfg1 = build_named(g, 'keys1', 'shapes1', 'kwargs1', 22)
+    sd2, cfg2 = build_named(g, 'keys2', 'shapes2', 'kwargs2', 23)
+    s1 = oracle_stage(sd1, cfg1, (1, 1, 8, 8, 8), list(T(g['draws1'])), 3)
+    assert (s1 - T(g['stage1'])).abs().max().item() <= 2e-3, (s1 - T(g['stage1'])).abs().max()
+    up = F.interpolate(T(g['stage1']), (16, 16, 16), mode='nearest')        # condition on the reference's own stage-1 output
+    s2 = oracle_stage(sd2, cfg2, (1, 1, 16, 16, 16), list(T(g['draws2'])), 3, lowres=up)
+    assert (s2 - T(g['stage2'])).abs().max().item() <= 2e-3, (s2 - T(g['stage2'])).abs().max()
+    up = F.interpolate(T(g['lowres']), (16, 16, 16), mode='nearest')
+    s3 = oracle_stage(sd2, cfg2, (1, 1, 16, 16, 16), list(T(g['draws3'])), 3, lowres=up)
+    assert (s3 - T(g['img_from2'])).abs().max().item() <= 2e-3, (s3 - T(g['img_from2'])).abs().max()

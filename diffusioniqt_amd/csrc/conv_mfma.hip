@@ -91,17 +91,21 @@ constexpr unsigned BUF_OOB = 0x80000000u, BUF_OOB_C = 0x40000000u;
 // tables hold byte offsets (or BUF_OOB for padding voxels / rows outside the output), the hardware range check supplies
 // the zeros and drops the masked stores, and a piece costs ~6 instructions instead of ~25.  These phases share a SIMD
 // with the co-resident workgroup's MFMA stream, which stretches every non-MFMA instruction ~3x (profiles/r01_conv_ablation.md).
-template <bool VEC4, bool BUF>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restrict__ x,
+// CKT = channels per staged K-chunk: 32 (78 KB of LDS for a 3x3x3 filter, 2 workgroups per CU) or 16 (44 KB, 3 per CU: a third
+// resident workgroup keeps two waves per SIMD on the MFMA pipe while one stages or stores).  The packed weight layout is the
+// 32-wide one either way; a 16-wide sub-chunk reads half rows of it.
+template <bool VEC4, bool BUF, int CKT>
+__global__ __launch_bounds__(256, CKT == 16 ? 3 : 2) void conv_fwd_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ wp,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ residual,
                                                           float* __restrict__ y, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LROW = CKT + 4, PCS = CKT / 4, PSH = CKT == 32 ? 3 : 2, SUB = CK / CKT;   // padded row, 16-B pieces per row, log2(PCS), sub-chunks per packed chunk
     const int HV = g.HD * g.HH * g.HWd;
-    float* halo = smem;                                  // [HV][36]
-    float* wbuf = smem + (size_t)HV * LDSROW;            // [2][64][36]
-    int* out_off = reinterpret_cast<int*>(wbuf + 2 * NT * LDSROW);   // [128] voxel -> output row or -1
+    float* halo = smem;                                  // [HV][LROW]
+    float* wbuf = smem + (size_t)HV * LROW;            // [2][64][LROW]
+    int* out_off = reinterpret_cast<int*>(wbuf + 2 * NT * LROW);   // [128] voxel -> output row or -1
     int* halo_src = out_off + MTILE;                                 // [HV] halo voxel -> input voxel index or -1
 
     const int tid = threadIdx.x;
@@ -172,45 +176,46 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     DIQT_STAMP();
 
-    const int wrow = tid >> 3, wc4 = (tid & 7) * 4;      // weight staging: rows wrow, wrow+32
+    const int wrow = tid >> PSH, wc4 = (tid & (PCS - 1)) * 4;      // weight staging: rows wrow (and wrow+32 when CKT == 32)
 
     // split-K (small spatial extents): grid.y slices the input-channel chunks; each slice writes its own output slab
-    const int chunkBeg = blockIdx.y * g.chunksPerSplit, chunkEnd = min(g.nChunks, chunkBeg + g.chunksPerSplit);
+    const int chunkBeg = blockIdx.y * g.chunksPerSplit * SUB, chunkEnd = min(g.nChunks, (int)(blockIdx.y + 1) * g.chunksPerSplit) * SUB;
     for (int chunk = chunkBeg; chunk < chunkEnd; ++chunk) {
-        const int ci0 = chunk * CK;
+        const int ci0 = chunk * CKT;
+        if (ci0 >= g.Cin) break;      // second half of a ragged last chunk (block-uniform)
         __syncthreads();   // all reads of the previous chunk's halo and of both weight buffers are done
-                if (chunk == 1) DIQT_STAMP();
+                if (chunk == chunkBeg + 1) DIQT_STAMP();
         // ---- stage halo chunk: loads are UNCONDITIONAL (clamped address, zero-selected afterwards) and issued in batches
         //      of 8 before any LDS store, so a batch costs one memory round trip instead of eight serialized ones ----
         if (BUF) {
             const unsigned coff = (ci0 + wc4 < g.Cin) ? (unsigned)(ci0 + wc4) * 4u : BUF_OOB_C;   // this thread's channel quad
-            for (int base = 0; base < HV * 8; base += 256 * 8) {
+            for (int base = 0; base < HV * PCS; base += 256 * 8) {
                 u32x4 v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int idx = base + u * 256 + tid;
                     // unconditional table read (clamped index) + select: a guarded read becomes an exec-masked branch
                     // with its own ds_read -> s_waitcnt round trip per piece
-                    const unsigned t = (unsigned)halo_src[min(idx >> 3, HV - 1)] + coff;
-                    const unsigned voff = (idx < HV * 8) ? t : BUF_OOB;
+                    const unsigned t = (unsigned)halo_src[min(idx >> PSH, HV - 1)] + coff;
+                    const unsigned voff = (idx < HV * PCS) ? t : BUF_OOB;
                     v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, 0, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int idx = base + u * 256 + tid;
-                    if (idx < HV * 8) *reinterpret_cast<u32x4*>(halo + (idx >> 3) * LDSROW + wc4) = v[u];
+                    if (idx < HV * PCS) *reinterpret_cast<u32x4*>(halo + (idx >> PSH) * LROW + wc4) = v[u];
                 }
             }
         } else
-        for (int base = 0; base < HV * 8; base += 256 * 8) {
+        for (int base = 0; base < HV * PCS; base += 256 * 8) {
             float4 v[8];
             bool ok[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int idx = base + u * 256 + tid;
-                const int hv = (idx < HV * 8) ? (idx >> 3) : 0, c4 = (idx & 7) * 4;
+                const int hv = (idx < HV * PCS) ? (idx >> PSH) : 0, c4 = (idx & (PCS - 1)) * 4;
                 const int src = halo_src[hv];
-                ok[u] = idx < HV * 8 && src >= 0 && ci0 + c4 < g.Cin;
+                ok[u] = idx < HV * PCS && src >= 0 && ci0 + c4 < g.Cin;
                 const size_t off = ok[u] ? (size_t)src * g.Cin + ci0 + c4 : 0;
                 if (VEC4) {
                     v[u] = *reinterpret_cast<const float4*>(x + off);
@@ -225,26 +230,25 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int idx = base + u * 256 + tid;
-                if (idx < HV * 8)
-                    *reinterpret_cast<float4*>(halo + (idx >> 3) * LDSROW + (idx & 7) * 4) =
+                if (idx < HV * PCS)
+                    *reinterpret_cast<float4*>(halo + (idx >> PSH) * LROW + (idx & (PCS - 1)) * 4) =
                         ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        if (chunk == 1) DIQT_STAMP();
+        if (chunk == chunkBeg + 1) DIQT_STAMP();
         // ---- weights: panel of tap 0 -> LDS now; panel t+1 is written at the START of tap t (its buffer was last read in
         //      tap t-1, retired by the barrier) from registers loaded during tap t-1, so neither the global latency nor the
         //      LDS write sits between the last MFMA of a tap and its barrier ----
-        const float* wchunk = wp + ((size_t)chunk * T * g.CoutPad + n0) * CK;
+        const float* wchunk = wp + ((size_t)(chunk / SUB) * T * g.CoutPad + n0) * CK + (chunk % SUB) * CKT;
         float4 r0, r1;
         {
             const float4 p0 = *reinterpret_cast<const float4*>(wchunk + (size_t)wrow * CK + wc4);
-            const float4 p1 = *reinterpret_cast<const float4*>(wchunk + (size_t)(wrow + 32) * CK + wc4);
-            *reinterpret_cast<float4*>(wbuf + wrow * LDSROW + wc4) = p0;
-            *reinterpret_cast<float4*>(wbuf + (wrow + 32) * LDSROW + wc4) = p1;
+            *reinterpret_cast<float4*>(wbuf + wrow * LROW + wc4) = p0;
+            if (CKT == 32) *reinterpret_cast<float4*>(wbuf + (wrow + 32) * LROW + wc4) = *reinterpret_cast<const float4*>(wchunk + (size_t)(wrow + 32) * CK + wc4);
             if (T > 1) {
                 const float* wt = wchunk + (size_t)g.CoutPad * CK;
                 r0 = *reinterpret_cast<const float4*>(wt + (size_t)wrow * CK + wc4);
-                r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
+                if (CKT == 32) r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
             }
         }
         __syncthreads();
@@ -255,29 +259,29 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
             for (int ky = 0; ky < g.kh; ++ky)
                 for (int kx = 0; kx < g.kw; ++kx, ++tap) {
                     if (tap + 1 < T) {
-                        float* wnext = wbuf + ((tap + 1) & 1) * (NT * LDSROW);
-                        *reinterpret_cast<float4*>(wnext + wrow * LDSROW + wc4) = r0;
-                        *reinterpret_cast<float4*>(wnext + (wrow + 32) * LDSROW + wc4) = r1;
+                        float* wnext = wbuf + ((tap + 1) & 1) * (NT * LROW);
+                        *reinterpret_cast<float4*>(wnext + wrow * LROW + wc4) = r0;
+                        if (CKT == 32) *reinterpret_cast<float4*>(wnext + (wrow + 32) * LROW + wc4) = r1;
                     }
                     if (tap + 2 < T) {
                         const float* wt = wchunk + (size_t)(tap + 2) * g.CoutPad * CK;
                         r0 = *reinterpret_cast<const float4*>(wt + (size_t)wrow * CK + wc4);
-                        r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
+                        if (CKT == 32) r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
                     }
-                    const float* wcur = wbuf + (tap & 1) * (NT * LDSROW);
-                    const float* ap = halo + (hidx_lane + (kz * g.HH + ky) * g.HWd + kx) * LDSROW + 4 * h;
-                    const float* bp = wcur + l31 * LDSROW + 4 * h;
+                    const float* wcur = wbuf + (tap & 1) * (NT * LROW);
+                    const float* ap = halo + (hidx_lane + (kz * g.HH + ky) * g.HWd + kx) * LROW + 4 * h;
+                    const float* bp = wcur + l31 * LROW + 4 * h;
                     // software-pipelined over q: the fragments of q+1 are in flight while the 8 MFMAs of q issue
                     float4 a = *reinterpret_cast<const float4*>(ap);
                     float4 b0 = *reinterpret_cast<const float4*>(bp);
-                    float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+                    float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LROW);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < CKT / 8; ++q) {
                         float4 an, b0n, b1n;
-                        if (q < 3) {
+                        if (q < CKT / 8 - 1) {
                             an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
                             b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
-                            b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+                            b1n = *reinterpret_cast<const float4*>(bp + 32 * LROW + 8 * (q + 1));
                         }
                         __builtin_amdgcn_sched_barrier(0);   // keep the q+1 reads ahead of q's MFMAs (hipcc sinks them otherwise)
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const float* __restric
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
-                        if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
+                        if (q < CKT / 8 - 1) { a = an; b0 = b0n; b1 = b1n; }
                     }
                     __syncthreads();
                 }
@@ -1536,14 +1540,23 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
         }
     }
     static const size_t ldspad = [] { const char* e = getenv("DIQT_CONV_LDSPAD"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();   // occupancy experiment
-    const size_t lds = ((size_t)HV * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int) + ldspad;
+    size_t lds = ((size_t)HV * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int) + ldspad;
     DIQT_REQUIRE(lds <= 160 * 1024, DIQT_E_UNSUPPORTED, "conv3d_fwd: halo tile needs %zu B of LDS", lds);
     const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
     const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
     static const bool nobuf = [] { const char* e = getenv("DIQT_CONV_NOBUF"); return e && e[0] == '1'; }();
     const bool buf = vec4 && !nobuf && xb < (1ull << 30) && yb < (1ull << 30);
     if (buf) { g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; }
-    auto kern = vec4 ? (buf ? conv_fwd_kernel<true, true> : conv_fwd_kernel<true, false>) : conv_fwd_kernel<false, false>;
+    // opt-in experiment (DIQT_CONV_CK16=1): 16-channel chunks = 44 KB of LDS for a 3x3x3 filter = three workgroups per CU instead of
+    // two.  Measured 2 % SLOWER on MI355X (64->64 @ 8x32^3: 467 vs 458 us; 128->128 @ 8x16^3: 243 vs 227 us): a third resident
+    // workgroup does not fill the staging bubbles, the doubled barrier count costs more (profiles/r01_conv_ablation.md)
+    static const int ck16_env = [] { const char* e = getenv("DIQT_CONV_CK16"); return e ? atoi(e) : 0; }();
+    const size_t lds16 = ((size_t)HV * (CK / 2 + 4 + 1) + 2 * NT * (CK / 2 + 4)) * sizeof(float) + MTILE * sizeof(int);
+    const bool ck16_ok = buf && lds16 * 3 <= 160 * 1024 && kd * kh * kw > 1;
+    const bool ck16 = ck16_ok && ck16_env == 1;
+    if (ck16) lds = lds16 + ldspad;
+    auto kern = vec4 ? (buf ? (ck16 ? conv_fwd_kernel<true, true, 16> : conv_fwd_kernel<true, true, 32>) : conv_fwd_kernel<true, false, 32>)
+                     : conv_fwd_kernel<false, false, 32>;
     static unsigned long long* dbg_buf = nullptr;
     static const bool dbg_on = [] { const char* e = getenv("DIQT_CONV_DBG"); return e && e[0] == '1'; }();
     if (dbg_on) {     // diagnostic build path only: cycle stamps per workgroup, read back with diqt_debug_conv_stamps()

@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-result"
 OBJS=""
 PIDS=""
-for f in conv_mfma elementwise bgemm conv_direct attention datapath; do
+for f in conv_mfma conv_half elementwise bgemm conv_direct attention datapath; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/diqt.h -nt $f.o ]; then
     rm -f $f.o
     $HIPCC $FLAGS -c $f.hip -o $f.o &

@@ -1,0 +1,400 @@
+// Mixed-precision forward convolution for gfx950 on v_mfma_f32_32x32x16_{f16,bf16}: fp16 / bf16 operands, fp32 accumulate.
+//
+// This is the autocast path of the sampler (`torch.autocast` around `sample`; the reference gets it from
+// ATen's autocast policy: conv3d / linear inputs are cast to the low-precision type, the result is rounded to it once).
+// Activations stay fp32 NDHWC in HBM; the cast happens while the halo tile is staged, so no other kernel changes.
+//
+// GEMM view as in conv_mfma.hip (M = voxels, N = Cout, K = taps x Cin), re-tiled for a 16x faster MFMA:
+//   * 512-thread workgroup (8 waves, two per SIMD), 256 output voxels x 64 output channels; wave w owns voxels 32w..32w+31
+//     and both 32-channel halves (two 32x32 accumulators).
+//   * halo tile (TD+kd-1)(TH+kh-1)(TW+kw-1) x 32 channels, converted to 16-bit, 80-byte LDS rows (64 B payload + 16 B pad:
+//     row r starts at 16-byte slot 5r mod 16, so the 16 lanes of a ds_read_b128 pass hit distinct slots).
+//   * weights of up to NINE taps (one kd-plane of a 3x3x3 filter) are staged per step, double-buffered: the next group's panels
+//     are loaded global -> registers before the tap loop and written to the other buffer after it, so a step has ONE barrier per
+//     36 MFMAs of a wave instead of one per 4.  The next chunk's halo is prefetched into registers during the last group.
+//   * per tap and wave: 6 ds_read_b128 (A k-steps 0/1, B for both channel halves) feed 4 MFMAs.
+// Packed weights: half/bf16 [chunk = ci/32][tap][co padded to 64][32 ci]  (conv_pack_weight_h_kernel).
+#include "common.h"
+#include <stdlib.h>
+
+namespace diqt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HCK = 32;          // channels per K-chunk
+constexpr int HROWB = 80;        // LDS row bytes (32 x 2 B + 16 B pad)
+constexpr int HNT = 64;          // output channels per workgroup
+constexpr int HMT = 256;         // output voxels per workgroup
+constexpr int HTG = 9;           // taps per staged weight group
+constexpr int HWREG = (HTG * 256 + 511) / 512;      // 16-byte weight pieces per thread and group
+constexpr int HHREG = 10;        // 16-byte fp32 halo pieces per thread that can be prefetched (HV <= 640)
+constexpr unsigned HBUF_OOB = 0x80000000u, HBUF_OOB_C = 0x40000000u;
+
+struct HalfGeom {
+    int B, D, H, W, Cin, Cout;
+    int Do, Ho, Wo;
+    int kd, kh, kw, pd, ph, pw;
+    int TD, TH, TW;
+    int tilesD, tilesH, tilesW;
+    int nNt, nChunks, CoutPad;
+    int HD, HH, HWd;
+    int TG, nGroups;             // taps per weight group, groups per chunk
+    int roundOut;                // 1: round the result to the operand type before the fp32 store (autocast semantics)
+    unsigned xBytes, yBytes;
+};
+
+__host__ __device__ inline int hcdiv(int a, int b) { return (a + b - 1) / b; }
+
+// NOTE: __builtin_bit_cast applied directly to a vector COMPONENT lvalue (v.y) reinterprets the first bytes of the whole vector
+// (hipcc 7.2: every component reads element 0); passing the component by value first is correct.
+__device__ __forceinline__ float asf(unsigned u) { return __builtin_bit_cast(float, u); }
+
+template <bool BF>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    if (BF) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        bf2 v = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, v);
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 v = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+}
+
+template <bool BF>
+__device__ __forceinline__ float round_through(float a) {
+    return BF ? (float)(__bf16)a : (float)(_Float16)a;
+}
+
+template <bool BF>
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    if (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// packed[((chunk*T + tap)*CoutPad + co)*32 + k] = (half) w[co][chunk*32 + k][tap]
+template <bool BF>
+__global__ void conv_pack_weight_h_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int Cout, int Cin, int T,
+                                          int CoutPad, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % HCK);
+        size_t r = i / HCK;
+        const int o = (int)(r % CoutPad);
+        r /= CoutPad;
+        const int tap = (int)(r % T);
+        const int in = (int)(r / T) * HCK + k;
+        const float v = (o < Cout && in < Cin) ? w[((size_t)o * Cin + in) * T + tap] : 0.f;
+        packed[i] = (unsigned short)(pack2<BF>(v, 0.f) & 0xffffu);
+    }
+}
+
+template <bool BF, bool PREF>
+__global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
+                                                             const float* __restrict__ bias, const float* __restrict__ residual,
+                                                             float* __restrict__ y, HalfGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const int HV = g.HD * g.HH * g.HWd;
+    unsigned char* halo = hsm;                                         // [HV][80 B]
+    unsigned char* wbuf = hsm + (size_t)HV * HROWB;                    // [2][TG][64][80 B]
+    const int wbufBytes = g.TG * HNT * HROWB;
+    int* out_off = reinterpret_cast<int*>(wbuf + 2 * (size_t)wbufBytes);   // [256]
+    int* halo_src = out_off + HMT;                                          // [HV]
+    int* tap_off = halo_src + HV;                                           // [T] byte offset of a tap inside the halo image
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int T = g.kd * g.kh * g.kw;
+
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = L % g.nNt;
+    int mt = L / g.nNt;
+    const int tx = mt % g.tilesW; mt /= g.tilesW;
+    const int ty = mt % g.tilesH; mt /= g.tilesH;
+    const int tz = mt % g.tilesD;
+    const int b = mt / g.tilesD;
+    const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
+    const int n0 = nt * HNT;
+
+    if (tid < HMT) {
+        const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
+        const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+        int off = (int)HBUF_OOB;
+        if (od < g.Do && oh < g.Ho && ow < g.Wo) off = (((b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout * 4;
+        out_off[tid] = off;
+    }
+    for (int hv = tid; hv < HV; hv += 512) {
+        const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+        const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+        int src = (int)HBUF_OOB;
+        if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) src = (((b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin * 4;
+        halo_src[hv] = src;
+    }
+    if (tid < T) {
+        const int kx = tid % g.kw, ky = (tid / g.kw) % g.kh, kz = tid / (g.kw * g.kh);
+        tap_off[tid] = ((kz * g.HH + ky) * g.HWd + kx) * HROWB;
+    }
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
+
+    int a_base;      // byte offset of this lane's voxel row (A operand) in the halo image at tap (0,0,0), k-half h
+    {
+        const int v = wave * 32 + l31;
+        const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
+        a_base = ((td * g.HH + th) * g.HWd + tw) * HROWB + h * 16;
+    }
+    const int b_base = l31 * HROWB + h * 16;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    const int hq = tid & 7;                         // this thread's channel quad inside a 32-channel chunk
+    const int nHalo = HV * 8;                       // 16-byte fp32 pieces of a halo chunk
+    __syncthreads();                                // tables visible
+
+    // ---- halo chunk: global fp32 -> registers (batches of 8 loads in flight) -> 16-bit LDS rows ----
+    auto stage_halo_sync = [&](int ci0) {
+        const unsigned coff = (ci0 + hq * 4 < g.Cin) ? (unsigned)(ci0 + hq * 4) * 4u : HBUF_OOB_C;
+        for (int base = 0; base < nHalo; base += 512 * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 512 + tid;
+                const unsigned t = (unsigned)halo_src[min(idx >> 3, HV - 1)] + coff;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, idx < nHalo ? t : HBUF_OOB, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 512 + tid;
+                if (idx < nHalo) {
+                    u32x2 p;
+                    p.x = pack2<BF>(asf(v[u].x), asf(v[u].y));
+                    p.y = pack2<BF>(asf(v[u].z), asf(v[u].w));
+                    *reinterpret_cast<u32x2*>(halo + (idx >> 3) * HROWB + hq * 8) = p;
+                }
+            }
+        }
+    };
+    // ---- weight group (chunk, taps t0..t0+n-1): global -> registers; registers -> LDS buffer ----
+    u32x4 wr[HWREG];
+    auto load_wgroup = [&](int chunk, int t0, int n) {
+        const unsigned short* src = wp + ((size_t)chunk * T * g.CoutPad + n0) * HCK;
+#pragma unroll
+        for (int u = 0; u < HWREG; ++u) {
+            const int idx = u * 512 + tid;
+            const int tap = idx >> 8, row = (idx >> 2) & 63, q = idx & 3;
+            if (tap < n) wr[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(t0 + tap) * g.CoutPad + row) * HCK + q * 8);
+        }
+    };
+    auto store_wgroup = [&](int buf, int n) {
+        unsigned char* dst = wbuf + buf * wbufBytes;
+#pragma unroll
+        for (int u = 0; u < HWREG; ++u) {
+            const int idx = u * 512 + tid;
+            const int tap = idx >> 8, row = (idx >> 2) & 63, q = idx & 3;
+            if (tap < n) *reinterpret_cast<u32x4*>(dst + (tap * HNT + row) * HROWB + q * 16) = wr[u];
+        }
+    };
+
+    stage_halo_sync(0);
+    load_wgroup(0, 0, min(g.TG, T));
+    store_wgroup(0, min(g.TG, T));
+    __syncthreads();
+
+    u32x4 hr[PREF ? HHREG : 1];
+    int step = 0;
+    for (int chunk = 0; chunk < g.nChunks; ++chunk) {
+        for (int grp = 0; grp < g.nGroups; ++grp, ++step) {
+            const int t0 = grp * g.TG, nTap = min(g.TG, T - t0);
+            const bool lastGrp = grp + 1 == g.nGroups, more = !(lastGrp && chunk + 1 == g.nChunks);
+            const int nchunk = lastGrp ? chunk + 1 : chunk, nt0 = lastGrp ? 0 : t0 + g.TG, nn = min(g.TG, T - nt0);
+            if (more) load_wgroup(nchunk, nt0, nn);
+            const bool prefHalo = PREF && lastGrp && more;
+            if constexpr (PREF) if (prefHalo) {
+                const int ci0 = (chunk + 1) * HCK;
+                const unsigned coff = (ci0 + hq * 4 < g.Cin) ? (unsigned)(ci0 + hq * 4) * 4u : HBUF_OOB_C;
+#pragma unroll
+                for (int u = 0; u < HHREG; ++u) {
+                    const int idx = u * 512 + tid;
+                    const unsigned t = (unsigned)halo_src[min(idx >> 3, HV - 1)] + coff;
+                    hr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, idx < nHalo ? t : HBUF_OOB, 0, 0);
+                }
+            }
+            // ---- taps of this group: fragments of tap t+1 are read while the MFMAs of tap t issue ----
+            const unsigned char* wcur = wbuf + (step & 1) * wbufBytes + b_base;
+            const unsigned char* ap = halo + a_base;
+            int toff = tap_off[t0];
+            u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + toff), a1 = *reinterpret_cast<const u32x4*>(ap + toff + 32);
+            u32x4 b00 = *reinterpret_cast<const u32x4*>(wcur), b01 = *reinterpret_cast<const u32x4*>(wcur + 32);
+            u32x4 b10 = *reinterpret_cast<const u32x4*>(wcur + 32 * HROWB), b11 = *reinterpret_cast<const u32x4*>(wcur + 32 * HROWB + 32);
+            for (int t = 0; t < nTap; ++t) {
+                u32x4 na0, na1, nb00, nb01, nb10, nb11;
+                if (t + 1 < nTap) {
+                    const int to2 = tap_off[t0 + t + 1];
+                    const unsigned char* wn = wcur + (t + 1) * (HNT * HROWB);
+                    na0 = *reinterpret_cast<const u32x4*>(ap + to2); na1 = *reinterpret_cast<const u32x4*>(ap + to2 + 32);
+                    nb00 = *reinterpret_cast<const u32x4*>(wn); nb01 = *reinterpret_cast<const u32x4*>(wn + 32);
+                    nb10 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB); nb11 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB + 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = mfma16<BF>(a0, b00, acc0);
+                acc1 = mfma16<BF>(a0, b10, acc1);
+                acc0 = mfma16<BF>(a1, b01, acc0);
+                acc1 = mfma16<BF>(a1, b11, acc1);
+                if (t + 1 < nTap) { a0 = na0; a1 = na1; b00 = nb00; b01 = nb01; b10 = nb10; b11 = nb11; }
+            }
+            if (more) store_wgroup((step + 1) & 1, nn);      // that buffer was last read in step-1, retired by its barrier
+            if (lastGrp && more) {
+                __syncthreads();                             // every wave is done with this chunk's halo image
+                bool done = false;
+                if constexpr (PREF) if (prefHalo) {
+                    done = true;
+#pragma unroll
+                    for (int u = 0; u < HHREG; ++u) {
+                        const int idx = u * 512 + tid;
+                        if (idx < nHalo) {
+                            u32x2 p;
+                            p.x = pack2<BF>(asf(hr[u].x), asf(hr[u].y));
+                            p.y = pack2<BF>(asf(hr[u].z), asf(hr[u].w));
+                            *reinterpret_cast<u32x2*>(halo + (idx >> 3) * HROWB + hq * 8) = p;
+                        }
+                    }
+                }
+                if (!done) stage_halo_sync((chunk + 1) * HCK);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[row = voxel][col = co]; row = (r&3) + 8*(r>>2) + 4*h ----
+    const int co0 = n0 + l31, co1 = n0 + 32 + l31;
+    const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
+    const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
+    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : HBUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : HBUF_OOB_C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned off = (unsigned)out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        if (g.roundOut) { v0 = round_through<BF>(v0); v1 = round_through<BF>(v1); }
+        if (residual) {
+            v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+            v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+    }
+}
+
+static size_t half_lds_bytes(const HalfGeom& g) {
+    const size_t HV = (size_t)g.HD * g.HH * g.HWd;
+    return HV * HROWB + 2 * (size_t)g.TG * HNT * HROWB + (HMT + HV + g.kd * g.kh * g.kw) * sizeof(int);
+}
+
+static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                      int epd, int eph, int epw) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kd <= 0 || kh <= 0 || kw <= 0) return false;
+    if (pd < 0 || ph < 0 || pw < 0 || pd + epd < 0 || ph + eph < 0 || pw + epw < 0) return false;
+    if (Cin % 4 != 0 || kd * kh * kw > 512) return false;
+    if (Cin < 8 && kd * kh * kw > 1) return false;          // the tap-packed fp32 kernel (conv_fwd_smallcin_kernel) is the better fit
+    if (kd == 1 && kh == 1 && kw == 1 && pd == 0 && ph == 0 && pw == 0 && epd == 0 && eph == 0 && epw == 0) {   // 1x1x1: flatten all voxels into W
+        const long long rows = (long long)B * D * H * W;
+        if (rows >= (1ll << 31)) return false;
+        B = 1; D = 1; H = 1; W = (int)rows;
+    }
+    g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+    g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw;
+    g.Do = D + 2 * pd + epd - kd + 1; g.Ho = H + 2 * ph + eph - kh + 1; g.Wo = W + 2 * pw + epw - kw + 1;
+    if (g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return false;
+    const int T = kd * kh * kw;
+    g.TG = T < HTG ? T : HTG;
+    g.nGroups = hcdiv(T, g.TG);
+    g.nNt = hcdiv(Cout, HNT); g.CoutPad = g.nNt * HNT; g.nChunks = hcdiv(Cin, HCK);
+    g.roundOut = 1;
+    static const int cand[][3] = {{4, 8, 8}, {8, 8, 4}, {8, 4, 8}, {2, 8, 16}, {2, 16, 8}, {1, 16, 16}, {16, 4, 4}, {4, 4, 16}, {4, 16, 4},
+                                  {16, 16, 1}, {16, 1, 16}, {32, 4, 2}, {64, 2, 2}, {256, 1, 1}, {1, 1, 256}, {1, 256, 1}, {1, 8, 32},
+                                  {1, 32, 8}, {8, 32, 1}, {32, 8, 1}, {1, 4, 64}, {1, 2, 128}, {128, 2, 1}, {128, 1, 2}};
+    double best = 1e300;
+    bool found = false;
+    for (auto& c : cand) {
+        HalfGeom t = g;
+        t.TD = c[0]; t.TH = c[1]; t.TW = c[2];
+        t.HD = c[0] + kd - 1; t.HH = c[1] + kh - 1; t.HWd = c[2] + kw - 1;
+        if (half_lds_bytes(t) > 160 * 1024) continue;
+        const double tiles = (double)hcdiv(g.Do, c[0]) * hcdiv(g.Ho, c[1]) * hcdiv(g.Wo, c[2]);
+        const double halo = (double)t.HD * t.HH * t.HWd;
+        const double cost = tiles * (halo * 1.0 + 256.0 * T);     // staging is relatively 16x dearer than on the f32 kernel
+        if (cost < best) { best = cost; g.TD = c[0]; g.TH = c[1]; g.TW = c[2]; found = true; }
+    }
+    if (!found) return false;
+    g.HD = g.TD + kd - 1; g.HH = g.TH + kh - 1; g.HWd = g.TW + kw - 1;
+    g.tilesD = hcdiv(g.Do, g.TD); g.tilesH = hcdiv(g.Ho, g.TH); g.tilesW = hcdiv(g.Wo, g.TW);
+    const long long nwg = (long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
+    if (nwg >= (1ll << 31)) return false;
+    const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
+    const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
+    if (xb >= (1ull << 30) || yb >= (1ull << 30)) return false;       // buffer-descriptor addressing
+    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb;
+    return true;
+}
+
+}  // namespace diqt
+
+using namespace diqt;
+
+// number of 16-bit elements of the packed low-precision weight (same [chunk][tap][co pad 64][32] order as the fp32 packing)
+extern "C" size_t diqt_conv_packed_h_elems(int Cout, int Cin, int kd, int kh, int kw) {
+    if (Cout <= 0 || Cin <= 0 || kd <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (size_t)hcdiv(Cin, HCK) * kd * kh * kw * (hcdiv(Cout, HNT) * HNT) * HCK;
+}
+
+extern "C" int diqt_conv_pack_weight_h(const float* w, void* packed, int Cout, int Cin, int kd, int kh, int kw, int bf16, void* stream) {
+    DIQT_REQUIRE(w && packed, DIQT_E_ALIGN, "conv_pack_weight_h: null pointer");
+    DIQT_REQUIRE(Cout > 0 && Cin > 0 && kd > 0 && kh > 0 && kw > 0, DIQT_E_SHAPE, "conv_pack_weight_h: bad shape");
+    const int T = kd * kh * kw, CoutPad = hcdiv(Cout, HNT) * HNT;
+    const size_t total = (size_t)hcdiv(Cin, HCK) * T * CoutPad * HCK;
+    auto k = bf16 ? conv_pack_weight_h_kernel<true> : conv_pack_weight_h_kernel<false>;
+    hipLaunchKernelGGL(k, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, static_cast<unsigned short*>(packed), Cout,
+                       Cin, T, CoutPad, total);
+    return check_launch("conv_pack_weight_h");
+}
+
+// 1 when diqt_conv3d_fwd_h takes this shape (Cin % 4 == 0, tensors < 1 GiB, halo tile within the LDS), else 0: the caller then
+// stays on the fp32 kernel, which is always correct under autocast (more precise than the reference)
+extern "C" int diqt_conv3d_fwd_h_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                           int epd, int eph, int epw) {
+    HalfGeom g;
+    return half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw) ? 1 : 0;
+}
+
+extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const float* bias, const float* residual, float* y, int B, int D,
+                                 int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph,
+                                 int epw, int bf16, int round_out, void* stream) {
+    DIQT_REQUIRE(x && packed_h && y, DIQT_E_ALIGN, "conv3d_fwd_h: null pointer");
+    DIQT_REQUIRE(aligned16(x) && aligned16(packed_h), DIQT_E_ALIGN, "conv3d_fwd_h: x and the packed weights must be 16-byte aligned");
+    HalfGeom g;
+    DIQT_REQUIRE(half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw), DIQT_E_UNSUPPORTED,
+                 "conv3d_fwd_h: shape not supported by the low-precision kernel (diqt_conv3d_fwd_h_supported == 0)");
+    g.roundOut = round_out ? 1 : 0;
+    const size_t lds = half_lds_bytes(g);
+    const int HV = g.HD * g.HH * g.HWd;
+    static const bool nopref = [] { const char* e = getenv("DIQT_CONVH_NOPREF"); return e && e[0] == '1'; }();
+    const bool pref = !nopref && HV * 8 <= 512 * HHREG;
+    void (*kern)(const float*, const unsigned short*, const float*, const float*, float*, HalfGeom) =
+        bf16 ? (pref ? conv_fwd_h_kernel<true, true> : conv_fwd_h_kernel<true, false>)
+             : (pref ? conv_fwd_h_kernel<false, true> : conv_fwd_h_kernel<false, false>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, (hipStream_t)stream, x, static_cast<const unsigned short*>(packed_h), bias,
+                       residual, y, g);
+    return check_launch("conv3d_fwd_h");
+}

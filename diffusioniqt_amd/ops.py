@@ -19,6 +19,45 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH += 1
 
 
+# --------------------------------------------------------------------------------------------
+# mixed precision: the reference's fp16 switch is torch.autocast (ImagenTrainer(fp16=True) -> Accelerator(mixed_precision='fp16'),
+# trainer.py:293-311; `torch.autocast` around ElucidatedImagen.sample).  Under autocast -- or inside
+# ``low_precision('fp16' | 'bf16')`` -- conv3d / linear FORWARDS run on the fp16 / bf16 MFMA kernel (fp32 accumulate, result
+# rounded once to the operand type like an fp16 output tensor); everything autocast keeps in fp32 (GroupNorm, soft-max, losses,
+# the sampler arithmetic) is untouched, and so are attention products and backward passes (fp32 here: more precise than the
+# reference, never less).  Activations stay fp32 in HBM; the cast happens inside the kernel while the halo tile is staged.
+# --------------------------------------------------------------------------------------------
+_LP_FORCED = None      # None: follow torch.autocast; 'off' | 'fp16' | 'bf16'
+
+
+class low_precision:
+    """Context manager forcing the conv/linear compute type: 'fp16', 'bf16' or 'off' (fp32 even under torch.autocast)."""
+
+    def __init__(self, mode):
+        assert mode in ('off', 'fp16', 'bf16'), mode
+        self.mode = mode
+
+    def __enter__(self):
+        global _LP_FORCED
+        self.prev, _LP_FORCED = _LP_FORCED, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _LP_FORCED
+        _LP_FORCED = self.prev
+        return False
+
+
+def lp_mode():
+    """None (fp32), 0 (fp16 operands) or 1 (bf16 operands) for the conv/linear forward launched now."""
+    if _LP_FORCED is not None:
+        return {'off': None, 'fp16': 0, 'bf16': 1}[_LP_FORCED]
+    if torch.is_autocast_enabled('cuda'):
+        dt = torch.get_autocast_dtype('cuda')
+        return 0 if dt == torch.float16 else (1 if dt == torch.bfloat16 else None)
+    return None
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -110,6 +149,49 @@ def _packed(weight5, mode):
     return packed
 
 
+def _packed_h(weight5, bf16):
+    """16-bit packed copy of an OIDHW weight for the fp16 / bf16 MFMA kernel, cached like ``_packed``."""
+    owner = weight5._base if weight5._base is not None else weight5
+    cache = getattr(owner, "_diqt_pack", None)
+    if cache is None:
+        cache = {}
+        try:
+            owner._diqt_pack = cache
+        except Exception:
+            pass
+    slot = ('h', bf16)
+    key = (slot, weight5.data_ptr(), weight5._version, _WEIGHT_EPOCH)
+    hit = cache.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    Cout, Cin, kd, kh, kw = weight5.shape
+    n = _lib.query("diqt_conv_packed_h_elems", Cout, Cin, kd, kh, kw)
+    packed = torch.empty(n, dtype=torch.int16, device=weight5.device)
+    _lib.call("diqt_conv_pack_weight_h", weight5.detach(), packed, Cout, Cin, kd, kh, kw, bf16, _stream())
+    cache[slot] = (key, packed)
+    return packed
+
+
+def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16):
+    """fp16 / bf16-operand forward (diqt_conv3d_fwd_h) or None when the low-precision kernel does not take this shape."""
+    B, D, H, W, Cin = x5.shape
+    Cout, _, kd, kh, kw = weight.shape
+    geo = (B, D, H, W, Cin, Cout, kd, kh, kw, *pad, *epad)
+    if not _lib.query("diqt_conv3d_fwd_h_supported", *geo):
+        return None
+    Do, Ho, Wo = D + 2 * pad[0] + epad[0] - kd + 1, H + 2 * pad[1] + epad[1] - kh + 1, W + 2 * pad[2] + epad[2] - kw + 1
+    y = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=x5.device)
+    if TIMER.enabled:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+    _lib.call("diqt_conv3d_fwd_h", x5, _packed_h(weight, bf16), bias, residual, y, *geo, bf16, 1, _stream())
+    if TIMER.enabled:
+        e.record()
+        TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_h_kernel",
+                              (B, D, H, W, Cin, Cout, kd, kh, kw)))
+    return y
+
+
 class ColStats:
     """Per-tile column sums (sum, sum of squares) of a conv output, written by the conv epilogue: [B, nblk, 2, C].
     Attached to the output tensor as ``_diqt_stats`` for the consumer's GroupNorm statistics / SE pooling."""
@@ -152,7 +234,10 @@ class _Conv3dFn(Function):
         _chk(x, weight, bias, residual)
         Cout, Cin, kd, kh, kw = weight.shape
         assert x.dim() == 5 and x.shape[-1] == Cin, f"conv3d: x {tuple(x.shape)} vs weight {tuple(weight.shape)}"
-        y = _conv_fwd_raw(x, _packed(weight, 0), bias, residual, Cout, (kd, kh, kw), pad, epad, stats_out)
+        lp = lp_mode()
+        y = _conv_fwd_half(x, weight, bias, residual, pad, epad, lp) if lp is not None else None
+        if y is None:
+            y = _conv_fwd_raw(x, _packed(weight, 0), bias, residual, Cout, (kd, kh, kw), pad, epad, stats_out)
         ctx.save_for_backward(x, weight)
         ctx.pad = pad
         ctx.epad = epad

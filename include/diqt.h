@@ -72,6 +72,21 @@ int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, cons
                     float* y, int B, int D, int H, int W, int Cin, int Cout,
                     int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
 
+/* Mixed-precision forward conv (v_mfma_f32_32x32x16_f16 / _bf16, fp32 accumulate): the autocast path of the samplers.
+ * Replaces ATen's autocast policy for conv3d / linear -- `torch.autocast` around `ElucidatedImagen.sample` and
+ * `ImagenTrainer(fp16=True)` -> `Accelerator(mixed_precision='fp16')` (trainer.py:293-311): operands are cast to fp16 (bf16 = 1:
+ * bf16) while the halo tile is staged, products accumulate in fp32, and with round_out = 1 the result (+ bias) is rounded once to
+ * the operand type before the fp32 store, as an fp16 output tensor would be.  x, y, bias, residual stay fp32 NDHWC.
+ * `packed_h`: 16-bit [ci/32][tap][co padded to 64][32] from diqt_conv_pack_weight_h (diqt_conv_packed_h_elems elements).
+ * diqt_conv3d_fwd_h_supported() == 0 (Cin % 4 != 0, a tensor >= 1 GiB, halo tile beyond the LDS): stay on diqt_conv3d_fwd.   */
+size_t diqt_conv_packed_h_elems(int Cout, int Cin, int kd, int kh, int kw);
+int diqt_conv_pack_weight_h(const float* w_oidhw, void* packed_h, int Cout, int Cin, int kd, int kh, int kw, int bf16, void* stream);
+int diqt_conv3d_fwd_h_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                int epd, int eph, int epw);
+int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const float* bias, const float* residual, float* y, int B, int D, int H,
+                      int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, int bf16,
+                      int round_out, void* stream);
+
 /* Forward conv that also emits per-tile column sums of its OUTPUT for the consumer's GroupNorm statistics / SE pooling
  * (Block -> Block and Block -> SE3D inside ResnetBlock, imagen_pytorch3D.py:568-632): stats[B][nblk][2][Cout] =
  * (sum, sum of squares) over the valid voxels of each output tile, nblk = diqt_conv3d_fwd_stats_blocks(...) (0: this shape

@@ -1,0 +1,174 @@
+"""Mixed-precision (autocast) forward path on a real MI355X: the fp16 / bf16 MFMA conv kernel (csrc/conv_half.hip).
+
+* integer-valued operands are exact in fp16/bf16 and their products sum exactly in fp32, so the kernel must be BIT-EXACT against a
+  float64 convolution rounded once to the operand type (autocast's output rounding) -- this pins the fragment layouts, tap offsets,
+  chunking, padding and the ragged edges without any tolerance;
+* random data: within one unit in the last place of the operand type of that same reference;
+* whole U-Nets under ``torch.autocast``: the deviation from the reference's own autocast output (fixtures made by the real reference
+  under CPU autocast, oracle/make_golden_autocast.py) is of the size of the reference's own fp16/bf16 round-off.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import iqt_oracle as O
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = lambda a: torch.from_numpy(np.asarray(a))
+LP = {'fp16': torch.float16, 'bf16': torch.bfloat16}
+
+
+def ref_conv(x, w, bias, pad, epad, dt, residual=None):
+    """float64 conv of the operands rounded to `dt`, + bias, rounded once to `dt`, + residual in fp32 (channels-last in/out)."""
+    xr = x.to(dt).double().permute(0, 4, 1, 2, 3)
+    wr = w.to(dt).double()
+    xp = F.pad(xr, (pad[2], pad[2] + epad[2], pad[1], pad[1] + epad[1], pad[0], pad[0] + epad[0]))
+    y = F.conv3d(xp, wr)
+    if bias is not None:
+        y = y + bias.double().view(1, -1, 1, 1, 1)
+    y = y.float().to(dt).float().permute(0, 2, 3, 4, 1).contiguous()
+    return y if residual is None else y + residual
+
+
+SHAPES = [  # B, D, H, W, Cin, Cout, k, pad, epad
+    (2, 8, 8, 8, 32, 64, (3, 3, 3), (1, 1, 1), (0, 0, 0)),
+    (1, 9, 10, 11, 36, 72, (3, 3, 3), (1, 1, 1), (0, 0, 0)),          # ragged tiles, ragged chunk, two Cout tiles
+    (2, 6, 12, 12, 64, 32, (1, 3, 3), (0, 1, 1), (0, 0, 0)),          # per-frame spatial conv of the pseudo-3D block
+    (2, 10, 6, 6, 32, 32, (3, 1, 1), (1, 0, 0), (0, 0, 0)),           # temporal conv
+    (1, 10, 4, 4, 40, 24, (3, 1, 1), (2, 0, 0), (-2, 0, 0)),          # causal: both pads on the low side
+    (1, 4, 8, 8, 96, 128, (1, 1, 1), (0, 0, 0), (0, 0, 0)),           # 1x1x1 / Linear rows
+    (1, 5, 5, 5, 8, 8, (3, 3, 3), (0, 0, 0), (0, 0, 0)),              # unpadded (boundary_pad mode), tiny
+    (1, 6, 6, 6, 128, 64, (3, 3, 3), (1, 1, 1), (0, 0, 0)),           # four K-chunks x three weight groups
+    (1, 2, 9, 9, 16, 16, (1, 5, 5), (0, 2, 2), (0, 0, 0)),            # 25 taps: groups of 9, 9, 7
+]
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_half_is_bit_exact_on_integer_data(shape, mode):
+    from diffusioniqt_amd import ops, _lib
+    B, D, H, W, Cin, Cout, k, pad, epad = shape
+    assert _lib.query("diqt_conv3d_fwd_h_supported", B, D, H, W, Cin, Cout, *k, *pad, *epad) == 1
+    g = torch.Generator().manual_seed(B * 1000 + Cin)
+    x = torch.randint(-3, 4, (B, D, H, W, Cin), generator=g).float()
+    w = torch.randint(-2, 3, (Cout, Cin, *k), generator=g).float()
+    bias = torch.randint(-4, 5, (Cout,), generator=g).float()
+    with ops.low_precision(mode), torch.no_grad():
+        y = ops.conv3d(x.to(DEV), w.to(DEV), bias.to(DEV), pad, extra_pad=epad)
+    ref = ref_conv(x, w, bias, pad, epad, LP[mode])
+    assert y.shape == ref.shape
+    assert torch.equal(y.cpu(), ref), (y.cpu() - ref).abs().max()
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_conv_half_random_data_residual_and_linear(mode):
+    from diffusioniqt_amd import ops
+    dt = LP[mode]
+    ulp = 2.0 ** -10 if mode == 'fp16' else 2.0 ** -7
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 8, 12, 12, 64, generator=g)
+    w = torch.randn(64, 64, 3, 3, 3, generator=g) * 0.03
+    bias = torch.randn(64, generator=g)
+    res = torch.randn(2, 8, 12, 12, 64, generator=g)
+    with ops.low_precision(mode), torch.no_grad():
+        y = ops.conv3d(x.to(DEV), w.to(DEV), bias.to(DEV), (1, 1, 1), residual=res.to(DEV))
+    ref = ref_conv(x, w, bias, (1, 1, 1), (0, 0, 0), dt, residual=res)
+    err = (y.cpu() - ref).abs()
+    assert (err <= ulp * (ref - res).abs() + 1e-6).all(), err.max()
+    assert (err > 0).float().mean().item() < 0.02          # fp32 accumulation order only rarely flips the final rounding
+    # Linear with > 64 rows goes through the same kernel
+    xl = torch.randn(3, 100, 96, generator=g)
+    wl = torch.randn(160, 96, generator=g) * 0.1
+    bl = torch.randn(160, generator=g)
+    with ops.low_precision(mode), torch.no_grad():
+        yl = ops.linear(xl.to(DEV), wl.to(DEV), bl.to(DEV))
+    refl = (xl.to(dt).double() @ wl.to(dt).double().t() + bl.double()).float().to(dt).float()
+    assert ((yl.cpu() - refl).abs() <= ulp * refl.abs() + 1e-6).all()
+
+
+def test_low_precision_follows_torch_autocast_and_off_switch():
+    from diffusioniqt_amd import ops
+    assert ops.lp_mode() is None
+    with torch.autocast('cuda', dtype=torch.float16):
+        assert ops.lp_mode() == 0
+        with ops.low_precision('off'):
+            assert ops.lp_mode() is None
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert ops.lp_mode() == 1
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 8, 8, 8, 32, generator=g).to(DEV)
+    w = (torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    with torch.no_grad():
+        y32 = ops.conv3d(x, w, None, (1, 1, 1))
+        with torch.autocast('cuda', dtype=torch.float16):
+            y16 = ops.conv3d(x, w, None, (1, 1, 1))
+            with ops.low_precision('off'):
+                yoff = ops.conv3d(x, w, None, (1, 1, 1))
+    assert torch.equal(yoff, y32) and not torch.equal(y16, y32)
+    assert y16.dtype == torch.float32 and (y16 - y32).abs().max().item() <= 4e-3 * y32.abs().max().item()
+
+
+def test_backward_under_autocast_uses_fp32_gradients():
+    """Forward on the fp16 kernel, backward-data / backward-weight on the exact fp32 kernels (more precise than the reference)."""
+    from diffusioniqt_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 8, 8, 8, 32, generator=g).to(DEV).requires_grad_()
+    w = (torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05).to(DEV).requires_grad_()
+    dy = torch.randn(1, 8, 8, 8, 32, generator=g).to(DEV)
+    ops.conv3d(x, w, None, (1, 1, 1)).backward(dy)
+    gx, gw = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = None
+    with torch.autocast('cuda', dtype=torch.float16):
+        ops.conv3d(x, w, None, (1, 1, 1)).backward(dy)
+    assert torch.equal(x.grad, gx) and torch.equal(w.grad, gw)
+
+
+def rel(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_unet3d_under_autocast_vs_reference_autocast(mode):
+    from diffusioniqt_amd.imagen_video import Unet3D
+    g = load_golden('unet3d_tiny')
+    a = load_golden('autocast_fwd')
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(str(g['kwargs'])).items()}
+    unet = Unet3D(**kw)
+    unet.load_state_dict(O.hash_fill_state_dict(unet.state_dict(), 11))
+    unet = unet.to(DEV).eval()
+    args = (T(g['x']).to(DEV), T(g['time']).to(DEV))
+    kws = dict(lowres_cond_img=T(g['lowres']).to(DEV), lowres_noise_times=T(g['lowres_times']).to(DEV))
+    with torch.no_grad():
+        y32 = unet(*args, **kws).cpu()
+        with torch.autocast('cuda', dtype=LP[mode]):
+            ylp = unet(*args, **kws).cpu()
+    ref32, reflp = T(a['B_y32']), T(a['B_y_' + mode])
+    assert rel(y32, ref32) < 1e-4
+    own, refs = rel(ylp, y32), rel(reflp, ref32)
+    assert 0 < own <= 1.5 * refs, (own, refs)                       # the low-precision kernel ran, and is no noisier than the reference
+    assert rel(ylp, reflp) <= 1.5 * refs, (rel(ylp, reflp), refs)   # and lands within the reference's own round-off of it
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_family_a_unet_under_autocast_vs_reference_autocast(mode):
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256
+    g = load_golden('unetA_tiny')
+    a = load_golden('autocast_fwd')
+    unet = SRUnet256(**json.loads(str(g['kwargs'])))
+    unet.load_state_dict(O.hash_fill_state_dict(unet.state_dict(), 0))
+    unet = unet.to(DEV).eval()
+    args = (T(g['x']).to(DEV), T(g['times']).to(DEV), T(g['log_snr']).to(DEV))
+    with torch.no_grad():
+        y32 = unet(*args, lowres_cond_img=T(g['lowres']).to(DEV)).cpu()
+        with torch.autocast('cuda', dtype=LP[mode]):
+            ylp = unet(*args, lowres_cond_img=T(g['lowres']).to(DEV)).cpu()
+    ref32, reflp = T(a['A_y32']), T(a['A_y_' + mode])
+    assert rel(y32, ref32) < 1e-4
+    own, refs = rel(ylp, y32), rel(reflp, ref32)
+    assert 0 < own <= 1.5 * refs, (own, refs)
+    assert rel(ylp, reflp) <= 1.5 * refs, (rel(ylp, reflp), refs)

@@ -36,6 +36,10 @@ if mode in ("fwd", "both"):
     with torch.no_grad():
         ms = timeit(lambda: ops.conv3d(x, w, bias, (1, 1, 1)), iters)
     print(f"conv fwd  B={B} {S}^3 {Cin}->{Cout}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
+if mode in ("fwdh",):           # fp16 / bf16 operand kernel (LP=fp16|bf16)
+    with torch.no_grad(), ops.low_precision(os.environ.get("LP", "fp16")):
+        ms = timeit(lambda: ops.conv3d(x, w, bias, (1, 1, 1)), iters)
+    print(f"conv fwd {os.environ.get('LP', 'fp16')}  B={B} {S}^3 {Cin}->{Cout}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
 if mode in ("bwdw", "both"):
     xr = x.clone()
     y = ops.conv3d(xr, w, bias, (1, 1, 1))

@@ -166,6 +166,21 @@ def main():
                         flops_per_launch=round(flops / n / 1e9, 3), flops_unit="GFLOP (algorithmic, 2*MAC) per average launch")
         assert torch.isfinite(state["img"]).all()
 
+    # ---------------- the same sampler step under torch.autocast(fp16): conv / linear forwards on the fp16 MFMA kernel (fp32
+    #                  accumulate), everything else fp32 -- the reference's mixed-precision switch.  Reported
+    #                  beside the fp32 headline, never as `value` ----
+    if args.mode in ("sample", "both"):
+        state["i"] = 0
+
+        def sample_step_fp16():
+            with torch.autocast('cuda', dtype=torch.float16):
+                sample_step()
+
+        ka = max(4, K // 2)
+        dt = timed(sample_step_fp16, min(W, 2), min(ka, K + W - min(W, 2)))
+        ka = min(ka, K + W - min(W, 2))
+        result["autocast_fp16"] = dict(ms_per_step=1e3 * dt / ka, patches_per_s=world * B * ka / dt, steps=ka)
+
     # ---------------- EDM (Karras) stochastic Heun sampler on the same U-Net: one call of ElucidatedImagen.sample with
     #                  n = max(4, K // 2) steps = 2n - 1 U-Net evals (elucidated_imagen.py:382-532); reported beside the headline ----
     if args.mode in ("sample", "both"):
@@ -265,7 +280,8 @@ def main():
     if rank == 0:
         primary = "sample" if "sample" in result else "train"
         out = {
-            "metric": "3D patches/sec (32^3, 1ch) — DDPM sample steps" if primary == "sample" else "3D patches/sec (32^3, 1ch) — train micro-steps",
+            "metric": ("3D patches/sec (32³, 1ch) — sample steps/sec x batch (one U-Net eval per patch and step: DDPM ancestral; EDM Heun in `edm`, "
+                       "train-steps/sec in `train`)") if primary == "sample" else "3D patches/sec (32³, 1ch) — train micro-steps",
             "value": round(result[primary]["patches_per_s"], 2), "unit": "patches/s",
             "n_gpus": world, "steps": K if primary == "sample" else result["train"]["steps"], "warmup": W,
             "ms_per_step": round(result[primary]["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
@@ -284,6 +300,10 @@ def main():
         if "unet3d" in result:
             out["unet3d"] = {k: round(v, 3) for k, v in result["unet3d"].items()}
             out["unet3d"]["note"] = "Family B: Unet3D dim 64, mults (1,2,4), 2 resnet blocks, attention at the last level + middle, 32^3 (190 GFLOP/patch/eval)"
+        if "autocast_fp16" in result:
+            out["autocast_fp16"] = {k: round(v, 3) for k, v in result["autocast_fp16"].items()}
+            out["autocast_fp16"]["note"] = ("same DDPM sampler step under torch.autocast(float16): conv/linear forwards on v_mfma_f32_32x32x16_f16 "
+                                            "(fp32 accumulate), all else fp32; reduced precision, NOT the headline")
         if "edm" in result:
             out["edm"] = {k: round(v, 3) for k, v in result["edm"].items()}
             out["edm"]["note"] = "ElucidatedImagen.sample (stochastic Heun, 2 U-Net evals per step except the last) driving the same C2 U-Net"

@@ -45,6 +45,7 @@ struct HalfGeom {
     int TG, nGroups;             // taps per weight group, groups per chunk
     int roundOut;                // 1: round the result to the operand type before the fp32 store (autocast semantics)
     unsigned xBytes, yBytes;
+    unsigned long long* dbg;     // diagnostic cycle stamps per workgroup (DIQT_CONVH_DBG=1), NULL in production
 };
 
 __host__ __device__ inline int hcdiv(int a, int b) { return (a + b - 1) / b; }
@@ -104,7 +105,6 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
     const int wbufBytes = g.TG * HNT * HROWB;
     int* out_off = reinterpret_cast<int*>(wbuf + 2 * (size_t)wbufBytes);   // [256]
     int* halo_src = out_off + HMT;                                          // [HV]
-    int* tap_off = halo_src + HV;                                           // [T] byte offset of a tap inside the halo image
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,10 +134,6 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
         int src = (int)HBUF_OOB;
         if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) src = (((b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin * 4;
         halo_src[hv] = src;
-    }
-    if (tid < T) {
-        const int kx = tid % g.kw, ky = (tid / g.kw) % g.kh, kz = tid / (g.kw * g.kh);
-        tap_off[tid] = ((kz * g.HH + ky) * g.HWd + kx) * HROWB;
     }
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
 
@@ -187,8 +183,10 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
 #pragma unroll
         for (int u = 0; u < HWREG; ++u) {
             const int idx = u * 512 + tid;
-            const int tap = idx >> 8, row = (idx >> 2) & 63, q = idx & 3;
-            if (tap < n) wr[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(t0 + tap) * g.CoutPad + row) * HCK + q * 8);
+            const int tap = min(idx >> 8, n - 1), row = (idx >> 2) & 63, q = idx & 3;
+            // UNCONDITIONAL (clamped tap): a guarded load becomes an exec-masked branch with an s_waitcnt vmcnt(0) in front of
+            // every load, i.e. one serialized L2 round trip per piece; the store below is the guarded side
+            wr[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(t0 + tap) * g.CoutPad + row) * HCK + q * 8);
         }
     };
     auto store_wgroup = [&](int buf, int n) {
@@ -201,11 +199,14 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
         }
     };
 
+    const long long ts0 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    long long tTap = 0, tSync = 0, tq = 0;
     stage_halo_sync(0);
     load_wgroup(0, 0, min(g.TG, T));
     store_wgroup(0, min(g.TG, T));
     __syncthreads();
 
+    const long long ts1 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
     u32x4 hr[PREF ? HHREG : 1];
     int step = 0;
     for (int chunk = 0; chunk < g.nChunks; ++chunk) {
@@ -225,19 +226,34 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
                     hr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, idx < nHalo ? t : HBUF_OOB, 0, 0);
                 }
             }
+            if (g.dbg) tq = (long long)__builtin_readcyclecounter();
             // ---- taps of this group: fragments of tap t+1 are read while the MFMAs of tap t issue ----
             const unsigned char* wcur = wbuf + (step & 1) * wbufBytes + b_base;
             const unsigned char* ap = halo + a_base;
-            int toff = tap_off[t0];
+            // tap (kz,ky,kx) -> byte offset in the halo image, advanced with wave-uniform counters (an LDS table read per tap
+            // would put a dependent LDS round trip in front of every tap's fragment reads)
+            int kx = t0 % g.kw, ky = (t0 / g.kw) % g.kh, kz = t0 / (g.kw * g.kh);
+            int toff = ((kz * g.HH + ky) * g.HWd + kx) * HROWB;
+            auto next_tap = [&]() {
+                toff += HROWB;
+                if (++kx == g.kw) {
+                    kx = 0; toff += (g.HWd - g.kw) * HROWB;
+                    if (++ky == g.kh) { ky = 0; toff += (g.HH - g.kh) * g.HWd * HROWB; }
+                }
+            };
             u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + toff), a1 = *reinterpret_cast<const u32x4*>(ap + toff + 32);
             u32x4 b00 = *reinterpret_cast<const u32x4*>(wcur), b01 = *reinterpret_cast<const u32x4*>(wcur + 32);
             u32x4 b10 = *reinterpret_cast<const u32x4*>(wcur + 32 * HROWB), b11 = *reinterpret_cast<const u32x4*>(wcur + 32 * HROWB + 32);
+            // the first tap's fragments land HERE: without this explicit wait hipcc's counter tracking merges "fragments pending"
+            // from the loop entry into the loop header and puts an s_waitcnt lgkmcnt(0) in front of every tap's MFMAs, i.e.
+            // behind the next tap's reads, which undoes the software pipelining
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
             for (int t = 0; t < nTap; ++t) {
                 u32x4 na0, na1, nb00, nb01, nb10, nb11;
                 if (t + 1 < nTap) {
-                    const int to2 = tap_off[t0 + t + 1];
+                    next_tap();
                     const unsigned char* wn = wcur + (t + 1) * (HNT * HROWB);
-                    na0 = *reinterpret_cast<const u32x4*>(ap + to2); na1 = *reinterpret_cast<const u32x4*>(ap + to2 + 32);
+                    na0 = *reinterpret_cast<const u32x4*>(ap + toff); na1 = *reinterpret_cast<const u32x4*>(ap + toff + 32);
                     nb00 = *reinterpret_cast<const u32x4*>(wn); nb01 = *reinterpret_cast<const u32x4*>(wn + 32);
                     nb10 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB); nb11 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB + 32);
                 }
@@ -248,6 +264,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
                 acc1 = mfma16<BF>(a1, b11, acc1);
                 if (t + 1 < nTap) { a0 = na0; a1 = na1; b00 = nb00; b01 = nb01; b10 = nb10; b11 = nb11; }
             }
+            if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tTap += tn - tq; tq = tn; }
             if (more) store_wgroup((step + 1) & 1, nn);      // that buffer was last read in step-1, retired by its barrier
             if (lastGrp && more) {
                 __syncthreads();                             // every wave is done with this chunk's halo image
@@ -268,8 +285,10 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
                 if (!done) stage_halo_sync((chunk + 1) * HCK);
             }
             __syncthreads();
+            if (g.dbg) tSync += (long long)__builtin_readcyclecounter() - tq;
         }
     }
+    const long long ts2 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
 
     // ---- epilogue: D[row = voxel][col = co]; row = (r&3) + 8*(r>>2) + 4*h ----
     const int co0 = n0 + l31, co1 = n0 + 32 + l31;
@@ -290,18 +309,24 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
     }
+    if (g.dbg && tid == 0) {
+        unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+        d[0] = (unsigned long long)(ts1 - ts0); d[1] = (unsigned long long)tTap; d[2] = (unsigned long long)tSync;
+        d[3] = (unsigned long long)((long long)__builtin_readcyclecounter() - ts2); d[4] = (unsigned long long)((long long)__builtin_readcyclecounter() - ts0);
+        d[5] = (unsigned long long)step;
+    }
 }
 
 static size_t half_lds_bytes(const HalfGeom& g) {
     const size_t HV = (size_t)g.HD * g.HH * g.HWd;
-    return HV * HROWB + 2 * (size_t)g.TG * HNT * HROWB + (HMT + HV + g.kd * g.kh * g.kw) * sizeof(int);
+    return HV * HROWB + 2 * (size_t)g.TG * HNT * HROWB + (HMT + HV) * sizeof(int);
 }
 
 static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                       int epd, int eph, int epw) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kd <= 0 || kh <= 0 || kw <= 0) return false;
     if (pd < 0 || ph < 0 || pw < 0 || pd + epd < 0 || ph + eph < 0 || pw + epw < 0) return false;
-    if (Cin % 4 != 0 || kd * kh * kw > 512) return false;
+    if (Cin % 4 != 0) return false;
     if (Cin < 8 && kd * kh * kw > 1) return false;          // the tap-packed fp32 kernel (conv_fwd_smallcin_kernel) is the better fit
     if (kd == 1 && kh == 1 && kw == 1 && pd == 0 && ph == 0 && pw == 0 && epd == 0 && eph == 0 && epw == 0) {   // 1x1x1: flatten all voxels into W
         const long long rows = (long long)B * D * H * W;
@@ -317,6 +342,7 @@ static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout
     g.nGroups = hcdiv(T, g.TG);
     g.nNt = hcdiv(Cout, HNT); g.CoutPad = g.nNt * HNT; g.nChunks = hcdiv(Cin, HCK);
     g.roundOut = 1;
+    g.dbg = nullptr;
     static const int cand[][3] = {{4, 8, 8}, {8, 8, 4}, {8, 4, 8}, {2, 8, 16}, {2, 16, 8}, {1, 16, 16}, {16, 4, 4}, {4, 4, 16}, {4, 16, 4},
                                   {16, 16, 1}, {16, 1, 16}, {32, 4, 2}, {64, 2, 2}, {256, 1, 1}, {1, 1, 256}, {1, 256, 1}, {1, 8, 32},
                                   {1, 32, 8}, {8, 32, 1}, {32, 8, 1}, {1, 4, 64}, {1, 2, 128}, {128, 2, 1}, {128, 1, 2}};
@@ -347,6 +373,18 @@ static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout
 }  // namespace diqt
 
 using namespace diqt;
+
+static unsigned long long* g_hdbg = nullptr;    // diagnostic only (DIQT_CONVH_DBG=1)
+static unsigned g_hdbg_n = 0;
+// diagnostic only (not part of include/diqt.h): per-workgroup cycle stamps of the last DIQT_CONVH_DBG=1 launch:
+// [prologue, tap loops, store + barrier waits, epilogue, lifetime, steps, -, -]
+extern "C" int diqt_debug_convh_stamps(unsigned long long* host_out, unsigned max_wg) {
+    if (!g_hdbg || !g_hdbg_n) return 0;
+    const unsigned n = g_hdbg_n < max_wg ? g_hdbg_n : max_wg;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    if (hipMemcpy(host_out, g_hdbg, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return (int)n;
+}
 
 // number of 16-bit elements of the packed low-precision weight (same [chunk][tap][co pad 64][32] order as the fp32 packing)
 extern "C" size_t diqt_conv_packed_h_elems(int Cout, int Cin, int kd, int kh, int kw) {
@@ -382,6 +420,12 @@ extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const flo
     DIQT_REQUIRE(half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw), DIQT_E_UNSUPPORTED,
                  "conv3d_fwd_h: shape not supported by the low-precision kernel (diqt_conv3d_fwd_h_supported == 0)");
     g.roundOut = round_out ? 1 : 0;
+    const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
+    static const bool dbg_on = [] { const char* e = getenv("DIQT_CONVH_DBG"); return e && e[0] == '1'; }();
+    if (dbg_on && nwg <= 65536) {
+        if (!g_hdbg) DIQT_REQUIRE(hipMalloc(&g_hdbg, (size_t)65536 * 8 * sizeof(unsigned long long)) == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: debug buffer");
+        g.dbg = g_hdbg; g_hdbg_n = nwg;
+    }
     const size_t lds = half_lds_bytes(g);
     const int HV = g.HD * g.HH * g.HWd;
     static const bool nopref = [] { const char* e = getenv("DIQT_CONVH_NOPREF"); return e && e[0] == '1'; }();
@@ -393,7 +437,6 @@ extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const flo
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, (hipStream_t)stream, x, static_cast<const unsigned short*>(packed_h), bias,
                        residual, y, g);
     return check_launch("conv3d_fwd_h");

@@ -40,6 +40,16 @@ if mode in ("fwdh",):           # fp16 / bf16 operand kernel (LP=fp16|bf16)
     with torch.no_grad(), ops.low_precision(os.environ.get("LP", "fp16")):
         ms = timeit(lambda: ops.conv3d(x, w, bias, (1, 1, 1)), iters)
     print(f"conv fwd {os.environ.get('LP', 'fp16')}  B={B} {S}^3 {Cin}->{Cout}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
+    if os.environ.get("DIQT_CONVH_DBG") == "1":
+        import ctypes
+        import numpy as np
+        lib = _lib.load()
+        buf = np.zeros((65536, 8), dtype=np.uint64)
+        n = lib.diqt_debug_convh_stamps(buf.ctypes.data_as(ctypes.c_void_p), 65536)
+        st = buf[:n].astype(np.int64)
+        names = ["prologue", "tap loops", "store+barrier", "epilogue", "lifetime", "steps"]
+        print(f"{n} workgroups; median cycles:", {k: int(np.median(st[:, i])) for i, k in enumerate(names)})
+        print("p10/p90 lifetime:", int(np.percentile(st[:, 4], 10)), int(np.percentile(st[:, 4], 90)))
 if mode in ("bwdw", "both"):
     xr = x.clone()
     y = ops.conv3d(xr, w, bias, (1, 1, 1))

@@ -91,6 +91,10 @@ def cast_torch_tensor(fn, cast_fp16=False):
         all_args = tuple(torch.from_numpy(t) if isinstance(t, np.ndarray) else t for t in all_args)
         if cast_device:
             all_args = tuple(t.to(dev) if isinstance(t, torch.Tensor) else t for t in all_args)
+        if cast_fp16 and getattr(model, 'cast_half_at_training', False):
+            # the reference hands .half() tensors to the model (:138-139); activations stay fp32 in HBM here, so the inputs are
+            # rounded through fp16 instead -- the same values
+            all_args = tuple(t.half().float() if isinstance(t, torch.Tensor) and t.is_floating_point() else t for t in all_args)
         args, kw_values = all_args[:split], all_args[split:]
         return fn(model, *args, **dict(zip(keys, kw_values)))
     return inner
@@ -309,7 +313,14 @@ class ImagenTrainer(nn.Module):
         assert not ImagenTrainer.locked, 'ImagenTrainer can only be initialized once per process - for the sake of distributed training, you will now have to create a separate script to train each unet (or a script that accepts unet number as an argument)'
         assert exists(imagen) ^ exists(imagen_checkpoint_path), 'either imagen instance is passed into the trainer, or a checkpoint path that contains the imagen config'
         assert exists(imagen), 'imagen_checkpoint_path (CLI configs) is dead code in the reference and not built'
-        assert not fp16 and precision in (None, 'no'), 'the MI355X path computes in fp32 (BASELINE: fp32 tolerance)'
+        # mixed precision (trainer.py:293-311: Accelerator(mixed_precision=...)): the model forward runs under torch.autocast, where
+        # conv3d / linear forwards take the fp16 / bf16 MFMA kernel (ops.lp_mode); master weights, gradients, loss and the
+        # optimiser stay fp32 and every backward kernel is fp32, so no loss scaling is needed (the scaler slot keeps its
+        # checkpoint key with an empty state)
+        assert not (fp16 and exists(precision)), 'either set fp16 = True or forward the precision ("fp16", "bf16") to Accelerator'
+        self.mixed_precision = default(precision, 'fp16' if fp16 else 'no')
+        assert self.mixed_precision in ('no', 'fp16', 'bf16'), self.mixed_precision
+        self.cast_half_at_training = self.mixed_precision == 'fp16'
         assert max_grad_norm is None and warmup_steps is None and cosine_decay_max_steps is None, \
             'grad clipping / LR schedules are off in the reference scripts (trainer.py:245-252) and not built'
         self.configs = configs
@@ -729,6 +740,11 @@ class ImagenTrainer(nn.Module):
             output = self.imagen.sample(*args, device=self.device, **kwargs)
         return output
 
+    def _autocast(self):
+        if self.mixed_precision == 'no' or not torch.cuda.is_available():
+            return nullcontext()
+        return torch.autocast('cuda', dtype=torch.float16 if self.mixed_precision == 'fp16' else torch.bfloat16)
+
     @partial(cast_torch_tensor, cast_fp16=True)
     def forward(self, *args, unet_number=None, max_batch_size=None, **kwargs):
         """trainer.py:1099-1128 -> (total_loss, pred, x_noisy, lowres)."""
@@ -742,7 +758,8 @@ class ImagenTrainer(nn.Module):
         for chunk_size_frac, (chunked_args, chunked_kwargs) in split_args_and_kwargs(*args, split_size=max_batch_size, **kwargs):
             self._micro_step += 1
             sync = self._is_sync_step()
-            out = self.imagen(*chunked_args, unet=self.unet_being_trained, unet_number=unet_number, **chunked_kwargs)
+            with self._autocast():
+                out = self.imagen(*chunked_args, unet=self.unet_being_trained, unet_number=unet_number, **chunked_kwargs)
             # Imagen.forward returns (loss, pred, x_noisy, lowres); ElucidatedImagen.forward a scalar loss (the reference
             # trainer crashes on the latter, trainer.py:1119 — driving EDM is a superset feature here)
             loss, pred, x_noisy, lowres_cond_img_noisy = out if isinstance(out, tuple) else (out, None, None, None)

@@ -172,3 +172,45 @@ def test_family_a_unet_under_autocast_vs_reference_autocast(mode):
     own, refs = rel(ylp, y32), rel(reflp, ref32)
     assert 0 < own <= 1.5 * refs, (own, refs)
     assert rel(ylp, reflp) <= 1.5 * refs, (rel(ylp, reflp), refs)
+
+
+def test_trainer_mixed_precision_switch():
+    """ImagenTrainer(fp16=True) / precision='bf16' (trainer.py:293-311): forward under autocast on the fp16 / bf16 kernel, fp32
+    gradients, optimiser and master weights; the first micro-step's loss agrees with the fp32 trainer's to low-precision
+    round-off and an optimiser step is taken after `gradient_accumulation_steps` micro-steps."""
+    from diffusioniqt_amd import ops
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256, Imagen, NullUnet
+    from diffusioniqt_amd.trainer import ImagenTrainer
+    g = load_golden('unetA_tiny')
+    kw = json.loads(str(g['kwargs']))
+    configs = {'Data': {'norm': 'z-score'}, 'Train': {'batch_sample': False, 'patch_size_sub': 8, 'pred_obj': 'x_start'},
+               'Eval': {'repeat': 1}}
+    hr, lr, noise, times = T(g['hr']), T(g['lowres']), T(g['noise']), T(g['times'])
+    losses = {}
+    for mode in ('no', 'fp16', 'bf16'):
+        unet = SRUnet256(**kw)
+        unet.load_state_dict(O.hash_fill_state_dict(unet.state_dict(), 0))
+        imagen = Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=float(g['min_bound']), image_sizes=(8, 8), channels=1,
+                        pred_objectives='x_start', timesteps=4, dynamic_thresholding=False, p2_loss_weight_gamma=0.0,
+                        cond_drop_prob=0.0).to(DEV)
+        imagen.noise_schedulers[1].sample_random_times = lambda b, device: times.clone()
+        ImagenTrainer.locked = False
+        trainer = ImagenTrainer(configs=configs, imagen=imagen, gradient_accumulation_steps=2, verbose=False,
+                                **({'fp16': True} if mode == 'fp16' else {'precision': mode} if mode == 'bf16' else {}))
+        assert trainer.mixed_precision == mode and trainer.cast_half_at_training == (mode == 'fp16')
+        w0 = trainer.imagen.unets[1].final_conv.weight.detach().clone()
+        seen = []
+        real = ops._conv_fwd_half
+        ops._conv_fwd_half = lambda *a, **k: (seen.append(a[-1]), real(*a, **k))[1]
+        try:
+            out = [trainer(hr, lowres_img=lr, unet_number=2, max_batch_size=2, noise=noise) for _ in range(2)]
+        finally:
+            ops._conv_fwd_half = real
+        trainer.update(unet_number=2)
+        losses[mode] = float(out[0][0]) if isinstance(out[0], tuple) else float(out[0])
+        assert (len(seen) > 0) == (mode != 'no') and all(b == (1 if mode == 'bf16' else 0) for b in seen)
+        w1 = trainer.imagen.unets[1].final_conv.weight.detach()
+        assert torch.isfinite(w1).all() and not torch.equal(w1, w0)
+    assert abs(losses['no'] - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    assert abs(losses['fp16'] - losses['no']) <= 5e-3 * abs(losses['no']), losses
+    assert abs(losses['bf16'] - losses['no']) <= 3e-2 * abs(losses['no']), losses

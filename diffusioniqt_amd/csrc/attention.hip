@@ -22,9 +22,8 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
                                                                const float* __restrict__ rel, const float* __restrict__ null_bias,
                                                                float* __restrict__ out, int n, int h, int E, int ns, int causal,
                                                                float scale) {
-    constexpr int D = 32 * ND, ROW = D + 4;
-    __shared__ __attribute__((aligned(16))) float Ks[AKT * ROW];
-    __shared__ __attribute__((aligned(16))) float Vs[AKT * ROW];
+    constexpr int D = 32 * ND, ROW = D + 4, NPF = AKT * (2 * D / 4) / 256;    // float4 pieces of a K|V tile per thread
+    __shared__ __attribute__((aligned(16))) float KVs[2][2][AKT * ROW];       // [buffer][K | V][key][ROW]
     const int g = blockIdx.y;
     const int M = E + ns, R = n * h;                       // keys, query rows of this batch entry
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,19 +49,37 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
         for (int i = 0; i < 16; ++i) o[c][i] = 0.f;
     float mrun = -INFINITY, lrun = 0.f;
 
-    const int ntiles = (M + AKT - 1) / AKT;
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();                                   // previous tile's fragment reads are done
-        // stage K | V rows of keys [32t, 32t+32): kv row = [k(D) | v(D)]; 32 keys x 2D floats = 16 x D float4 -> D/16 per thread
-        for (int e = tid; e < AKT * (2 * D / 4); e += 256) {
+    // K | V tile of keys [32t, 32t+32): kv row = [k(D) | v(D)].  The next tile is loaded global -> registers BEFORE this tile's
+    // MFMAs and written to the other LDS buffer after them: one barrier per tile and no memory round trip between tiles.
+    // Loads are unconditional (clamped key, zero-selected): a guarded load becomes an exec-masked branch with its own wait.
+    float4 pre[NPF];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = u * 256 + tid;
             const int key = e / (2 * D / 4), c4 = (e % (2 * D / 4)) * 4;
             const int j = t * AKT + key;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < M) v = *reinterpret_cast<const float4*>(kvg + (size_t)j * 2 * D + c4);
-            if (c4 < D) *reinterpret_cast<float4*>(Ks + key * ROW + c4) = v;
-            else *reinterpret_cast<float4*>(Vs + key * ROW + (c4 - D)) = v;
+            const float4 v = *reinterpret_cast<const float4*>(kvg + (size_t)min(j, M - 1) * 2 * D + c4);
+            pre[u] = j < M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = u * 256 + tid;
+            const int key = e / (2 * D / 4), c4 = (e % (2 * D / 4)) * 4;
+            if (c4 < D) *reinterpret_cast<float4*>(&KVs[buf][0][key * ROW + c4]) = pre[u];
+            else *reinterpret_cast<float4*>(&KVs[buf][1][key * ROW + (c4 - D)]) = pre[u];
+        }
+    };
+    const int ntiles = (M + AKT - 1) / AKT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const float* Ks = KVs[t & 1][0];
+        const float* Vs = KVs[t & 1][1];
+        if (t + 1 < ntiles) load_tile(t + 1);
         // ---- S^T = K Q^T ----
         f32x16 s;
 #pragma unroll
@@ -116,6 +133,8 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
 #pragma unroll
             for (int c = 0; c < ND; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * c], s[i], o[c], 0, 0, 0);
         }
+        if (t + 1 < ntiles) store_tile((t + 1) & 1);       // that buffer was last read in tile t-1, retired by its barrier
+        __syncthreads();
     }
     // ---- epilogue: O^T rows are head-dim indices, columns are queries: out[g, r, dd] = o / l ----
     if (rvalid) {

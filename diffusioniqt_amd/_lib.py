@@ -103,6 +103,8 @@ PROTOTYPES = {
     "diqt_linear_small_workspace_bytes": (Z, [I, I, I]),
     "diqt_linear_small_fwd": (I, [P, P, P, P, I, I, I, P]),
     "diqt_linear_small_bwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, P]),
+    "diqt_mqa_attention_fwd_h": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, P]),
+    "diqt_cast_to_h": (I, [P, P, Z, I, P]),
     "diqt_conv_packed_h_elems": (Z, [I, I, I, I, I]),
     "diqt_conv_pack_weight_h": (I, [P, P, I, I, I, I, I, I, P]),
     "diqt_conv3d_fwd_h_supported": (I, [I] * 15),

@@ -1348,8 +1348,8 @@ static unsigned g_dbg_n = 0;
 extern "C" int diqt_debug_conv_stamps(unsigned long long* host_out, unsigned max_wg) {
     if (!g_dbg_ptr || !g_dbg_n) return 0;
     const unsigned n = g_dbg_n < max_wg ? g_dbg_n : max_wg;
-    hipDeviceSynchronize();
-    hipMemcpy(host_out, g_dbg_ptr, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host_out, g_dbg_ptr, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     return (int)n;
 }
 
@@ -1532,7 +1532,7 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
             static unsigned long long* pdbg = nullptr;
             static const bool pdbg_on = [] { const char* e = getenv("DIQT_CONV_DBG"); return e && e[0] == '1'; }();
             if (pdbg_on) {
-                if (!pdbg) hipMalloc(&pdbg, (size_t)65536 * 8 * sizeof(unsigned long long));
+                if (!pdbg) (void)hipMalloc(&pdbg, (size_t)65536 * 8 * sizeof(unsigned long long));
                 g.dbg = pdbg; g_dbg_ptr = pdbg; g_dbg_n = grid;
             }
             hipLaunchKernelGGL(pk, dim3(grid), dim3(256), plds, (hipStream_t)stream, x, packed, bias, residual, y, g, (int)nwg, ablate);
@@ -1560,7 +1560,7 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
     static unsigned long long* dbg_buf = nullptr;
     static const bool dbg_on = [] { const char* e = getenv("DIQT_CONV_DBG"); return e && e[0] == '1'; }();
     if (dbg_on) {     // diagnostic build path only: cycle stamps per workgroup, read back with diqt_debug_conv_stamps()
-        if (!dbg_buf) hipMalloc(&dbg_buf, (size_t)65536 * 8 * sizeof(unsigned long long));
+        if (!dbg_buf) (void)hipMalloc(&dbg_buf, (size_t)65536 * 8 * sizeof(unsigned long long));
         if (nwg <= 65536) g.dbg = dbg_buf;
         g_dbg_ptr = dbg_buf; g_dbg_n = nwg <= 65536 ? nwg : 0;
     }
@@ -1903,7 +1903,7 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
         static unsigned long long* bdbg = nullptr;
         static const bool bdbg_on = [] { const char* e = getenv("DIQT_CONV_DBG"); return e && e[0] == '1'; }();
         if (bdbg_on) {
-            if (!bdbg) hipMalloc(&bdbg, (size_t)65536 * 8 * sizeof(unsigned long long));
+            if (!bdbg) (void)hipMalloc(&bdbg, (size_t)65536 * 8 * sizeof(unsigned long long));
             b2.g.dbg = bdbg; g_dbg_ptr = bdbg; g_dbg_n = g.nChunks * b2.coBlocks * b2.tapGroups * ks2 * (splitCo ? 4 : 8);
         }
         if (dbias) { bias_part = slabs + (size_t)ksplit * g.nChunks * T * g.CoutPad * CK; bias_parts = ks2; }

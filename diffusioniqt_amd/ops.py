@@ -997,6 +997,13 @@ def mqa_attention_nograd(q, kv_ext, rel, null_bias, n, h, d, n_extra, n_self, ca
     _chk(q, kv_ext, rel, null_bias)
     G = q.shape[0]
     out = torch.empty((G, n, h * d), dtype=torch.float32, device=q.device)
+    lp = lp_mode()
+    if lp is not None:          # autocast: q k^T and p v on the fp16 / bf16 MFMA, soft-max statistics in fp32
+        kv_h = torch.empty(kv_ext.shape, dtype=torch.int16, device=q.device)
+        _lib.call("diqt_cast_to_h", kv_ext, kv_h, kv_ext.numel(), lp, _stream())
+        _lib.call("diqt_mqa_attention_fwd_h", q, kv_h, rel, null_bias, out, G, n, h, d, n_extra, n_self, int(causal), float(scale),
+                  lp, 1, _stream())
+        return out
     _lib.call("diqt_mqa_attention_fwd", q, kv_ext, rel, null_bias, out, G, n, h, d, n_extra, n_self, int(causal), float(scale),
               _stream())
     return out

@@ -377,6 +377,17 @@ int diqt_attn_softmax_bwd_ws(const float* p, const float* dp, float* dsim, float
 int diqt_mqa_attention_fwd(const float* q, const float* kv, const float* rel, const float* null_bias, float* out, int G,
                            int n, int h, int d, int n_extra, int n_self, int causal, float scale, void* stream);
 
+/* Mixed-precision variant for torch.autocast (the reference's `einsum('b h i d, b j d -> b h i j')` and `einsum(attn, v)` run in
+ * fp16 / bf16 there, its soft-max in fp32; imagen_video.py:483-520): q k^T and p v on v_mfma_f32_32x32x16_{f16,bf16} with fp32
+ * accumulation and fp32 soft-max statistics; q and out stay fp32 in HBM, `kv_h` is the 16-bit copy of kv (diqt_cast_to_h: every
+ * workgroup streams all keys, so the copy halves the dominant traffic); round_out = 1 rounds the result once to the operand type.
+ * Otherwise the arguments and layouts of diqt_mqa_attention_fwd.                                      */
+int diqt_mqa_attention_fwd_h(const float* q, const void* kv_h, const float* rel, const float* null_bias, float* out, int G, int n,
+                             int h, int d, int n_extra, int n_self, int causal, float scale, int bf16, int round_out, void* stream);
+/* y[i] = (fp16 | bf16) x[i]: the 16-bit copy of the K|V rows that diqt_mqa_attention_fwd_h streams (n even).                   */
+int diqt_cast_to_h(const float* x, void* y_h, size_t n, int bf16, void* stream);
+
+
 /* batched fp32 MFMA GEMM: C[g] = alpha * op(A[g]) * op(B[g]) (+ beta*C[g]); row-major, strides in floats */
 int diqt_bgemm(const float* A, const float* Bm, float* C, int batch, int M, int N, int K,
                int transA, int transB, long long strideA, long long strideB, long long strideC,

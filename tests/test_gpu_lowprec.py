@@ -214,3 +214,44 @@ def test_trainer_mixed_precision_switch():
     assert abs(losses['no'] - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
     assert abs(losses['fp16'] - losses['no']) <= 5e-3 * abs(losses['no']), losses
     assert abs(losses['bf16'] - losses['no']) <= 3e-2 * abs(losses['no']), losses
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("G,n,h,d,E,use_rel,causal", [(2, 40, 4, 64, 1, False, False), (3, 16, 8, 64, 1, True, True),
+                                                       (1, 300, 2, 32, 3, False, False), (2, 33, 3, 32, 1, True, False),
+                                                       (1, 1, 8, 64, 1, True, True), (1, 2048, 8, 64, 5, False, False),
+                                                       (2, 70, 2, 64, 1, True, True)])
+def test_fused_attention_low_precision(G, n, h, d, E, use_rel, causal, mode):
+    """diqt_mqa_attention_fwd_h under ops.low_precision: float64 attention of the operands as the kernel rounds them (scaled q, k, v
+    and the probabilities to 16 bit; scores, soft-max statistics and accumulation in fp32), result rounded once to the operand type."""
+    from diffusioniqt_amd import ops
+    dt = LP[mode]
+    ulp = 2.0 ** -10 if mode == 'fp16' else 2.0 ** -7
+    gen = torch.Generator().manual_seed(G * 100 + n)
+    q = torch.randn(G, n, h * d, generator=gen)
+    kv = torch.randn(G, E + n, 2 * d, generator=gen)
+    rel = torch.randn(2 * n - 1, h, generator=gen) if use_rel else None
+    nb = torch.randn(h, generator=gen) if use_rel else None
+    scale = d ** -0.5
+    qd = (q * scale).to(dt).double().reshape(G, n, h, d)
+    k, v = kv.to(dt).double()[..., :d], kv.to(dt).double()[..., d:]
+    sim = torch.einsum('gihd,gjd->gihj', qd, k)
+    if use_rel:
+        i = torch.arange(n)[:, None]; j = torch.arange(n)[None, :]
+        sim[..., E:] += rel.double()[(i - j + n - 1)].permute(0, 2, 1)[None]
+        sim[..., E - 1] += nb.double()[None, None, :]
+    if causal:
+        i = torch.arange(n)[:, None]; j = torch.arange(n)[None, :]
+        sim[..., E:] = sim[..., E:].masked_fill((j > i)[None, :, None, :].expand(G, n, h, n), float('-inf'))
+    p = sim.softmax(dim=-1)
+    ref = torch.einsum('gihj,gjd->gihd', p, v).reshape(G, n, h * d)
+    with ops.low_precision(mode), torch.no_grad():
+        got = ops.mqa_attention_nograd(q.to(DEV), kv.to(DEV), rel.to(DEV) if use_rel else None, nb.to(DEV) if use_rel else None,
+                                       n, h, d, E, n, causal, scale).cpu().double()
+    # un-normalised probabilities are rounded to 16 bit before p v (relative error <= ulp/2 each) and the result once more
+    err = (got - ref).abs().max().item()
+    assert err <= 2.5 * ulp * ref.abs().max().item(), (err, ref.abs().max().item())
+    with torch.no_grad():
+        full = ops.mqa_attention_nograd(q.to(DEV), kv.to(DEV), rel.to(DEV) if use_rel else None, nb.to(DEV) if use_rel else None,
+                                        n, h, d, E, n, causal, scale).cpu().double()
+    assert not torch.equal(full, got)          # the low-precision kernel really ran

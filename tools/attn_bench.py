@@ -19,7 +19,10 @@ for name, G, n, h, d, E, use_rel, causal in SHAPES:
     kv = torch.randn(G, E + n, 2 * d, device=dev)
     rel = torch.randn(2 * n - 1, h, device=dev) if use_rel else None
     nb = torch.randn(h, device=dev) if use_rel else None
-    fn = lambda: ops.mqa_attention_nograd(q, kv, rel, nb, n, h, d, E, n, causal, d ** -0.5)
+    lpm = os.environ.get("LP", "off")
+    def fn():
+        with ops.low_precision(lpm):
+            return ops.mqa_attention_nograd(q, kv, rel, nb, n, h, d, E, n, causal, d ** -0.5)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

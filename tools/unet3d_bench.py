@@ -17,9 +17,16 @@ t = torch.randn(B, device=dev) * 0.5
 lt = torch.full((B,), 0.2, device=dev)
 
 
+AC = os.environ.get("AUTOCAST")       # fp16 | bf16: run under torch.autocast
+
+
 def step():
     with torch.no_grad():
-        unet(x, t, lowres_cond_img=lr, lowres_noise_times=lt)
+        if AC:
+            with torch.autocast('cuda', dtype=torch.float16 if AC == 'fp16' else torch.bfloat16):
+                unet(x, t, lowres_cond_img=lr, lowres_noise_times=lt)
+        else:
+            unet(x, t, lowres_cond_img=lr, lowres_noise_times=lt)
 
 
 for _ in range(3):

@@ -380,6 +380,16 @@ def test_bgemm_large_tiles_all_layouts(ops, g_, M, N, K):
     close(Bd.grad, Br.grad, tol=1e-4, what="bgemm dB")
 
 
+def test_softmax_over_tokens_with_few_columns(ops):
+    """LinearAttention's k.softmax(dim=-2) on [b*h, n, d] (imagen_pytorch3D.py:926-1016): the workgroup-per-outer kernel (inner divides
+    1024, n >= 64) and the one-thread-per-column kernel next to it."""
+    gen = torch.Generator().manual_seed(21)
+    for outer, n, inner in ((8, 512, 64), (3, 100, 32), (2, 64, 1024), (2, 70, 48)):
+        x = torch.randn(outer, n, inner, generator=gen) * 3
+        got = ops.softmax(x.to(DEV), dim=1, scale=0.125)
+        close(got, 0.125 * torch.softmax(x.double(), dim=1), tol=3e-5, what=f"softmax over n {outer}x{n}x{inner}")
+
+
 def test_softmax_few_long_rows(ops):
     """GlobalContext soft-max over all positions: 8 rows of 32768 (one workgroup per row)."""
     gen = torch.Generator().manual_seed(5)

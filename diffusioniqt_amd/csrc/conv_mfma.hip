@@ -370,6 +370,112 @@ __global__ __launch_bounds__(256, CKT == 16 ? 3 : 2) void conv_fwd_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// 1x1x1 filters / Linear rows (pixel-shuffle and down-sample projections, attention and feed-forward projections, res_conv):
+// a plain GEMM y[rows][Cout] = x[rows][Cin] W^T.  With ONE tap per 32-channel chunk the generic kernel above stages a chunk,
+// issues 32 MFMAs per wave and stages again -- every chunk pays a global round trip (61-71 TFLOP/s).  Here the next chunk's
+// A rows and weight panel are loaded global -> registers BEFORE the chunk's MFMAs and written to the other LDS buffer after
+// them (one barrier per chunk, no memory latency between chunks).  Same tile (128 rows x 64 co, 4 waves), packed weights,
+// fragment order and buffer-descriptor epilogue as conv_fwd_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv1x1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                             const float* __restrict__ bias, const float* __restrict__ residual,
+                                                             float* __restrict__ y, ConvGeom g) {
+    __shared__ __attribute__((aligned(16))) float As[2][MTILE * LDSROW];
+    __shared__ __attribute__((aligned(16))) float Ws[2][NT * LDSROW];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = L % g.nNt, mt = L / g.nNt;
+    const int n0 = nt * NT;
+    const long long rows = (long long)g.B * g.D * g.H * g.W;          // make_geom flattened every voxel into W
+    const long long r0 = (long long)mt * MTILE;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
+
+    // this thread's pieces: A rows (tid >> 3) + 32 u, channel quad (tid & 7); weight rows (tid >> 3), +32
+    const int prow = tid >> 3, pc4 = (tid & 7) * 4;
+    unsigned aoff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long r = r0 + prow + 32 * u;
+        aoff[u] = r < rows ? (unsigned)(r * g.Cin * 4) : BUF_OOB;
+    }
+    u32x4 ra[4];
+    float4 rw0, rw1;
+    auto load_chunk = [&](int chunk) {
+        const int ci = chunk * CK + pc4;
+        const unsigned coff = ci < g.Cin ? (unsigned)ci * 4u : BUF_OOB_C;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, aoff[u] + coff, 0, 0);
+        const float* wchunk = wp + ((size_t)chunk * g.CoutPad + n0) * CK;
+        rw0 = *reinterpret_cast<const float4*>(wchunk + (size_t)prow * CK + pc4);
+        rw1 = *reinterpret_cast<const float4*>(wchunk + (size_t)(prow + 32) * CK + pc4);
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4*>(&As[buf][(prow + 32 * u) * LDSROW + pc4]) = ra[u];
+        *reinterpret_cast<float4*>(&Ws[buf][prow * LDSROW + pc4]) = rw0;
+        *reinterpret_cast<float4*>(&Ws[buf][(prow + 32) * LDSROW + pc4]) = rw1;
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < g.nChunks; ++chunk) {
+        if (chunk + 1 < g.nChunks) load_chunk(chunk + 1);
+        const float* ap = &As[chunk & 1][(wave * 32 + l31) * LDSROW + 4 * h];
+        const float* bp = &Ws[chunk & 1][l31 * LDSROW + 4 * h];
+        float4 a = *reinterpret_cast<const float4*>(ap);
+        float4 b0 = *reinterpret_cast<const float4*>(bp);
+        float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 an, b0n, b1n;
+            if (q < 3) {
+                an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+                b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+                b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+            if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
+        }
+        if (chunk + 1 < g.nChunks) store_chunk((chunk + 1) & 1);       // last read in chunk-1, retired by its barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row][col = co]; row = (r&3) + 8*(r>>2) + 4*h ----
+    const int co0 = n0 + l31, co1 = n0 + 32 + l31;
+    const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
+    const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
+    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long row = r0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const unsigned off = row < rows ? (unsigned)(row * g.Cout * 4) : BUF_OOB;
+        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        if (residual) {        // wave-uniform
+            v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+            v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward for Cin <= 4 (the init convs: 2 -> 64 3x3x3 of Family A, the (1,k,k) cross-embed convs of Family B): the GEMM K
 // axis is (tap, ci) packed densely -- K = taps * CINP in chunks of 32 -- instead of one 32-wide (mostly zero) channel chunk
 // per tap: 13.5x fewer MFMAs for 3x3x3 x 2 channels.  Per chunk an im2col tile As[128 voxels][32 k] is gathered from the
@@ -1591,6 +1697,11 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
     }
     DIQT_REQUIRE(!stats || buf, DIQT_E_UNSUPPORTED, "conv3d_fwd: output statistics need the buffer-path kernel");
     g.stats = stats;
+    static const bool no1x1 = [] { const char* e = getenv("DIQT_CONV_NO1X1"); return e && e[0] == '1'; }();
+    if (buf && !stats && !dbg_on && !no1x1 && kd * kh * kw == 1 && g.B == 1 && g.D == 1 && g.H == 1 && g.Wo == g.W && g.TW == MTILE) {     // the flattened-rows geometry of make_geom
+        hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, packed, bias, residual, y, g);
+        return check_launch("conv3d_fwd(1x1x1)");
+    }
     hipLaunchKernelGGL(kern, dim3(gridx), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
     return check_launch("conv3d_fwd");
 }

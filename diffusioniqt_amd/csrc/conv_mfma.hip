@@ -1580,9 +1580,55 @@ extern "C" int diqt_conv3d_fwd_ws(const float* x, const float* packed, const flo
                            pw, epd, eph, epw, stream, nullptr);
 }
 
+static int conv3d_fwd_one(const float* x, const float* packed, const float* bias, const float* residual,
+                          float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                          int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats);
+
+// The fast kernels address x and y through 32-bit buffer descriptors (tensors < 1 GiB).  Larger launches -- big patch batches are the
+// natural way to use 288 GB of HBM -- are cut into independent sub-launches below that size: row ranges for the flattened 1x1x1 /
+// Linear geometry, batch-entry ranges otherwise (a single batch entry >= 1 GiB still takes the pointer-arithmetic kernel).
 static int conv3d_fwd_impl(const float* x, const float* packed, const float* bias, const float* residual,
                            float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
                            int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats) {
+    const long long Do = (long long)D + 2 * pd + epd - kd + 1, Ho = (long long)H + 2 * ph + eph - kh + 1, Wo = (long long)W + 2 * pw + epw - kw + 1;
+    const unsigned long long lim = (1ull << 30) - 1;
+    if (B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Do > 0 && Ho > 0 && Wo > 0) {
+        const unsigned long long xin = (unsigned long long)D * H * W * Cin * 4ull, yout = (unsigned long long)Do * Ho * Wo * Cout * 4ull;
+        const bool flat = kd == 1 && kh == 1 && kw == 1 && !pd && !ph && !pw && !epd && !eph && !epw;
+        if ((xin * B > lim || yout * B > lim) && !stats) {
+            if (flat) {
+                const long long rows = (long long)B * D * H * W;
+                long long per = (long long)(lim / (4ull * (unsigned long long)(Cin > Cout ? Cin : Cout))) / MTILE * MTILE;
+                if (per >= MTILE && rows > per && rows < (1ll << 31)) {
+                    for (long long r = 0; r < rows; r += per) {
+                        const int nr = (int)(rows - r < per ? rows - r : per);
+                        const int rc = conv3d_fwd_one(x + r * Cin, packed, bias, residual ? residual + r * Cout : nullptr, y + r * Cout,
+                                                      nullptr, 0, 1, 1, 1, nr, Cin, Cout, 1, 1, 1, 0, 0, 0, 0, 0, 0, stream, nullptr);
+                        if (rc) return rc;
+                    }
+                    return DIQT_OK;
+                }
+            } else if (B > 1 && xin <= lim && yout <= lim) {
+                unsigned long long per = lim / (xin > yout ? xin : yout);
+                if (per < 1) per = 1;
+                for (int b0 = 0; b0 < B; b0 += (int)per) {
+                    const int nb = B - b0 < (int)per ? B - b0 : (int)per;
+                    const int rc = conv3d_fwd_one(x + (size_t)b0 * (xin / 4), packed, bias, residual ? residual + (size_t)b0 * (yout / 4) : nullptr,
+                                                  y + (size_t)b0 * (yout / 4), nullptr, 0, nb, D, H, W, Cin, Cout, kd, kh, kw, pd,
+                                                  ph, pw, epd, eph, epw, stream, nullptr);
+                    if (rc) return rc;
+                }
+                return DIQT_OK;
+            }
+        }
+    }
+    return conv3d_fwd_one(x, packed, bias, residual, y, workspace, workspace_bytes, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph,
+                          epw, stream, stats);
+}
+
+static int conv3d_fwd_one(const float* x, const float* packed, const float* bias, const float* residual,
+                          float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                          int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats) {
     DIQT_REQUIRE(x && packed && y, DIQT_E_ALIGN, "conv3d_fwd: null pointer");
     ConvGeom g;
     int rc = make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);

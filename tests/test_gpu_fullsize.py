@@ -134,3 +134,29 @@ def test_c2_sampling_and_training_flow_full_size():
     img, noisy, x0 = trainer.sample(batch_size=8, start_image_or_video=lr, start_at_unet_number=2, use_tqdm=False)
     assert img.shape == (8, 1, 32, 32, 32) and torch.isfinite(img).all() and img.min().item() >= mb - 1e-6
     assert len(noisy) == 33 and len(x0) == 33 and all(np.isfinite(a).all() for a in noisy)
+
+
+def test_convs_beyond_one_gib_split_into_fast_sub_launches():
+    """Tensors >= 1 GiB (big patch batches on 288 GB of HBM) are cut into sub-launches below the 32-bit buffer-descriptor range: a
+    Linear with a 1.25 GiB output and a 3x3x3 conv whose batch makes x and y 1.5 GiB each give, slice for slice, the bits of the same
+    op on the slice alone."""
+    from diffusioniqt_amd import ops
+    torch.manual_seed(0)
+    dev = "cuda"
+    with torch.no_grad():
+        rows, Cin, Cout = 640 * 1024, 64, 512                        # y: 1.25 GiB
+        x = torch.randn(rows, Cin, device=dev)
+        w = torch.randn(Cout, Cin, device=dev) * 0.1
+        b = torch.randn(Cout, device=dev)
+        y = ops.linear(x, w, b)
+        for lo in (0, 524160 - 4096, rows - 8192):                   # across the first cut (524160 rows = 1 GiB - 128 rows of 2 KB);
+            # 8192-row slices: large enough that the slice alone is not a split-K launch (which sums in another order)
+            assert torch.equal(y[lo:lo + 8192], ops.linear(x[lo:lo + 8192].contiguous(), w, b)), lo
+        del x, y
+        B, S, C = 40, 32, 256                                         # 32 MiB per batch entry: x and y are 1.25 GiB each
+        x = torch.randn(B, S, S, S, C, device=dev)
+        w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.02
+        b = torch.randn(C, device=dev)
+        y = ops.conv3d(x, w, b, (1, 1, 1))
+        for lo in (0, 30, 31, 39):                                    # sub-launches hold 31 batch entries
+            assert torch.equal(y[lo:lo + 1], ops.conv3d(x[lo:lo + 1].contiguous(), w, b, (1, 1, 1)))

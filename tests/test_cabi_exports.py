@@ -38,6 +38,14 @@ def test_shape_queries_without_a_gpu():
     assert _lib.query("diqt_conv3d_lds_bytes", 0, 4, 4, 3, 3, 3, 1, 1, 1, 0, 0, 0) < 0
     assert _lib.query("diqt_reduce_workspace_bytes", 8, 64) > 0
     assert _lib.query("diqt_conv3d_bwd_weight_workspace_bytes", 8, 32, 32, 32, 64, 64, 3, 3, 3, 1, 1, 1, 0, 0, 0) > 0
+    # mixed-precision conv: 16-bit packed size and the shapes it takes (Cin % 4, >= 8 channels for multi-tap filters, < 1 GiB, LDS)
+    assert _lib.query("diqt_conv_packed_h_elems", 64, 64, 3, 3, 3) == 2 * 27 * 64 * 32
+    geo = (8, 32, 32, 32, 64, 64, 3, 3, 3, 1, 1, 1, 0, 0, 0)
+    assert _lib.query("diqt_conv3d_fwd_h_supported", *geo) == 1
+    assert _lib.query("diqt_conv3d_fwd_h_supported", 8, 32, 32, 32, 65, 1, 1, 3, 3, 0, 1, 1, 0, 0, 0) == 0     # Cin % 4
+    assert _lib.query("diqt_conv3d_fwd_h_supported", 8, 32, 32, 32, 2, 64, 3, 3, 3, 1, 1, 1, 0, 0, 0) == 0      # tap-packed fp32 kernel
+    assert _lib.query("diqt_conv3d_fwd_h_supported", 64, 64, 64, 64, 64, 64, 3, 3, 3, 1, 1, 1, 0, 0, 0) == 0    # 4 GiB tensors
+    assert _lib.query("diqt_conv3d_fwd_h_supported", 1, 16, 16, 16, 32, 32, 15, 15, 15, 7, 7, 7, 0, 0, 0) == 0  # halo beyond the LDS
 
 
 def test_bad_arguments_return_error_codes_not_crashes():
@@ -48,6 +56,10 @@ def test_bad_arguments_return_error_codes_not_crashes():
     assert lib.diqt_groupnorm_stats(None, None, None, None, 0, 1, 1, 6, 4, 1e-5, None) == -2
     with pytest.raises(RuntimeError):
         _lib.call("diqt_act_fwd", None, None, 16, 1, None)
+    assert lib.diqt_conv3d_fwd_h(None, None, None, None, None, *([1] * 15), 0, 1, None) == -2
+    assert lib.diqt_conv_pack_weight_h(None, None, 8, 8, 3, 3, 3, 0, None) == -2
+    assert lib.diqt_mqa_attention_fwd_h(None, None, None, None, None, 1, 1, 1, 64, 1, 1, 0, 1.0, 0, 1, None) == -2
+    assert lib.diqt_cast_to_h(None, None, 16, 0, None) == -2
 
 
 def test_product_has_no_cpu_fallback():

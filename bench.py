@@ -52,7 +52,7 @@ def pmc_traffic(batch, size):
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]
-        return next(v["hbm_bytes_per_launch"] for name, v in k.items() if "conv_fwd_kernel<true, true>" in name)
+        return next(v["hbm_bytes_per_launch"] for name, v in k.items() if "conv_fwd_kernel<true, true" in name)
     except Exception:
         return None
 
@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-family-b", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline loops only (no EDM / autocast / Family-B lines): the command profiled under profiles/")
     args = ap.parse_args()
 
     from diffusioniqt_amd import distributed as D, ops, _lib
@@ -169,7 +170,7 @@ def main():
     # ---------------- the same sampler step under torch.autocast(fp16): conv / linear forwards on the fp16 MFMA kernel (fp32
     #                  accumulate), everything else fp32 -- the reference's mixed-precision switch.  Reported
     #                  beside the fp32 headline, never as `value` ----
-    if args.mode in ("sample", "both"):
+    if args.mode in ("sample", "both") and not args.no_extras:
         state["i"] = 0
 
         def sample_step_fp16():
@@ -183,7 +184,7 @@ def main():
 
     # ---------------- EDM (Karras) stochastic Heun sampler on the same U-Net: one call of ElucidatedImagen.sample with
     #                  n = max(4, K // 2) steps = 2n - 1 U-Net evals (elucidated_imagen.py:382-532); reported beside the headline ----
-    if args.mode in ("sample", "both"):
+    if args.mode in ("sample", "both") and not args.no_extras:
         from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
         n_edm = max(4, K // 2)
         elu = ElucidatedImagen(unets=(NullUnet(), unet), image_sizes=(S, S), channels=1, condition_on_text=False,
@@ -201,7 +202,7 @@ def main():
 
     # ---------------- Family B: pseudo-3D Unet3D, dim 64, mults (1,2,4), mid + last-level attention, 32^3,
     #                  same batch: one eval (sampling path: fused MQA attention) and one fwd+bwd; reported beside the headline ----
-    if args.mode == "both" and not args.no_family_b:
+    if args.mode == "both" and not args.no_family_b and not args.no_extras:
         from diffusioniqt_amd.imagen_video import Unet3D
         torch.manual_seed(43)
         u3 = Unet3D(dim=64, dim_mults=(1, 2, 4), channels=1, cond_on_text=False, text_embed_dim=None, lowres_cond=True,

@@ -620,287 +620,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_smallcin_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// persistent forward / backward-data kernel (the default): <= 2 workgroups per CU walk the tile list of
-// "their" XCD; the halo chunk of the NEXT (tile, chunk) item is fetched global -> registers while the
-// current item's 27 x 32 MFMAs run and is written to LDS at the item boundary (async-stage split), so HBM
-// latency, workgroup launch and index math are off the MFMA critical path.  Same math, same LDS images.
-// ---------------------------------------------------------------------------------------------
-template <bool VEC4, bool BUF, int NR, int KD, int KH, int KW>
-__global__ __launch_bounds__(256, 2) void conv_fwd_persist_kernel(const float* __restrict__ x,
-                                                                  const float* __restrict__ wp,
-                                                                  const float* __restrict__ bias,
-                                                                  const float* __restrict__ residual,
-                                                                  float* __restrict__ y, ConvGeom g, int nTiles, int ablate) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int HV = g.HD * g.HH * g.HWd;
-    float* halo = smem;                                  // [HV][36]
-    float* wbuf = smem + (size_t)HV * LDSROW;            // [2][64][36]
-    int* out_off = reinterpret_cast<int*>(wbuf + 2 * NT * LDSROW);   // [2][128]
-    int* halo_src = out_off + 2 * MTILE;                              // [2][HV]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    constexpr int T = KD * KH * KW;      // the tap loop is fully unrolled: register-array indices must be static
-
-    // tile ownership: XCD x (= blockIdx % 8 under round-robin placement; speed only) owns a contiguous range
-    const int G8 = gridDim.x / kNumXcd;                  // workgroups per XCD (grid is a multiple of 8)
-    const int xcd = blockIdx.x % kNumXcd, j = blockIdx.x / kNumXcd;
-    const int tpx = (nTiles + kNumXcd - 1) / kNumXcd;
-    const int tileEnd = min((xcd + 1) * tpx, nTiles);
-    int tile = xcd * tpx + j;
-    if (tile >= tileEnd) return;
-
-    struct TilePos { int b, d0, h0, w0, n0; };
-    auto decode = [&](int t) {
-        TilePos p;
-        p.n0 = (t % g.nNt) * NT;
-        int mt = t / g.nNt;
-        p.w0 = (mt % g.tilesW) * g.TW; mt /= g.tilesW;
-        p.h0 = (mt % g.tilesH) * g.TH; mt /= g.tilesH;
-        p.d0 = (mt % g.tilesD) * g.TD;
-        p.b = mt / g.tilesD;
-        return p;
-    };
-    auto fill_tables = [&](const TilePos& p, int slot) {
-        for (int hv = tid; hv < HV; hv += 256) {
-            const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
-            const int iz = p.d0 + hz - g.pd, iy = p.h0 + hy - g.ph, ix = p.w0 + hx - g.pw;
-            int src = BUF ? (int)BUF_OOB : -1;
-            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
-                src = ((p.b * g.D + iz) * g.H + iy) * g.W + ix;
-                if (BUF) src *= g.Cin * 4;
-            }
-            halo_src[slot * HV + hv] = src;
-        }
-        if (tid < MTILE) {
-            const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
-            const int od = p.d0 + td, oh = p.h0 + th, ow = p.w0 + tw;
-            int off = BUF ? (int)BUF_OOB : -1;
-            if (od < g.Do && oh < g.Ho && ow < g.Wo) {
-                off = ((p.b * g.Do + od) * g.Ho + oh) * g.Wo + ow;
-                if (BUF) off *= g.Cout * 4;
-            }
-            out_off[slot * MTILE + tid] = off;
-        }
-    };
-    float4 R[NR];
-    unsigned okmask = 0;
-    // one 16-byte piece of the next item's halo chunk (piece r of thread tid covers halo element tid + 256 r)
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, BUF ? (int)g.xBytes : 0, 0x00020000);
-    unsigned voffs[NR];       // BUF: byte offsets of the next item's halo pieces (table read hoisted out of the tap loop)
-    auto read_offsets = [&](int slot) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int idx = tid + 256 * r;
-            const unsigned t = (unsigned)halo_src[slot * HV + min(idx >> 3, HV - 1)];
-            voffs[r] = idx < HV * 8 ? t : BUF_OOB;
-        }
-    };
-    auto load_piece = [&](int r, int slot, int ci0) -> float4 {
-        if (BUF) {
-            const int c4 = (tid & 7) * 4;
-            const unsigned coff = (ci0 + c4 < g.Cin) ? (unsigned)(ci0 + c4) * 4u : BUF_OOB_C;
-            return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voffs[r] + coff, 0, 0));
-        }
-        const int idx = tid + 256 * r;
-        const int hv = (idx < HV * 8) ? (idx >> 3) : 0, c4 = (idx & 7) * 4;
-        const int src = halo_src[slot * HV + hv];
-        const bool ok = idx < HV * 8 && src >= 0 && ci0 + c4 < g.Cin && !(ablate & 2);
-        const size_t off = ok ? (size_t)src * g.Cin + ci0 + c4 : 0;     // unconditional load from a clamped address
-        float4 v;
-        if (VEC4) {
-            v = *reinterpret_cast<const float4*>(x + off);
-        } else {
-            const int rem = ok ? g.Cin - (ci0 + c4) : 0;
-            v.x = x[off];
-            v.y = rem > 1 ? x[off + 1] : 0.f;
-            v.z = rem > 2 ? x[off + 2] : 0.f;
-            v.w = rem > 3 ? x[off + 3] : 0.f;
-        }
-        if (ok) okmask |= (1u << r); else okmask &= ~(1u << r);     // the zero-select happens at LDS-store time: using v here
-        return v;                                                     // would make the wave wait for the load immediately
-    };
-    auto issue_loads = [&](int slot, int ci0) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) R[r] = load_piece(r, slot, ci0);
-    };
-    auto store_halo = [&]() {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int idx = tid + 256 * r;
-            if (idx < HV * 8)
-                *reinterpret_cast<float4*>(halo + (idx >> 3) * LDSROW + (idx & 7) * 4) =
-                    (BUF || ((okmask >> r) & 1u)) ? R[r] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-
-    int hidx_lane;
-    {
-        const int v = wave * 32 + l31;
-        const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
-        hidx_lane = (td * g.HH + th) * g.HWd + tw;
-    }
-    const int wrow = tid >> 3, wc4 = (tid & 7) * 4;
-
-    long long tsum[4] = {0, 0, 0, 0};      // diagnostic: [wait at item start, staging, tap loop, epilogue]
-    long long tprev = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
-#define DIQT_ACC(i) do { if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tsum[i] += tn - tprev; tprev = tn; } } while (0)
-    int slot = 0;
-    TilePos pos = decode(tile);
-    fill_tables(pos, 0);
-    __syncthreads();
-    if (BUF) read_offsets(0);
-    issue_loads(0, 0);
-    // stagger: the second resident set of workgroups starts half a tap late, so the two waves sharing a SIMD do not
-    // reach their barriers / LDS-read waits in lockstep (speed only)
-    {   // experiment: de-phase workgroups by a placement-independent pseudo-random start delay of up to (ablate>>8) K-cycles
-        unsigned hsh = blockIdx.x * 2654435761u; hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
-        const int nsl = (ablate >> 8) ? (int)(hsh % (unsigned)(ablate >> 8)) : 0;
-        for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-
-    // static tile walk: a per-XCD atomic tile queue and alternating wave priorities were tried against the ~8 % MFMA-rate
-    // advantage of the older co-resident workgroup (profiles/r01_conv_ablation.md): 4 tiles per workgroup are too coarse to steal
-    while (true) {
-        const int nextTile = tile + G8;
-        const bool haveNextTile = nextTile < tileEnd;
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-
-        for (int chunk = 0; chunk < g.nChunks; ++chunk) {
-            const bool lastChunk = chunk == g.nChunks - 1;
-            __syncthreads();          // every wave is done reading the previous item's halo and weight buffers
-            DIQT_ACC(0);
-            store_halo();             // waits for the prefetched registers (issued one item ago)
-            const float* wchunk = wp + ((size_t)chunk * T * g.CoutPad + pos.n0) * CK;
-            {
-                const float4 r0 = *reinterpret_cast<const float4*>(wchunk + (size_t)wrow * CK + wc4);
-                const float4 r1 = *reinterpret_cast<const float4*>(wchunk + (size_t)(wrow + 32) * CK + wc4);
-                *reinterpret_cast<float4*>(wbuf + wrow * LDSROW + wc4) = r0;
-                *reinterpret_cast<float4*>(wbuf + (wrow + 32) * LDSROW + wc4) = r1;
-            }
-            TilePos npos = pos;
-            if (lastChunk && haveNextTile) {
-                npos = decode(nextTile);
-                fill_tables(npos, slot ^ 1);
-            }
-            __syncthreads();
-            if (BUF && lastChunk && haveNextTile) read_offsets(slot ^ 1);
-            DIQT_ACC(1);
-            // the next item's halo chunk is prefetched into registers ONE PIECE PER TAP, each piece issued right after
-            // that tap's weight-panel loads: vmcnt retires in order, so the end-of-tap wait for the weight panel then
-            // leaves the (younger) halo piece in flight instead of stalling on a whole-chunk burst
-            const bool havePrefetch = !lastChunk || haveNextTile;
-            const int pslot = lastChunk ? (slot ^ 1) : slot;
-            const int pci0 = lastChunk ? 0 : (chunk + 1) * CK;
-            constexpr int ppt = (NR + T - 1) / T;              // pieces per tap
-
-#pragma unroll
-            for (int tap = 0; tap < T; ++tap) {
-                    {
-                        const int kx = tap % KW, ky = (tap / KW) % KH, kz = tap / (KW * KH);
-                        float4 r0, r1;
-                        const bool more = (tap + 1 < T);
-                        if (more && !(ablate & 8)) {
-                            const float* wt = wchunk + (size_t)(tap + 1) * g.CoutPad * CK;
-                            r0 = *reinterpret_cast<const float4*>(wt + (size_t)wrow * CK + wc4);
-                            r1 = *reinterpret_cast<const float4*>(wt + (size_t)(wrow + 32) * CK + wc4);
-                        }
-                        if (havePrefetch) {
-#pragma unroll
-                            for (int r = 0; r < NR; ++r)
-                                if (r >= tap * ppt && r < (tap + 1) * ppt) R[r] = load_piece(r, pslot, pci0);
-                        }
-                        const float* wcur = wbuf + (tap & 1) * (NT * LDSROW);
-                        const float* ap = (ablate & 32) ? halo + (l31 + tap) * LDSROW + 4 * h
-                                                        : halo + (hidx_lane + (kz * g.HH + ky) * g.HWd + kx) * LDSROW + 4 * h;
-                        const float* bp = wcur + l31 * LDSROW + 4 * h;
-                        float4 a = *reinterpret_cast<const float4*>(ap);
-                        float4 b0 = *reinterpret_cast<const float4*>(bp);
-                        float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float4 an, b0n, b1n;
-                            if (q < 3 && !(ablate & 16)) {
-                                an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
-                                b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
-                                b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
-                            if (q < 3 && !(ablate & 16)) { a = an; b0 = b0n; b1 = b1n; }
-                        }
-                        if (more && !(ablate & 1)) {
-                            float* wnext = wbuf + ((tap + 1) & 1) * (NT * LDSROW);
-                            *reinterpret_cast<float4*>(wnext + wrow * LDSROW + wc4) = r0;
-                            *reinterpret_cast<float4*>(wnext + (wrow + 32) * LDSROW + wc4) = r1;
-                            __syncthreads();
-                        }
-                    }
-            }
-            DIQT_ACC(2);
-            if (lastChunk && (ablate & 4)) { pos = npos; }
-            if (lastChunk && !(ablate & 4)) {
-                // epilogue of this tile (out_off[slot] stays valid: the next tile's table went to slot^1)
-                const int co0 = pos.n0 + l31, co1 = pos.n0 + 32 + l31;
-                const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
-                const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
-                if (BUF) {
-                    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
-                    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
-                    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned off = (unsigned)out_off[slot * MTILE + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-                        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-                        if (residual) {
-                            v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
-                            v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
-                        }
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
-                    }
-                } else
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int off = out_off[slot * MTILE + wave * 32 + row];
-                    if (off < 0) continue;
-                    const size_t o = (size_t)off * g.Cout;
-                    if (co0 < g.Cout) {
-                        float v = acc0[r] + bias0;
-                        if (residual) v += residual[o + co0];
-                        y[o + co0] = v;
-                    }
-                    if (co1 < g.Cout) {
-                        float v = acc1[r] + bias1;
-                        if (residual) v += residual[o + co1];
-                        y[o + co1] = v;
-                    }
-                }
-                pos = npos;
-                DIQT_ACC(3);
-            }
-        }
-        if (!haveNextTile) break;
-        tile = nextTile;
-        slot ^= 1;
-    }
-    if (g.dbg && tid == 0)
-        for (int q = 0; q < 4; ++q) g.dbg[(size_t)blockIdx.x * 8 + q] = (unsigned long long)tsum[q];
-#undef DIQT_ACC
-}
-
-// ---------------------------------------------------------------------------------------------
 // backward-weight (split-K partial slabs)
 // ---------------------------------------------------------------------------------------------
 constexpr int BW_MAXT = 5;       // taps per wave pair
@@ -1549,10 +1268,9 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
 extern "C" int diqt_conv3d_fwd_stats_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
                                             int pw, int epd, int eph, int epw) {
     static const bool off = [] { const char* e = getenv("DIQT_CONV_NOSTATS"); return e && e[0] == '1'; }();
-    static const bool persist_ok = [] { const char* e = getenv("DIQT_CONV_PERSIST"); return e && e[0] == '1'; }();
     static const bool nobuf = [] { const char* e = getenv("DIQT_CONV_NOBUF"); return e && e[0] == '1'; }();
     ConvGeom g;
-    if (off || persist_ok || nobuf || make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return 0;
+    if (off || nobuf || make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return 0;
     if (kd * kh * kw == 1) return 0;                                   // flattened 1x1x1 tiles cross batch entries
     if (Cin % 4 != 0 || smallcin_pad(Cin, kd * kh * kw) || fwd_ksplit(g) > 1) return 0;
     const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
@@ -1654,42 +1372,6 @@ static int conv3d_fwd_one(const float* x, const float* packed, const float* bias
             return check_launch("conv3d_fwd(small Cin)");
         }
         DIQT_REQUIRE(false, DIQT_E_UNSUPPORTED, "conv3d_fwd: small-Cin halo needs %zu B of LDS", slds);
-    }
-    // opt-in: measured equal to the one-tile-per-workgroup kernel on MI355X (118 vs 121 TFLOP/s, profiles/r01_conv_ablation.md)
-    static const bool persist_ok = [] { const char* e = getenv("DIQT_CONV_PERSIST"); return e && e[0] == '1'; }();
-    const bool k333 = kd == 3 && kh == 3 && kw == 3, k133 = kd == 1 && kh == 3 && kw == 3;
-    if (persist_ok && HV * 8 <= 256 * 13 && (k333 || k133)) {
-        const size_t plds = ((size_t)HV * (LDSROW + 2) + 2 * NT * LDSROW) * sizeof(float) + 2 * MTILE * sizeof(int);
-        if (plds <= 160 * 1024) {
-            const unsigned long long pxb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
-            const unsigned long long pyb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
-            const bool pbuf = vec4 && pxb < (1ull << 30) && pyb < (1ull << 30);
-            if (pbuf) { g.xBytes = (unsigned)pxb; g.yBytes = (unsigned)pyb; }
-            void (*pk)(const float*, const float*, const float*, const float*, float*, ConvGeom, int, int) =
-                k333 ? (vec4 ? (pbuf ? conv_fwd_persist_kernel<true, true, 13, 3, 3, 3> : conv_fwd_persist_kernel<true, false, 13, 3, 3, 3>)
-                             : conv_fwd_persist_kernel<false, false, 13, 3, 3, 3>)
-                     : (vec4 ? (pbuf ? conv_fwd_persist_kernel<true, true, 13, 1, 3, 3> : conv_fwd_persist_kernel<true, false, 13, 1, 3, 3>)
-                             : conv_fwd_persist_kernel<false, false, 13, 1, 3, 3>);
-            if (plds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-                DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            }
-            // resident workgroups: 2 per CU when the LDS image allows it, else 1; always a multiple of 8 (XCDs)
-            const unsigned perCu = plds <= 80 * 1024 ? 2u : 1u;
-            unsigned grid = 256u * perCu;
-            const unsigned need = (nwg + kNumXcd - 1) / kNumXcd * kNumXcd;
-            if (grid > need) grid = need;
-            static const int ablate = [] { const char* e = getenv("DIQT_CONV_ABLATE"); return e ? atoi(e) : 0; }();   // timing-only diagnostics
-            static unsigned long long* pdbg = nullptr;
-            static const bool pdbg_on = [] { const char* e = getenv("DIQT_CONV_DBG"); return e && e[0] == '1'; }();
-            if (pdbg_on) {
-                if (!pdbg) (void)hipMalloc(&pdbg, (size_t)65536 * 8 * sizeof(unsigned long long));
-                g.dbg = pdbg; g_dbg_ptr = pdbg; g_dbg_n = grid;
-            }
-            hipLaunchKernelGGL(pk, dim3(grid), dim3(256), plds, (hipStream_t)stream, x, packed, bias, residual, y, g, (int)nwg, ablate);
-            return check_launch("conv3d_fwd(persistent)");
-        }
     }
     static const size_t ldspad = [] { const char* e = getenv("DIQT_CONV_LDSPAD"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();   // occupancy experiment
     size_t lds = ((size_t)HV * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int) + ldspad;

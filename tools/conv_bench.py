@@ -87,20 +87,6 @@ if os.environ.get("DIQT_CONV_DBG") == "1":
     buf = np.zeros((65536, 8), dtype=np.uint64)
     n = lib.diqt_debug_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p), 65536)
     st = buf[:n].astype(np.int64)
-    if os.environ.get("DIQT_CONV_PERSIST") == "1":
-        tot = st[:, :4].sum(axis=1)
-        for i, nm in enumerate(["wait at item start", "store halo+W0+tables", "tap loops", "epilogues"]):
-            print(f"  {nm:22s} median {np.median(st[:, i]):10.0f} cycles = {100 * np.median(st[:, i] / tot):5.1f} % of workgroup life")
-        print(f"  workgroup life median {np.median(tot):.0f} cycles, {n} persistent workgroups; min {tot.min()} p10 {np.percentile(tot, 10):.0f} "
-              f"p90 {np.percentile(tot, 90):.0f} max {tot.max()}")
-        order = np.argsort(tot)
-        for nm, sel in (("fastest 10%", order[: n // 10]), ("middle", order[n // 2 - n // 20: n // 2 + n // 20]), ("slowest 10%", order[-(n // 10):])):
-            print(f"    {nm:12s}: life {np.median(tot[sel]):.0f}  wait {np.median(st[sel, 0]):.0f} store {np.median(st[sel, 1]):.0f} "
-                  f"taps {np.median(st[sel, 2]):.0f} epi {np.median(st[sel, 3]):.0f}   blockIdx/8 %4 histogram {np.bincount((sel // 8) % 4, minlength=4)}  blockIdx>=256: {np.mean(sel >= 256):.2f}")
-        for xcd in range(0):
-            m = np.arange(n) % 8 == xcd
-            print(f"    XCD {xcd}: life median {np.median(tot[m]):.0f}  max {tot[m].max()}   wait {np.median(st[m, 0]):.0f} store {np.median(st[m, 1]):.0f} taps {np.median(st[m, 2]):.0f} epi {np.median(st[m, 3]):.0f}")
-        sys.exit(0)
     if os.environ.get("DIQT_CONV_STAGGER") == "-1":
         cyc = (st[:, 7] - st[:, 0]).astype(np.float64)
         rt = (st[:, 6] - st[:, 1]).astype(np.float64)          # 100 MHz ticks

@@ -160,3 +160,61 @@ def test_convs_beyond_one_gib_split_into_fast_sub_launches():
         y = ops.conv3d(x, w, b, (1, 1, 1))
         for lo in (0, 30, 31, 39):                                    # sub-launches hold 31 batch entries
             assert torch.equal(y[lo:lo + 1], ops.conv3d(x[lo:lo + 1].contiguous(), w, b, (1, 1, 1)))
+
+
+def test_c4_full_size_linear_attention_unet():
+    """BASELINE.json configs[3] at its full size: SRUnet256 img 64, dim 128, LinearAttention at every level + middle,
+    deep_feature, batch_sample factor 1, one 64^3 volume (6133 GFLOP per eval).  Properties: finite, run-to-run bit-exact, and the
+    mixed-precision (autocast) evaluation stays within low-precision round-off of the fp32 one."""
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256
+    S = 64
+    kw = dict(img_size=S, dim=128, init_dim=128, dim_mults=(1, 2, 4), channels=1, num_resnet_blocks=(2, 2, 2), init_conv_kernel_size=3,
+              lowres_cond=True, init_cross_embed=False, att_type='linear', attn_dim_head=64, attend_at_middle=True,
+              attend_at_enc=[True, True, True], attend_at_enc_depth=[1, 1, 1], attend_at_enc_heads=[8, 8, 8], memory_efficient=False,
+              use_se_attn='True,', pixel_shuffle_upsample=True, boundary=False, batch_sample=True, batch_sample_factor=1, deep_feature=True)
+    torch.manual_seed(4)
+    unet = SRUnet256(**kw).to(DEV).eval()
+    assert sum(p.numel() for p in unet.parameters()) == 58919433          # SURVEY.md §8 C4 probe
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(1, 1, S, S, S, generator=g).to(DEV)
+    lr = torch.randn(1, 1, S, S, S, generator=g).to(DEV)
+    t = torch.rand(1, generator=g).to(DEV)
+    with torch.no_grad():
+        y1 = unet(x, None, t, lowres_cond_img=lr)
+        y2 = unet(x, None, t, lowres_cond_img=lr)
+        with torch.autocast('cuda', dtype=torch.float16):
+            yh = unet(x, None, t, lowres_cond_img=lr)
+    assert tuple(y1.shape) == (1, 1, S, S, S) and torch.isfinite(y1).all()
+    assert torch.equal(y1, y2), "C4 eval is not run-to-run deterministic"
+    rel = ((yh - y1).norm() / y1.norm()).item()
+    assert 0 < rel < 2e-2, rel
+
+
+def test_c5_full_size_cascade_sampling():
+    """BASELINE.json configs[4] at its full sizes: ElucidatedImagen((Unet3D @ 32, Unet3D @ 64 lowres_cond), image_sizes
+    (32, 64), temporal_downsample_factor (2, 1)), sample(video_frames=64) under torch.autocast(float16) -- 2 EDM steps per stage instead
+    of 64 to keep the test short (3 U-Net evals per stage; 169 + 1902 GFLOP per eval).  Shapes, finiteness, the clamp range, and
+    run-to-run bit-exactness for identical injected noise."""
+    from diffusioniqt_amd.imagen_video import Unet3D
+    from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
+    kw = dict(dim=64, dim_mults=(1, 2, 4), channels=1, cond_on_text=False, text_embed_dim=None, layer_attns=False, layer_cross_attns=False,
+              attend_at_middle=True, num_resnet_blocks=2, attn_pool_text=False)
+    torch.manual_seed(5)
+    u1, u2 = Unet3D(lowres_cond=False, **kw), Unet3D(lowres_cond=True, **kw)
+    for u in (u1, u2):                                   # final convs are zero-initialised in the reference: make the output depend on the net
+        for p in u.final_conv.parameters():
+            torch.nn.init.normal_(p, std=0.05)
+    elu = ElucidatedImagen(unets=(u1, u2), image_sizes=(32, 64), channels=1, condition_on_text=False, auto_normalize_img=False,
+                           cond_drop_prob=0.0, num_sample_steps=2, temporal_downsample_factor=(2, 1)).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    noise = [torch.randn(1, 1, 32, 32, 32, generator=g) for _ in range(3)] + [torch.randn(1, 1, 64, 64, 64, generator=g) for _ in range(4)]
+    outs = []
+    for _ in range(2):
+        with torch.autocast('cuda', dtype=torch.float16):
+            o = elu.sample(batch_size=1, video_frames=64, return_all_unet_outputs=True, use_tqdm=False, noise=[n.clone() for n in noise])
+        outs.append(o)
+    s1, s2 = outs[0]
+    assert tuple(s1.shape) == (1, 1, 32, 32, 32) and tuple(s2.shape) == (1, 1, 64, 64, 64)
+    assert torch.isfinite(s1).all() and torch.isfinite(s2).all()
+    assert s2.abs().max().item() <= 1.0 + 1e-6 and s2.abs().max().item() > 0      # dynamic thresholding / clamp of the last step
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "cascade sampling is not deterministic"

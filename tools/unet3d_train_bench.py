@@ -45,3 +45,15 @@ if os.environ.get("BGEMM_SHAPES") == "1":
         g, M, N, K = k[:4]
         print(f"{g:5d} {M:6d} {N:6d} {K:6d}  {k[4]}  {k[5]}  {len(evs):5d} {1e3 * ms / len(evs):9.1f} {2.0 * g * M * N * K * len(evs) / ms / 1e9:9.1f}")
     print("bgemm (python-called) total ms:", tot)
+
+if os.environ.get("CONV_SHAPES") == "1":
+    ops.TIMER.enabled = True
+    ops.TIMER.reset()
+    for _ in range(2):
+        step()
+    rows = sorted(ops.TIMER.by_shape().items(), key=lambda kv: -kv[1][0])
+    tot = sum(v[0] for _, v in rows)
+    print(f"timed conv launches {tot / 2:.3f} ms per fwd+bwd")
+    for (tag, sh), (ms, fl, nn) in rows[:28]:
+        Bq, Dd, H, W, Ci, Co, kd, kh, kw = sh
+        print(f"{tag:24s} {f'{Bq}x{Dd}x{H}x{W}':>16s} {f'{Ci}->{Co}':>10s} {f'{kd}{kh}{kw}':>5s} {nn // 2:4d} {1e3 * ms / nn:9.1f} us {fl / ms / 1e9:7.1f} TF {100 * ms / tot:5.1f}%")

@@ -240,6 +240,13 @@ def main():
         dt = timed(train_step, W, kt)
         result["train"] = dict(ms_per_step=1e3 * dt / kt, steps_per_s=kt / dt, patches_per_s=world * B * kt / dt,
                                steps=kt)
+        if not args.no_extras:
+            # the same micro-steps with ImagenTrainer's mixed-precision switch (precision='bf16', trainer.py:293-311): forward and
+            # backward-data on the bf16 MFMA kernel, weight gradients / optimiser / master weights fp32.  Beside the fp32 line.
+            trainer.mixed_precision = 'bf16'
+            dtb = timed(train_step, 2, kt)
+            trainer.mixed_precision = 'no'
+            result["train_bf16"] = dict(ms_per_step=1e3 * dtb / kt, patches_per_s=world * B * kt / dtb, steps=kt)
 
     # ---------------- CPU baseline: the oracle on the host cores, bounded sample ----------------
     cpu = None
@@ -296,6 +303,10 @@ def main():
         if "train" in result:
             out["train"] = {k: round(v, 3) for k, v in result["train"].items()}
             out["train"]["note"] = "ImagenTrainer.forward micro-step: fwd+bwd (558 GFLOP/patch), grad all-reduce + fused Adam every 4th, EMA"
+        if "train_bf16" in result:
+            out["train_bf16"] = {k: round(v, 3) for k, v in result["train_bf16"].items()}
+            out["train_bf16"]["note"] = ("same micro-steps with ImagenTrainer(precision='bf16'): forward + backward-data on the bf16 MFMA kernel, "
+                                         "weight gradients / Adam / master weights fp32; reduced precision, NOT the headline")
         if "sample" in result:
             out["sample_steps_per_s"] = round(1e3 / result["sample"]["ms_per_step"], 3)
         if "unet3d" in result:

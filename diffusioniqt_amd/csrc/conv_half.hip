@@ -78,10 +78,11 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// packed[((chunk*T + tap)*CoutPad + co)*32 + k] = (half) w[co][chunk*32 + k][tap]
+// packed[((chunk*T + tap)*CoutPad + o)*32 + k]:  mode 0: (half) w[o][chunk*32 + k][tap]  (effective out, in = Cout, Cin);
+// mode 1 (backward-data: dX = conv(dY, flipped W)): (half) w[chunk*32 + k][o][T-1-tap]  (effective out, in = Cin, Cout)
 template <bool BF>
 __global__ void conv_pack_weight_h_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int Cout, int Cin, int T,
-                                          int CoutPad, size_t total) {
+                                          int mode, int CoutPad, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % HCK);
         size_t r = i / HCK;
@@ -89,7 +90,12 @@ __global__ void conv_pack_weight_h_kernel(const float* __restrict__ w, unsigned 
         r /= CoutPad;
         const int tap = (int)(r % T);
         const int in = (int)(r / T) * HCK + k;
-        const float v = (o < Cout && in < Cin) ? w[((size_t)o * Cin + in) * T + tap] : 0.f;
+        float v = 0.f;
+        if (mode == 0) {
+            if (o < Cout && in < Cin) v = w[((size_t)o * Cin + in) * T + tap];
+        } else {
+            if (o < Cin && in < Cout) v = w[((size_t)in * Cin + o) * T + (T - 1 - tap)];
+        }
         packed[i] = (unsigned short)(pack2<BF>(v, 0.f) & 0xffffu);
     }
 }
@@ -392,14 +398,16 @@ extern "C" size_t diqt_conv_packed_h_elems(int Cout, int Cin, int kd, int kh, in
     return (size_t)hcdiv(Cin, HCK) * kd * kh * kw * (hcdiv(Cout, HNT) * HNT) * HCK;
 }
 
-extern "C" int diqt_conv_pack_weight_h(const float* w, void* packed, int Cout, int Cin, int kd, int kh, int kw, int bf16, void* stream) {
+extern "C" int diqt_conv_pack_weight_h(const float* w, void* packed, int Cout, int Cin, int kd, int kh, int kw, int mode, int bf16,
+                                       void* stream) {
     DIQT_REQUIRE(w && packed, DIQT_E_ALIGN, "conv_pack_weight_h: null pointer");
-    DIQT_REQUIRE(Cout > 0 && Cin > 0 && kd > 0 && kh > 0 && kw > 0, DIQT_E_SHAPE, "conv_pack_weight_h: bad shape");
-    const int T = kd * kh * kw, CoutPad = hcdiv(Cout, HNT) * HNT;
-    const size_t total = (size_t)hcdiv(Cin, HCK) * T * CoutPad * HCK;
+    DIQT_REQUIRE(Cout > 0 && Cin > 0 && kd > 0 && kh > 0 && kw > 0 && (mode == 0 || mode == 1), DIQT_E_SHAPE, "conv_pack_weight_h: bad shape/mode");
+    const int T = kd * kh * kw, outEff = mode == 0 ? Cout : Cin, inEff = mode == 0 ? Cin : Cout;
+    const int CoutPad = hcdiv(outEff, HNT) * HNT;
+    const size_t total = (size_t)hcdiv(inEff, HCK) * T * CoutPad * HCK;
     auto k = bf16 ? conv_pack_weight_h_kernel<true> : conv_pack_weight_h_kernel<false>;
     hipLaunchKernelGGL(k, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, static_cast<unsigned short*>(packed), Cout,
-                       Cin, T, CoutPad, total);
+                       Cin, T, mode, CoutPad, total);
     return check_launch("conv_pack_weight_h");
 }
 

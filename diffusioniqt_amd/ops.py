@@ -149,8 +149,8 @@ def _packed(weight5, mode):
     return packed
 
 
-def _packed_h(weight5, bf16):
-    """16-bit packed copy of an OIDHW weight for the fp16 / bf16 MFMA kernel, cached like ``_packed``."""
+def _packed_h(weight5, bf16, mode=0):
+    """16-bit packed copy of an OIDHW weight for the fp16 / bf16 MFMA kernel, cached like ``_packed`` (mode 1: backward-data)."""
     owner = weight5._base if weight5._base is not None else weight5
     cache = getattr(owner, "_diqt_pack", None)
     if cache is None:
@@ -159,23 +159,26 @@ def _packed_h(weight5, bf16):
             owner._diqt_pack = cache
         except Exception:
             pass
-    slot = ('h', bf16)
+    slot = ('h', bf16, mode)
     key = (slot, weight5.data_ptr(), weight5._version, _WEIGHT_EPOCH)
     hit = cache.get(slot)
     if hit is not None and hit[0] == key:
         return hit[1]
     Cout, Cin, kd, kh, kw = weight5.shape
-    n = _lib.query("diqt_conv_packed_h_elems", Cout, Cin, kd, kh, kw)
+    eff = (Cout, Cin) if mode == 0 else (Cin, Cout)
+    n = _lib.query("diqt_conv_packed_h_elems", eff[0], eff[1], kd, kh, kw)
     packed = torch.empty(n, dtype=torch.int16, device=weight5.device)
-    _lib.call("diqt_conv_pack_weight_h", weight5.detach(), packed, Cout, Cin, kd, kh, kw, bf16, _stream())
+    _lib.call("diqt_conv_pack_weight_h", weight5.detach(), packed, Cout, Cin, kd, kh, kw, mode, bf16, _stream())
     cache[slot] = (key, packed)
     return packed
 
 
-def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16):
-    """fp16 / bf16-operand forward (diqt_conv3d_fwd_h) or None when the low-precision kernel does not take this shape."""
+def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0):
+    """fp16 / bf16-operand forward (mode 0) or backward-data (mode 1: x5 is dY, pad / epad already transformed) through
+    diqt_conv3d_fwd_h, or None when the low-precision kernel does not take this shape."""
     B, D, H, W, Cin = x5.shape
-    Cout, _, kd, kh, kw = weight.shape
+    kd, kh, kw = weight.shape[2:]
+    Cout = weight.shape[0] if mode == 0 else weight.shape[1]
     geo = (B, D, H, W, Cin, Cout, kd, kh, kw, *pad, *epad)
     if not _lib.query("diqt_conv3d_fwd_h_supported", *geo):
         return None
@@ -184,7 +187,7 @@ def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16):
     if TIMER.enabled:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-    _lib.call("diqt_conv3d_fwd_h", x5, _packed_h(weight, bf16), bias, residual, y, *geo, bf16, 1, _stream())
+    _lib.call("diqt_conv3d_fwd_h", x5, _packed_h(weight, bf16, mode), bias, residual, y, *geo, bf16, 1, _stream())
     if TIMER.enabled:
         e.record()
         TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_h_kernel",
@@ -248,6 +251,7 @@ class _Conv3dFn(Function):
         ctx.save_for_backward(x, weight)
         ctx.pad = pad
         ctx.epad = epad
+        ctx.lp = lp                 # backward runs outside the autocast region: remember the forward's compute type
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         return y
@@ -263,8 +267,12 @@ class _Conv3dFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # dX = conv(dY, flipped W): low pad' = k-1-pad_lo, high pad' = k-1-pad_hi  ->  epad' = -epad
-            dx = _conv_fwd_raw(dy, _packed(weight, 1), None, None, Cin, (kd, kh, kw),
-                               (kd - 1 - pd, kh - 1 - ph, kw - 1 - pw), (-epd, -eph, -epw))
+            bpad, bepad = (kd - 1 - pd, kh - 1 - ph, kw - 1 - pw), (-epd, -eph, -epw)
+            # bf16 training: backward-data on the bf16 MFMA kernel too (the reference's autocast backward runs in the forward's
+            # type).  fp16 gradients would need the GradScaler the reference pairs with fp16; they stay on the fp32 kernel.
+            dx = _conv_fwd_half(dy, weight, None, None, bpad, bepad, 1, mode=1) if ctx.lp == 1 else None
+            if dx is None:
+                dx = _conv_fwd_raw(dy, _packed(weight, 1), None, None, Cin, (kd, kh, kw), bpad, bepad)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None

@@ -77,10 +77,13 @@ int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, cons
  * `ImagenTrainer(fp16=True)` -> `Accelerator(mixed_precision='fp16')` (trainer.py:293-311): operands are cast to fp16 (bf16 = 1:
  * bf16) while the halo tile is staged, products accumulate in fp32, and with round_out = 1 the result (+ bias) is rounded once to
  * the operand type before the fp32 store, as an fp16 output tensor would be.  x, y, bias, residual stay fp32 NDHWC.
- * `packed_h`: 16-bit [ci/32][tap][co padded to 64][32] from diqt_conv_pack_weight_h (diqt_conv_packed_h_elems elements).
+ * `packed_h`: 16-bit [ci/32][tap][co padded to 64][32] from diqt_conv_pack_weight_h (diqt_conv_packed_h_elems elements of the
+ * EFFECTIVE out/in channel counts).  With the mode-1 packing the same entry point computes backward-data (dX from dY), which the
+ * bf16 training path uses; fp16 gradients would need loss scaling and stay on the fp32 kernel.
  * diqt_conv3d_fwd_h_supported() == 0 (Cin % 4 != 0, a tensor >= 1 GiB, halo tile beyond the LDS): stay on diqt_conv3d_fwd.   */
 size_t diqt_conv_packed_h_elems(int Cout, int Cin, int kd, int kh, int kw);
-int diqt_conv_pack_weight_h(const float* w_oidhw, void* packed_h, int Cout, int Cin, int kd, int kh, int kw, int bf16, void* stream);
+int diqt_conv_pack_weight_h(const float* w_oidhw, void* packed_h, int Cout, int Cin, int kd, int kh, int kw, int mode, int bf16,
+                            void* stream);   /* mode as in diqt_conv_pack_weight: 1 = flipped / swapped packing for backward-data */
 int diqt_conv3d_fwd_h_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                                 int epd, int eph, int epw);
 int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const float* bias, const float* residual, float* y, int B, int D, int H,

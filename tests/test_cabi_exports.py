@@ -57,7 +57,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     with pytest.raises(RuntimeError):
         _lib.call("diqt_act_fwd", None, None, 16, 1, None)
     assert lib.diqt_conv3d_fwd_h(None, None, None, None, None, *([1] * 15), 0, 1, None) == -2
-    assert lib.diqt_conv_pack_weight_h(None, None, 8, 8, 3, 3, 3, 0, None) == -2
+    assert lib.diqt_conv_pack_weight_h(None, None, 8, 8, 3, 3, 3, 0, 0, None) == -2
     assert lib.diqt_mqa_attention_fwd_h(None, None, None, None, None, 1, 1, 1, 64, 1, 1, 0, 1.0, 0, 1, None) == -2
     assert lib.diqt_cast_to_h(None, None, 16, 0, None) == -2
 

@@ -128,6 +128,32 @@ def test_backward_under_autocast_uses_fp32_gradients():
     assert torch.equal(x.grad, gx) and torch.equal(w.grad, gw)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 32, 64, (3, 3, 3), (1, 1, 1), (0, 0, 0)), (1, 9, 6, 7, 40, 24, (3, 1, 1), (2, 0, 0), (-2, 0, 0)),
+                                   (1, 4, 8, 8, 96, 128, (1, 1, 1), (0, 0, 0), (0, 0, 0)), (2, 5, 12, 12, 64, 32, (1, 3, 3), (0, 1, 1), (0, 0, 0))])
+def test_bf16_training_backward_data_on_the_bf16_kernel(shape):
+    """precision='bf16': the forward's compute type is remembered and backward-data (dX = conv(dY, flipped W), mode-1 packing) runs on
+    the bf16 kernel as well -- bit-exact on integer-valued data against float64 autograd rounded once to bf16 -- while the weight and
+    bias gradients stay on the exact fp32 kernels."""
+    from diffusioniqt_amd import ops
+    B, D, H, W, Cin, Cout, k, pad, epad = shape
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randint(-3, 4, (B, D, H, W, Cin), generator=g).float()
+    w = torch.randint(-2, 3, (Cout, Cin, *k), generator=g).float()
+    xr = x.double().permute(0, 4, 1, 2, 3).requires_grad_()
+    wr = w.double().requires_grad_()
+    xp = F.pad(xr, (pad[2], pad[2] + epad[2], pad[1], pad[1] + epad[1], pad[0], pad[0] + epad[0]))
+    yr = F.conv3d(xp, wr)
+    dy = torch.randint(-2, 3, tuple(yr.shape), generator=g).double()
+    yr.backward(dy)
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y = ops.conv3d(xd, wd, None, pad, extra_pad=epad)
+    y.backward(dy.float().permute(0, 2, 3, 4, 1).contiguous().to(DEV))            # outside the autocast region, like loss.backward()
+    dx_ref = xr.grad.float().to(torch.bfloat16).float().permute(0, 2, 3, 4, 1)
+    assert torch.equal(xd.grad.cpu(), dx_ref), (xd.grad.cpu() - dx_ref).abs().max()
+    assert torch.equal(wd.grad.cpu(), wr.grad.float())                             # exact: integer data, fp32 kernel
+
+
 def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 

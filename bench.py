@@ -240,6 +240,21 @@ def main():
         dt = timed(train_step, W, kt)
         result["train"] = dict(ms_per_step=1e3 * dt / kt, steps_per_s=kt / dt, patches_per_s=world * B * kt / dt,
                                steps=kt)
+        if not args.no_kernel_timer:
+            # roofline of the training step's own dominant kernel (weight gradients), HIP events around every launch of a few
+            # extra micro-steps outside the timed region (the events would perturb it)
+            ops.TIMER.reset()
+            ops.TIMER.enabled = True
+            for _ in range(4):
+                train_step()
+            sync_all()
+            ops.TIMER.enabled = False
+            summ_t = ops.TIMER.summary()
+            if "conv_bwd_weight_kernel" in summ_t:
+                ms, flops, n = summ_t["conv_bwd_weight_kernel"]
+                result["train"]["bwd_weight_tflops"] = flops / (ms * 1e-3) / 1e12
+                result["train"]["bwd_weight_frac_of_f32_mfma_peak"] = flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                result["train"]["bwd_weight_avg_launch_ms"] = ms / n
         if not args.no_extras:
             # the same micro-steps with ImagenTrainer's mixed-precision switch (precision='bf16', trainer.py:293-311): forward and
             # backward-data on the bf16 MFMA kernel, weight gradients / optimiser / master weights fp32.  Beside the fp32 line.

@@ -50,6 +50,8 @@ PROTOTYPES = {
     "diqt_learned_sinu_bwd": (I, [P, P, P, P, I, I, P]),
     "diqt_channel_mean": (I, [P, P, P, Z, I, I, I, P]),
     "diqt_gate_residual_fwd": (I, [P, P, P, P, F, P, I, I, I, P]),
+    "diqt_gate_residual_stats_blocks": (I, [I, I]),
+    "diqt_gate_residual_fwd_stats": (I, [P, P, P, P, P, I, I, I, P]),
     "diqt_gate_residual_bwd": (I, [P, P, P, P, Z, I, I, I, P]),
     "diqt_se_mlp_fwd": (I, [P, P, P, P, P, I, I, I, P]),
     "diqt_se_mlp_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),

@@ -528,6 +528,50 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const float* __restr
     }
 }
 
+// y = h*gate[b][c] + res AND per-workgroup column sums (sum, sum of squares) of y for the consumer's GroupNorm statistics
+// (ResnetBlock output -> the next block's first GroupNorm, imagen_pytorch3D.py:568-614): stats[b][blk][2][C].
+// 1024 % C == 0, so a thread's channel quad is the same in every grid-stride iteration (stride = gridDim.x * 1024 floats) and
+// the threads t, t + C/4, ... of a workgroup share it: fixed-order combine through LDS, one partial row per workgroup.
+__global__ __launch_bounds__(256) void gate_residual_stats_kernel(const float* __restrict__ h, const float* __restrict__ gate,
+                                                                  const float* __restrict__ res, float* __restrict__ y,
+                                                                  float* __restrict__ stats, int rows, int C) {
+    __shared__ float red[256 * 8];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const size_t per = (size_t)rows * C, n4 = per >> 2;
+    const float* hb = h + (size_t)b * per;
+    const float* rb = res ? res + (size_t)b * per : nullptr;
+    float* yb = y + (size_t)b * per;
+    const int c = (t * 4) % C;
+    const float4 gq = *reinterpret_cast<const float4*>(gate + (size_t)b * C + c);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + t; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = *reinterpret_cast<const float4*>(hb + i * 4);
+        v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
+        if (rb) {
+            const float4 r = *reinterpret_cast<const float4*>(rb + i * 4);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        *reinterpret_cast<float4*>(yb + i * 4) = v;
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        q0 = fmaf(v.x, v.x, q0); q1 = fmaf(v.y, v.y, q1); q2 = fmaf(v.z, v.z, q2); q3 = fmaf(v.w, v.w, q3);
+    }
+    float* mine = red + t * 8;
+    mine[0] = s0; mine[1] = s1; mine[2] = s2; mine[3] = s3; mine[4] = q0; mine[5] = q1; mine[6] = q2; mine[7] = q3;
+    __syncthreads();
+    const int nq = C / 4;                         // channel quads; nq divides 256
+    if (t < nq) {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = red[t * 8 + k];
+        for (int u = t + nq; u < 256; u += nq)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += red[u * 8 + k];
+        float* o = stats + (((size_t)b * gridDim.x + blockIdx.x) * 2) * C + 4 * t;
+        *reinterpret_cast<float4*>(o) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(o + C) = make_float4(a[4], a[5], a[6], a[7]);
+    }
+}
+
 // SE3D.fc on [B][C] (single block: B*C*Cr MACs is a few 100k at most)
 __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, float* __restrict__ hidden,
@@ -1521,6 +1565,26 @@ extern "C" int diqt_gate_residual_fwd(const float* h, const float* gate, const f
     else
         hipLaunchKernelGGL(gate_residual_kernel<false>, grid, dim3(256), 0, STREAM, h, gate, res, addc, alpha, y, rows, C);
     return check_launch("gate_residual_fwd");
+}
+
+// number of per-workgroup partial rows diqt_gate_residual_fwd_stats writes per batch entry (0: shape not supported -- C must divide
+// 1024 and be a multiple of 4 -- use diqt_gate_residual_fwd and a statistics pass)
+extern "C" int diqt_gate_residual_stats_blocks(int rows, int C) {
+    if (rows <= 0 || C < 4 || C % 4 != 0 || 1024 % C != 0) return 0;
+    const size_t per = (size_t)rows * C;
+    return (int)grid_for(per / 4 + 1, 256, 512);
+}
+
+extern "C" int diqt_gate_residual_fwd_stats(const float* h, const float* gate, const float* res, float* y, float* stats, int B, int rows,
+                                            int C, void* stream) {
+    DIQT_REQUIRE(h && gate && y && stats, DIQT_E_ALIGN, "gate_residual_fwd_stats: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0, DIQT_E_SHAPE, "gate_residual_fwd_stats: bad shape");
+    const int nblk = diqt_gate_residual_stats_blocks(rows, C);
+    DIQT_REQUIRE(nblk > 0, DIQT_E_UNSUPPORTED, "gate_residual_fwd_stats: C = %d must be a multiple of 4 dividing 1024", C);
+    DIQT_REQUIRE(aligned16(h) && aligned16(gate) && aligned16(y) && aligned16(stats) && (!res || aligned16(res)), DIQT_E_ALIGN,
+                 "gate_residual_fwd_stats: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(gate_residual_stats_kernel, dim3(nblk, B), dim3(256), 0, STREAM, h, gate, res, y, stats, rows, C);
+    return check_launch("gate_residual_fwd_stats");
 }
 
 extern "C" int diqt_gate_residual_bwd(const float* h, const float* dy, float* dgate, void* workspace,

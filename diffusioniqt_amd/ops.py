@@ -535,7 +535,7 @@ def learned_sinusoidal(t, w):
 # --------------------------------------------------------------------------------------------
 class _SEResidualFn(Function):
     @staticmethod
-    def forward(ctx, h, w1, w2, res, pre=None):
+    def forward(ctx, h, w1, w2, res, pre=None, stats_out=None):
         _chk(h, w1, w2, res)
         B, C = h.shape[0], h.shape[-1]
         rows = h.numel() // (B * C)
@@ -552,7 +552,14 @@ class _SEResidualFn(Function):
         gate = torch.empty((B, C), dtype=torch.float32, device=dev)
         _lib.call("diqt_se_mlp_fwd", pooled, w1, w2, hidden, gate, B, C, Cr, s)
         y = torch.empty_like(h)
-        _lib.call("diqt_gate_residual_fwd", h, gate, res, None, 0.0, y, B, rows, C, s)
+        nblk = _lib.query("diqt_gate_residual_stats_blocks", rows, C) if stats_out is not None else 0
+        if nblk > 0:
+            # the block's output feeds the next block's first GroupNorm: its per-workgroup column sums ride along (no statistics pass)
+            stats = torch.empty((B, nblk, 2, C), dtype=torch.float32, device=dev)
+            _lib.call("diqt_gate_residual_fwd_stats", h, gate, res, y, stats, B, rows, C, s)
+            stats_out.append(ColStats(stats, nblk, rows))
+        else:
+            _lib.call("diqt_gate_residual_fwd", h, gate, res, None, 0.0, y, B, rows, C, s)
         ctx.save_for_backward(h, w1, w2, pooled, hidden, gate)
         ctx.has_res = res is not None
         return y
@@ -575,12 +582,16 @@ class _SEResidualFn(Function):
         _lib.call("diqt_se_mlp_bwd", pooled, w1, w2, hidden, gate, dgate, dpooled, dw1, dw2, scratch, B, C, Cr, s)
         dh = torch.empty_like(h)
         _lib.call("diqt_gate_residual_fwd", dy, gate, None, dpooled, 1.0 / rows, dh, B, rows, C, s)
-        return dh, dw1, dw2, (dy if ctx.has_res else None), None
+        return dh, dw1, dw2, (dy if ctx.has_res else None), None, None
 
 
 def se_gate_residual(h, w1, w2, res=None):
     """h * sigmoid(relu(mean(h) w1^T) w2^T) + res."""
-    return _SEResidualFn.apply(h, w1, w2, res, getattr(h, "_diqt_stats", None))
+    holder = []
+    y = _SEResidualFn.apply(h, w1, w2, res, getattr(h, "_diqt_stats", None), holder)
+    if holder:
+        y._diqt_stats = holder[0]           # consumed by groupnorm_act on this exact tensor
+    return y
 
 
 class _AddFn(Function):

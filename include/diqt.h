@@ -219,6 +219,13 @@ int diqt_weighted_colsum(const float* x, const float* w, float* out, void* works
  * backward dh = dy*gate + (1/rows)*dpooled[b][c] of the gate AND of the mean pool in one pass.        */
 int diqt_gate_residual_fwd(const float* h, const float* gate, const float* res, const float* addc, float alpha,
                            float* y, int B, int rows_per_batch, int C, void* stream);
+/* The same with res only, plus per-workgroup column sums of y for the consumer's GroupNorm statistics (a ResnetBlock's output feeds
+ * the next block's first GroupNorm, imagen_pytorch3D.py:568-614): stats[B][nblk][2 (sum, sum of squares)][C],
+ * nblk = diqt_gate_residual_stats_blocks(rows, C) (0: C is not a multiple of 4 dividing 1024 -- use the plain entry point).
+ * Feed them to diqt_groupnorm_stats_from_partials; saves one full read of y.                                                  */
+int diqt_gate_residual_stats_blocks(int rows, int C);
+int diqt_gate_residual_fwd_stats(const float* h, const float* gate, const float* res, float* y, float* stats, int B, int rows, int C,
+                                 void* stream);
 /* dgate[b][c] = sum_rows dy*h */
 int diqt_gate_residual_bwd(const float* h, const float* dy, float* dgate, void* workspace, size_t workspace_bytes,
                            int B, int rows_per_batch, int C, void* stream);

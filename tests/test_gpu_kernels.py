@@ -380,6 +380,34 @@ def test_bgemm_large_tiles_all_layouts(ops, g_, M, N, K):
     close(Bd.grad, Br.grad, tol=1e-4, what="bgemm dB")
 
 
+def test_gate_residual_emits_groupnorm_statistics(ops):
+    """se_gate_residual attaches per-workgroup column sums of its OUTPUT; the next GroupNorm finalises its statistics from them
+    (no pass over the tensor) and must produce what it produces from a statistics pass over the same tensor."""
+    from diffusioniqt_amd import _lib
+    gen = torch.Generator().manual_seed(31)
+    for B, S, C in ((2, 8, 64), (3, 6, 128), (1, 5, 32), (2, 4, 48)):              # 48 does not divide 1024: no statistics
+        h = torch.randn(B, S, S, S, C, generator=gen).to(DEV)
+        res = torch.randn(B, S, S, S, C, generator=gen).to(DEV)
+        w1 = (torch.randn(max(C // 16, 1), C, generator=gen) * 0.2).to(DEV)
+        w2 = (torch.randn(C, max(C // 16, 1), generator=gen) * 0.2).to(DEV)
+        gamma, beta = torch.randn(C, generator=gen).to(DEV), torch.randn(C, generator=gen).to(DEV)
+        with torch.no_grad():
+            y = ops.se_gate_residual(h, w1, w2, res)
+            st = getattr(y, "_diqt_stats", None)
+            assert (st is not None) == (_lib.query("diqt_gate_residual_stats_blocks", S ** 3, C) > 0) == (1024 % C == 0)
+            ref = h * torch.sigmoid(torch.relu(h.mean(dim=(1, 2, 3)) @ w1.t()) @ w2.t())[:, None, None, None, :] + res
+            close(y, ref, tol=3e-5, what="gate residual")
+            if st is None:
+                continue
+            sums = st.partials.double().sum(dim=1)                                      # [B, 2, C]
+            close(sums[:, 0], y.double().sum(dim=(1, 2, 3)), tol=1e-5, what="column sums")
+            close(sums[:, 1], (y.double() ** 2).sum(dim=(1, 2, 3)), tol=1e-5, what="column sums of squares")
+            a = ops.groupnorm_act(y, gamma, beta, None, 8, ops.ACT_MISH)               # statistics from the partials
+            yc = y.clone()                                                              # same values, no partials attached
+            bfull = ops.groupnorm_act(yc, gamma, beta, None, 8, ops.ACT_MISH)
+            close(a, bfull, tol=2e-5, what="GroupNorm from gate_residual partials")
+
+
 def test_softmax_over_tokens_with_few_columns(ops):
     """LinearAttention's k.softmax(dim=-2) on [b*h, n, d] (imagen_pytorch3D.py:926-1016): the workgroup-per-outer kernel (inner divides
     1024, n >= 64) and the one-thread-per-column kernel next to it."""

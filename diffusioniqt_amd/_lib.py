@@ -54,6 +54,7 @@ PROTOTYPES = {
     "diqt_gate_residual_fwd_stats": (I, [P, P, P, P, P, I, I, I, P]),
     "diqt_gate_residual_bwd": (I, [P, P, P, P, Z, I, I, I, P]),
     "diqt_se_mlp_fwd": (I, [P, P, P, P, P, I, I, I, P]),
+    "diqt_se_pool_mlp_fwd": (I, [P, I, I, P, P, P, P, P, I, I, I, P]),
     "diqt_se_mlp_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "diqt_add_channel_broadcast": (I, [P, P, F, I, I, I, P]),
     "diqt_space_to_depth2": (I, [P, P, I, I, I, I, I, P]),

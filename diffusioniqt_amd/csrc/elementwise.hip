@@ -590,6 +590,52 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
         gate[i] = 1.f / (1.f + __expf(-s));
     }
 }
+// SE3D squeeze + excitation for ONE batch entry per workgroup (imagen_pytorch3D.py:617-632): channel means finished from the
+// producer's per-tile column sums (or taken from `pooled_in`), then fc1 -> ReLU -> fc2 -> sigmoid.  The single-workgroup kernel
+// above spends 10 us per call on 32 threads doing 64-long strided dot products; a sampler step has 19 of them.
+__global__ __launch_bounds__(256) void se_pool_mlp_fwd_kernel(const float* __restrict__ partials, int nblk, float alpha,
+                                                              const float* __restrict__ pooled_in, const float* __restrict__ w1,
+                                                              const float* __restrict__ w2, float* __restrict__ pooled,
+                                                              float* __restrict__ hidden, float* __restrict__ gate, int C, int Cr) {
+    extern __shared__ float sm[];          // [256] scratch | [C] pooled | [Cr] hidden
+    float* red = sm;
+    float* pl = sm + 256;
+    float* hid = pl + C;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (partials) {                        // fixed order: row group rg of channel c sums tiles rg, rg + RG, ...; groups combined in order
+        for (int c0 = 0; c0 < C; c0 += 256) {
+            const int cw = min(256, C - c0), RG = 256 / cw;              // cw divides 256 whenever C does or is a multiple of 256
+            const int c = c0 + t % cw, rg = t / cw;
+            float a = 0.f;
+            if (rg < RG)
+                for (int k = rg; k < nblk; k += RG) a += partials[(((size_t)b * nblk + k) * 2) * C + c];
+            red[t] = a;
+            __syncthreads();
+            if (t < cw) {
+                float v = red[t];
+                for (int r = 1; r < RG; ++r) v += red[r * cw + t];
+                pl[c0 + t] = alpha * v;
+                pooled[(size_t)b * C + c0 + t] = alpha * v;
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int c = t; c < C; c += 256) pl[c] = pooled_in[(size_t)b * C + c];
+        __syncthreads();
+    }
+    for (int r = wave; r < Cr; r += 4) {   // one wave per hidden unit: lane-strided dot product, butterfly sum
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(w1[(size_t)r * C + c], pl[c], a);
+        a = wave_sum(a);
+        if (lane == 0) { const float hv = fmaxf(a, 0.f); hid[r] = hv; hidden[(size_t)b * Cr + r] = hv; }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float a = 0.f;
+        for (int r = 0; r < Cr; ++r) a = fmaf(w2[(size_t)c * Cr + r], hid[r], a);
+        gate[(size_t)b * C + c] = 1.f / (1.f + __expf(-a));
+    }
+}
 __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, const float* __restrict__ hidden,
                                                          const float* __restrict__ gate, const float* __restrict__ dgate,
@@ -1601,6 +1647,20 @@ extern "C" int diqt_se_mlp_fwd(const float* pooled, const float* w1, const float
     DIQT_REQUIRE(B > 0 && C > 0 && Cr > 0, DIQT_E_SHAPE, "se_mlp_fwd: bad shape");
     hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(1), dim3(256), 0, STREAM, pooled, w1, w2, hidden, gate, B, C, Cr);
     return check_launch("se_mlp_fwd");
+}
+// squeeze + excitation in one launch: `partials` (per-tile column sums of h from its producer, [B][nblk][2][C]) or, when NULL,
+// `pooled` as input; writes pooled (when computed here), hidden and gate
+extern "C" int diqt_se_pool_mlp_fwd(const float* partials, int nblk, int rows, float* pooled, const float* w1, const float* w2,
+                                    float* hidden, float* gate, int B, int C, int Cr, void* stream) {
+    DIQT_REQUIRE(pooled && w1 && w2 && hidden && gate, DIQT_E_ALIGN, "se_pool_mlp_fwd: null pointer");
+    DIQT_REQUIRE(B > 0 && C > 0 && Cr > 0 && (!partials || (nblk > 0 && rows > 0)), DIQT_E_SHAPE, "se_pool_mlp_fwd: bad shape");
+    DIQT_REQUIRE(!partials || 256 % (C < 256 ? C : 256) == 0 && (C <= 256 || C % 256 == 0), DIQT_E_UNSUPPORTED,
+                 "se_pool_mlp_fwd: C = %d must divide 256 or be a multiple of it to finish the channel means here", C);
+    const size_t lds = (size_t)(256 + C + Cr) * sizeof(float);
+    DIQT_REQUIRE(lds <= 64 * 1024, DIQT_E_UNSUPPORTED, "se_pool_mlp_fwd: C too large");
+    hipLaunchKernelGGL(se_pool_mlp_fwd_kernel, dim3(B), dim3(256), lds, STREAM, partials, nblk, partials ? 1.f / (float)rows : 1.f,
+                       partials ? nullptr : pooled, w1, w2, pooled, hidden, gate, C, Cr);
+    return check_launch("se_pool_mlp_fwd");
 }
 extern "C" int diqt_se_mlp_bwd(const float* pooled, const float* w1, const float* w2, const float* hidden,
                                const float* gate, const float* dgate, float* dpooled, float* dw1, float* dw2,

@@ -543,14 +543,19 @@ class _SEResidualFn(Function):
         dev = h.device
         s = _stream()
         pooled = torch.empty((B, C), dtype=torch.float32, device=dev)
-        if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
-            _lib.call("diqt_channel_mean_from_partials", pre.partials, pooled, B, pre.nblk, rows, C, s)
-        else:
-            ws, n = _reduce_ws(B, C, dev)
-            _lib.call("diqt_channel_mean", h, pooled, ws, n, B, rows, C, s)
         hidden = torch.empty((B, Cr), dtype=torch.float32, device=dev)
         gate = torch.empty((B, C), dtype=torch.float32, device=dev)
-        _lib.call("diqt_se_mlp_fwd", pooled, w1, w2, hidden, gate, B, C, Cr, s)
+        fused = 256 % min(C, 256) == 0 and (C <= 256 or C % 256 == 0)
+        if fused and pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
+            # channel means from the producing conv's per-tile column sums + the two-layer gate MLP in ONE launch
+            _lib.call("diqt_se_pool_mlp_fwd", pre.partials, pre.nblk, rows, pooled, w1, w2, hidden, gate, B, C, Cr, s)
+        else:
+            if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
+                _lib.call("diqt_channel_mean_from_partials", pre.partials, pooled, B, pre.nblk, rows, C, s)
+            else:
+                ws, n = _reduce_ws(B, C, dev)
+                _lib.call("diqt_channel_mean", h, pooled, ws, n, B, rows, C, s)
+            _lib.call("diqt_se_pool_mlp_fwd", None, 0, 0, pooled, w1, w2, hidden, gate, B, C, Cr, s)
         y = torch.empty_like(h)
         nblk = _lib.query("diqt_gate_residual_stats_blocks", rows, C) if stats_out is not None else 0
         if nblk > 0:

@@ -233,6 +233,11 @@ int diqt_gate_residual_bwd(const float* h, const float* dy, float* dgate, void* 
  * w1[Cr][C], w2[C][Cr], no biases.  bwd: dpooled, dw1, dw2 from dgate; scratch >= B*(C+Cr) floats.     */
 int diqt_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* hidden, float* gate,
                     int B, int C, int Cr, void* stream);
+/* SE3D squeeze + excitation in ONE launch, one workgroup per batch entry: the channel means are finished from the producer's
+ * per-tile column sums `partials` [B][nblk][2][C] (diqt_conv3d_fwd_ex) -- or read from `pooled` when partials == NULL -- then
+ * fc1 -> ReLU -> fc2 -> sigmoid.  Writes pooled (when computed here), hidden [B][Cr] and gate [B][C].                         */
+int diqt_se_pool_mlp_fwd(const float* partials, int nblk, int rows, float* pooled, const float* w1, const float* w2, float* hidden,
+                         float* gate, int B, int C, int Cr, void* stream);
 int diqt_se_mlp_bwd(const float* pooled, const float* w1, const float* w2, const float* hidden, const float* gate,
                     const float* dgate, float* dpooled, float* dw1, float* dw2, float* scratch,
                     int B, int C, int Cr, void* stream);

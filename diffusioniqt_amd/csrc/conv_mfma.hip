@@ -370,6 +370,211 @@ __global__ __launch_bounds__(256, CKT == 16 ? 3 : 2) void conv_fwd_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// 8-wave variant for the large launches (>= two resident rounds): ONE 512-thread workgroup per CU owns 256 output voxels
+// (e.g. 4x8x8: halo 6x10x10 = 2.34 input voxels per output voxel instead of 3.13 for the 128-voxel tile) x 64 output channels.
+// With a single workgroup on the CU nothing else would run beside its staging, so the staging is taken off the critical path
+// inside the workgroup instead of across workgroups:
+//   * the NEXT chunk's halo is loaded global -> registers at the start of a chunk's last tap group and written to LDS at the
+//     chunk boundary (the loads fly during ~6k MFMA cycles per wave);
+//   * weight panels come in groups of F8_TG taps, double-buffered: group s+1 global -> registers before the taps of group s, ->
+//     the other LDS buffer after them: ONE barrier per F8_TG taps (per 96 MFMAs of a wave) instead of one per tap.
+// Two waves per SIMD as before (wave w: voxels 32w..32w+31, both 32-channel halves), same fragment order, LDS rows, packed weights
+// and epilogue (incl. the per-tile column sums) as conv_fwd_kernel, hence the same bits per output element.
+// ---------------------------------------------------------------------------------------------
+constexpr int F8_MT = 256;       // output voxels per workgroup
+constexpr int F8_TG = 3;         // taps per weight group
+constexpr int F8_HREG = 10;      // 16-byte halo pieces per thread held in registers (HV <= 640)
+constexpr int F8_WREG = (F8_TG * 512 + 511) / 512;    // 16-byte weight pieces per thread and group: a tap's 64 x 32-float panel = 512 pieces
+
+__global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                           const float* __restrict__ bias, const float* __restrict__ residual,
+                                                           float* __restrict__ y, ConvGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HV = g.HD * g.HH * g.HWd;
+    float* halo = smem;                                              // [HV][36]
+    float* wbuf = smem + (size_t)HV * LDSROW;                        // [2][F8_TG][64][36]
+    constexpr int WBUF = F8_TG * NT * LDSROW;
+    int* out_off = reinterpret_cast<int*>(wbuf + 2 * WBUF);          // [256]
+    int* halo_src = out_off + F8_MT;                                 // [HV]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int T = g.kd * g.kh * g.kw;
+    const int nGroups = (T + F8_TG - 1) / F8_TG;
+
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = L % g.nNt;
+    int mt = L / g.nNt;
+    const int tx = mt % g.tilesW; mt /= g.tilesW;
+    const int ty = mt % g.tilesH; mt /= g.tilesH;
+    const int tz = mt % g.tilesD;
+    const int b = mt / g.tilesD;
+    const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
+    const int n0 = nt * NT;
+
+    if (tid < F8_MT) {
+        const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
+        const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+        int off = (int)BUF_OOB;
+        if (od < g.Do && oh < g.Ho && ow < g.Wo) off = (((b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout * 4;
+        out_off[tid] = off;
+    }
+    for (int hv = tid; hv < HV; hv += 512) {
+        const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+        const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+        int src = (int)BUF_OOB;
+        if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) src = (((b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin * 4;
+        halo_src[hv] = src;
+    }
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
+
+    int hidx_lane;
+    {
+        const int v = wave * 32 + l31;
+        const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
+        hidx_lane = (td * g.HH + th) * g.HWd + tw;
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    const int hc4 = (tid & 7) * 4;                  // this thread's channel quad inside a chunk (512 % 8 == 0)
+    const int nHalo = HV * 8;
+    __syncthreads();                                // tables visible
+
+    u32x4 hr[F8_HREG];
+    auto load_halo = [&](int ci0) {                 // all pieces of a chunk in flight at once; unconditional loads (range-checked descriptor)
+        const unsigned coff = (ci0 + hc4 < g.Cin) ? (unsigned)(ci0 + hc4) * 4u : BUF_OOB_C;
+#pragma unroll
+        for (int u = 0; u < F8_HREG; ++u) {
+            const int idx = u * 512 + tid;
+            const unsigned t = (unsigned)halo_src[min(idx >> 3, HV - 1)] + coff;
+            hr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, idx < nHalo ? t : BUF_OOB, 0, 0);
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int u = 0; u < F8_HREG; ++u) {
+            const int idx = u * 512 + tid;
+            if (idx < nHalo) *reinterpret_cast<u32x4*>(halo + (idx >> 3) * LDSROW + hc4) = hr[u];
+        }
+    };
+    u32x4 wr[F8_WREG];
+    const int wrow = tid >> 3, wc4 = (tid & 7) * 4;            // piece tid of a tap panel: row tid / 8, channel quad tid % 8
+    auto load_wgroup = [&](int chunk, int t0, int n) {
+        const float* src = wp + ((size_t)chunk * T * g.CoutPad + n0) * CK;
+#pragma unroll
+        for (int u = 0; u < F8_WREG; ++u)
+            wr[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(t0 + min(u, n - 1)) * g.CoutPad + wrow) * CK + wc4);   // unconditional
+    };
+    auto store_wgroup = [&](int buf, int n) {
+        float* dst = wbuf + buf * WBUF;
+#pragma unroll
+        for (int u = 0; u < F8_WREG; ++u)
+            if (u < n) *reinterpret_cast<u32x4*>(dst + (u * NT + wrow) * LDSROW + wc4) = wr[u];
+    };
+
+    load_halo(0);
+    load_wgroup(0, 0, min(F8_TG, T));
+    store_halo();
+    store_wgroup(0, min(F8_TG, T));
+    __syncthreads();
+
+    int step = 0;
+    for (int chunk = 0; chunk < g.nChunks; ++chunk) {
+        for (int grp = 0; grp < nGroups; ++grp, ++step) {
+            const int t0 = grp * F8_TG, nTap = min(F8_TG, T - t0);
+            const bool lastGrp = grp + 1 == nGroups, more = !(lastGrp && chunk + 1 == g.nChunks);
+            const int nchunk = lastGrp ? chunk + 1 : chunk, nt0 = lastGrp ? 0 : t0 + F8_TG, nn = min(F8_TG, T - nt0);
+            if (more) load_wgroup(nchunk, nt0, nn);
+            const bool nextHalo = lastGrp && more;
+            if (nextHalo) load_halo((chunk + 1) * CK);
+            int kx = t0 % g.kw, ky = (t0 / g.kw) % g.kh, kz = t0 / (g.kw * g.kh);
+            int trow = (kz * g.HH + ky) * g.HWd + kx;                 // wave-uniform halo row offset of the tap
+            const float* wcur = wbuf + (step & 1) * WBUF + l31 * LDSROW + 4 * h;
+            for (int t = 0; t < nTap; ++t) {
+                const float* ap = halo + (hidx_lane + trow) * LDSROW + 4 * h;
+                const float* bp = wcur + t * (NT * LDSROW);
+                float4 a = *reinterpret_cast<const float4*>(ap);
+                float4 b0 = *reinterpret_cast<const float4*>(bp);
+                float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 an, b0n, b1n;
+                    if (q < 3) {
+                        an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+                        b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+                        b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+                    if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
+                }
+                trow += 1;
+                if (++kx == g.kw) {
+                    kx = 0; trow += g.HWd - g.kw;
+                    if (++ky == g.kh) { ky = 0; trow += (g.HH - g.kh) * g.HWd; }
+                }
+            }
+            if (more) store_wgroup((step + 1) & 1, nn);      // that buffer was last read in step-1, retired by its barrier
+            if (nextHalo) {
+                __syncthreads();                             // every wave is done with this chunk's halo image
+                store_halo();
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[row=voxel][col=co]; row = (r&3) + 8*(r>>2) + 4*h ----
+    const int co0 = n0 + l31, co1 = n0 + 32 + l31;
+    const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
+    const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
+    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
+    float cs0 = 0.f, cq0 = 0.f, cs1 = 0.f, cq1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned off = (unsigned)out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        if (residual) {        // wave-uniform
+            v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+            v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+        if (g.stats && off != BUF_OOB) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
+    }
+    if (g.stats) {             // block-uniform: fixed-order combine of lane halves, then of the 8 waves through LDS
+        cs0 += __shfl_xor(cs0, 32, 64); cq0 += __shfl_xor(cq0, 32, 64);
+        cs1 += __shfl_xor(cs1, 32, 64); cq1 += __shfl_xor(cq1, 32, 64);
+        float* red = halo;     // every wave passed the last barrier: the halo image is dead
+        if (h == 0) {
+            red[(wave * 4 + 0) * 32 + l31] = cs0; red[(wave * 4 + 1) * 32 + l31] = cq0;
+            red[(wave * 4 + 2) * 32 + l31] = cs1; red[(wave * 4 + 3) * 32 + l31] = cq1;
+        }
+        __syncthreads();
+        if (tid < 128) {       // q = tid >> 5: 0 sum(co0) 1 sumsq(co0) 2 sum(co1) 3 sumsq(co1)
+            const int q = tid >> 5, l = tid & 31;
+            float v = red[q * 32 + l];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) v += red[(w * 4 + q) * 32 + l];
+            const int co = n0 + (q >> 1) * 32 + l;
+            const int tpb = g.tilesD * g.tilesH * g.tilesW, tIn = (tz * g.tilesH + ty) * g.tilesW + tx;
+            if (co < g.Cout) g.stats[(((size_t)b * tpb + tIn) * 2 + (q & 1)) * g.Cout + co] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 1x1x1 filters / Linear rows (pixel-shuffle and down-sample projections, attention and feed-forward projections, res_conv):
 // a plain GEMM y[rows][Cout] = x[rows][Cin] W^T.  With ONE tap per 32-channel chunk the generic kernel above stages a chunk,
 // issues 32 MFMAs per wave and stages again -- every chunk pays a global round trip (61-71 TFLOP/s).  Here the next chunk's
@@ -1263,6 +1468,38 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
                            epw, stream, nullptr);
 }
 
+// 8-wave forward plan: the geometry re-tiled for 256-voxel workgroups, or false when conv_fwd8_kernel does not take the launch
+// (fewer than two resident rounds of 256-voxel tiles, halo beyond the prefetch registers or the LDS, tensors >= 1 GiB, Cin % 4)
+static bool fwd8_plan(const ConvGeom& g, ConvGeom& g8, size_t& lds) {
+    static const int mode = [] { const char* e = getenv("DIQT_CONV_W8"); return e ? atoi(e) : 1; }();      // 0: never
+    const int T = g.kd * g.kh * g.kw;
+    if (!mode || T < 2 || g.Cin % 4 != 0 || smallcin_pad(g.Cin, T)) return false;
+    const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
+    const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
+    if (xb >= (1ull << 30) || yb >= (1ull << 30)) return false;
+    static const int cand[][3] = {{4, 8, 8}, {8, 8, 4}, {8, 4, 8}, {2, 8, 16}, {2, 16, 8}, {1, 16, 16}, {16, 4, 4}, {4, 4, 16}, {4, 16, 4},
+                                  {1, 8, 32}, {1, 32, 8}, {32, 4, 2}, {64, 2, 2}, {256, 1, 1}, {1, 1, 256}};
+    double best = 1e300;
+    bool found = false;
+    g8 = g;
+    for (auto& c : cand) {
+        const long long hv = (long long)(c[0] + g.kd - 1) * (c[1] + g.kh - 1) * (c[2] + g.kw - 1);
+        if (hv * 8 > 512 * F8_HREG) continue;
+        const size_t l = ((size_t)hv * LDSROW + 2 * (size_t)F8_TG * NT * LDSROW) * sizeof(float) + (F8_MT + (size_t)hv) * sizeof(int);
+        if (l > 160 * 1024) continue;
+        const double tiles = (double)cdiv(g.Do, c[0]) * cdiv(g.Ho, c[1]) * cdiv(g.Wo, c[2]);
+        const double cost = tiles * ((double)hv * 0.15 + 256.0 * T);
+        if (cost < best) { best = cost; g8.TD = c[0]; g8.TH = c[1]; g8.TW = c[2]; lds = l; found = true; }
+    }
+    if (!found) return false;
+    g8.tilesD = cdiv(g.Do, g8.TD); g8.tilesH = cdiv(g.Ho, g8.TH); g8.tilesW = cdiv(g.Wo, g8.TW);
+    g8.HD = g8.TD + g.kd - 1; g8.HH = g8.TH + g.kh - 1; g8.HWd = g8.TW + g.kw - 1;
+    const long long nwg8 = (long long)g.B * g8.tilesD * g8.tilesH * g8.tilesW * g.nNt;
+    if (nwg8 < (mode == 2 ? 1 : 512)) return false;              // needs at least two rounds of one workgroup per CU to pay (mode 2: always)
+    g8.xBytes = (unsigned)xb; g8.yBytes = (unsigned)yb;
+    return true;
+}
+
 // per-tile output statistics are produced by the buffer-path kernel of an unsplit launch; returns the number of tiles per batch
 // entry (the `nblk` of the [B][nblk][2][Cout] partial layout) or 0 when this shape would take another path
 extern "C" int diqt_conv3d_fwd_stats_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
@@ -1278,6 +1515,9 @@ extern "C" int diqt_conv3d_fwd_stats_blocks(int B, int D, int H, int W, int Cin,
     if (xb >= (1ull << 30) || yb >= (1ull << 30)) return 0;
     const size_t lds = ((size_t)g.HD * g.HH * g.HWd * (LDSROW + 1) + 2 * NT * LDSROW) * sizeof(float) + MTILE * sizeof(int);
     if (lds > 160 * 1024) return 0;
+    ConvGeom g8;
+    size_t lds8;
+    if (fwd8_plan(g, g8, lds8)) return g8.tilesD * g8.tilesH * g8.tilesW;      // the 8-wave kernel writes one row per 256-voxel tile
     return g.tilesD * g.tilesH * g.tilesW;
 }
 
@@ -1425,6 +1665,20 @@ static int conv3d_fwd_one(const float* x, const float* packed, const float* bias
     }
     DIQT_REQUIRE(!stats || buf, DIQT_E_UNSUPPORTED, "conv3d_fwd: output statistics need the buffer-path kernel");
     g.stats = stats;
+    if (buf && !dbg_on && !ck16) {
+        ConvGeom g8;
+        size_t lds8;
+        if (fwd8_plan(g, g8, lds8)) {
+            g8.stats = stats;
+            if (lds8 > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+                DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            }
+            const unsigned nwg8 = (unsigned)((long long)g8.B * g8.tilesD * g8.tilesH * g8.tilesW * g8.nNt);
+            hipLaunchKernelGGL(conv_fwd8_kernel, dim3(nwg8), dim3(512), lds8, (hipStream_t)stream, x, packed, bias, residual, y, g8);
+            return check_launch("conv3d_fwd(8 waves)");
+        }
+    }
     static const bool no1x1 = [] { const char* e = getenv("DIQT_CONV_NO1X1"); return e && e[0] == '1'; }();
     if (buf && !stats && !dbg_on && !no1x1 && kd * kh * kw == 1 && g.B == 1 && g.D == 1 && g.H == 1 && g.Wo == g.W && g.TW == MTILE) {     // the flattened-rows geometry of make_geom
         hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, packed, bias, residual, y, g);

@@ -1473,7 +1473,8 @@ extern "C" int diqt_conv3d_fwd(const float* x, const float* packed, const float*
 static bool fwd8_plan(const ConvGeom& g, ConvGeom& g8, size_t& lds) {
     static const int mode = [] { const char* e = getenv("DIQT_CONV_W8"); return e ? atoi(e) : 1; }();      // 0: never
     const int T = g.kd * g.kh * g.kw;
-    if (!mode || T < 2 || g.Cin % 4 != 0 || smallcin_pad(g.Cin, T)) return false;
+    // measured: +1.2 % on 27-tap filters, -3.5 % on the 9-tap (1,3,3) filters of the pseudo-3D blocks (a chunk there is 3 steps long)
+    if (!mode || (T < 12 && mode != 2) || T < 2 || g.Cin % 4 != 0 || smallcin_pad(g.Cin, T)) return false;
     const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
     const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
     if (xb >= (1ull << 30) || yb >= (1ull << 30)) return false;

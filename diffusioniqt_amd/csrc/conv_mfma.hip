@@ -475,12 +475,15 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
             if (u < n) *reinterpret_cast<u32x4*>(dst + (u * NT + wrow) * LDSROW + wc4) = wr[u];
     };
 
+    const long long ts0 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    long long tTap = 0, tSync = 0, tq = 0;
     load_halo(0);
     load_wgroup(0, 0, min(F8_TG, T));
     store_halo();
     store_wgroup(0, min(F8_TG, T));
     __syncthreads();
 
+    const long long ts1 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
     int step = 0;
     for (int chunk = 0; chunk < g.nChunks; ++chunk) {
         for (int grp = 0; grp < nGroups; ++grp, ++step) {
@@ -493,12 +496,24 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
             int kx = t0 % g.kw, ky = (t0 / g.kw) % g.kh, kz = t0 / (g.kw * g.kh);
             int trow = (kz * g.HH + ky) * g.HWd + kx;                 // wave-uniform halo row offset of the tap
             const float* wcur = wbuf + (step & 1) * WBUF + l31 * LDSROW + 4 * h;
+            if (g.dbg) tq = (long long)__builtin_readcyclecounter();
+            // fragments are prefetched one 8-MFMA group ahead ACROSS tap boundaries too: a wave that has the SIMD to itself (its
+            // partner waits at the step barrier) otherwise exposes the LDS latency of every tap's first reads and runs at 80 %
+            const float* ap = halo + (hidx_lane + trow) * LDSROW + 4 * h;
+            const float* bp = wcur;
+            float4 a = *reinterpret_cast<const float4*>(ap);
+            float4 b0 = *reinterpret_cast<const float4*>(bp);
+            float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
             for (int t = 0; t < nTap; ++t) {
-                const float* ap = halo + (hidx_lane + trow) * LDSROW + 4 * h;
-                const float* bp = wcur + t * (NT * LDSROW);
-                float4 a = *reinterpret_cast<const float4*>(ap);
-                float4 b0 = *reinterpret_cast<const float4*>(bp);
-                float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+                // halo row offset of the NEXT tap (wave-uniform counters)
+                int ntrow = trow + 1, nkx = kx + 1, nky = ky;
+                if (nkx == g.kw) {
+                    nkx = 0; ntrow += g.HWd - g.kw;
+                    if (++nky == g.kh) { nky = 0; ntrow += (g.HH - g.kh) * g.HWd; }
+                }
+                const float* apn = halo + (hidx_lane + ntrow) * LDSROW + 4 * h;
+                const float* bpn = bp + NT * LDSROW;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float4 an, b0n, b1n;
@@ -506,6 +521,13 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
                         an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
                         b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
                         b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+                    } else {
+                        // UNCONDITIONAL, also after the step's last tap (a harmless read of the following LDS rows): with a guarded
+                        // prefetch the paths into the loop header carry different numbers of pending reads and hipcc falls back to
+                        // s_waitcnt lgkmcnt(0) in front of the first MFMA group of every tap
+                        an = *reinterpret_cast<const float4*>(apn);
+                        b0n = *reinterpret_cast<const float4*>(bpn);
+                        b1n = *reinterpret_cast<const float4*>(bpn + 32 * LDSROW);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
@@ -516,22 +538,25 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
-                    if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
+                    a = an; b0 = b0n; b1 = b1n;
                 }
-                trow += 1;
-                if (++kx == g.kw) {
-                    kx = 0; trow += g.HWd - g.kw;
-                    if (++ky == g.kh) { ky = 0; trow += (g.HH - g.kh) * g.HWd; }
-                }
+                trow = ntrow; kx = nkx; ky = nky;
+                ap = apn; bp = bpn;
+                // the next tap's first fragments were requested eight MFMAs ago: retire them HERE so that no read is pending on either
+                // edge into the loop header (hipcc then needs no wait in front of the first MFMA group, only the counted ones)
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
             }
+            if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tTap += tn - tq; tq = tn; }
             if (more) store_wgroup((step + 1) & 1, nn);      // that buffer was last read in step-1, retired by its barrier
             if (nextHalo) {
                 __syncthreads();                             // every wave is done with this chunk's halo image
                 store_halo();
             }
             __syncthreads();
+            if (g.dbg) tSync += (long long)__builtin_readcyclecounter() - tq;
         }
     }
+    const long long ts2 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
 
     // ---- epilogue: D[row=voxel][col=co]; row = (r&3) + 8*(r>>2) + 4*h ----
     const int co0 = n0 + l31, co1 = n0 + 32 + l31;
@@ -571,6 +596,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
             const int tpb = g.tilesD * g.tilesH * g.tilesW, tIn = (tz * g.tilesH + ty) * g.tilesW + tx;
             if (co < g.Cout) g.stats[(((size_t)b * tpb + tIn) * 2 + (q & 1)) * g.Cout + co] = v;
         }
+    }
+    if (g.dbg && tid == 0) {     // diagnostic (DIQT_CONV_DBG=1): [prologue, tap loops, store + barriers, epilogue, lifetime, steps]
+        unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+        const long long te = (long long)__builtin_readcyclecounter();
+        d[0] = (unsigned long long)(ts1 - ts0); d[1] = (unsigned long long)tTap; d[2] = (unsigned long long)tSync;
+        d[3] = (unsigned long long)(te - ts2); d[4] = (unsigned long long)(te - ts0); d[5] = (unsigned long long)step;
     }
 }
 
@@ -1666,11 +1697,16 @@ static int conv3d_fwd_one(const float* x, const float* packed, const float* bias
     }
     DIQT_REQUIRE(!stats || buf, DIQT_E_UNSUPPORTED, "conv3d_fwd: output statistics need the buffer-path kernel");
     g.stats = stats;
-    if (buf && !dbg_on && !ck16) {
+    if (buf && !ck16) {
         ConvGeom g8;
         size_t lds8;
         if (fwd8_plan(g, g8, lds8)) {
             g8.stats = stats;
+            g8.dbg = nullptr;
+            if (dbg_on) {
+                const long long n8 = (long long)g8.B * g8.tilesD * g8.tilesH * g8.tilesW * g8.nNt;
+                if (n8 <= 65536) { g8.dbg = dbg_buf; g_dbg_ptr = dbg_buf; g_dbg_n = (unsigned)n8; }
+            }
             if (lds8 > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
                 DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -382,19 +382,21 @@ __global__ __launch_bounds__(256, CKT == 16 ? 3 : 2) void conv_fwd_kernel(const 
 // and epilogue (incl. the per-tile column sums) as conv_fwd_kernel, hence the same bits per output element.
 // ---------------------------------------------------------------------------------------------
 constexpr int F8_MT = 256;       // output voxels per workgroup
-constexpr int F8_TG = 3;         // taps per weight group
+constexpr int F8_TG = 2;         // taps per step
+constexpr int F8_NWB = 3;        // weight-group buffers (see the step protocol in the kernel)
 constexpr int F8_HREG = 10;      // 16-byte halo pieces per thread held in registers (HV <= 640)
-constexpr int F8_WREG = (F8_TG * 512 + 511) / 512;    // 16-byte weight pieces per thread and group: a tap's 64 x 32-float panel = 512 pieces
+constexpr int F8_WREG = F8_TG;   // 16-byte weight pieces per thread and step: a tap's 64 x 32-float panel = 512 pieces
 
 __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias, const float* __restrict__ residual,
                                                            float* __restrict__ y, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned long long rt_in = g.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;      // diagnostic: 100 MHz wall clock at entry
     const int HV = g.HD * g.HH * g.HWd;
     float* halo = smem;                                              // [HV][36]
-    float* wbuf = smem + (size_t)HV * LDSROW;                        // [2][F8_TG][64][36]
+    float* wbuf = smem + (size_t)HV * LDSROW;                        // [F8_NWB][F8_TG][64][36]
     constexpr int WBUF = F8_TG * NT * LDSROW;
-    int* out_off = reinterpret_cast<int*>(wbuf + 2 * WBUF);          // [256]
+    int* out_off = reinterpret_cast<int*>(wbuf + F8_NWB * WBUF);     // [256]
     int* halo_src = out_off + F8_MT;                                 // [HV]
 
     const int tid = threadIdx.x;
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
     const int l31 = lane & 31, h = lane >> 5;
     const int T = g.kd * g.kh * g.kw;
     const int nGroups = (T + F8_TG - 1) / F8_TG;
+    const int nSteps = g.nChunks * nGroups;
 
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = L % g.nNt;
@@ -462,100 +465,124 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
     };
     u32x4 wr[F8_WREG];
     const int wrow = tid >> 3, wc4 = (tid & 7) * 4;            // piece tid of a tap panel: row tid / 8, channel quad tid % 8
-    auto load_wgroup = [&](int chunk, int t0, int n) {
-        const float* src = wp + ((size_t)chunk * T * g.CoutPad + n0) * CK;
+    // weight panels of (chunk, tap group) -> registers (unconditional, clamped tap); all index arithmetic of the step loop is kept
+    // incremental and wave-uniform: a division per step costs as much as one of its MFMAs
+    const float* wthread = wp + ((size_t)n0 + wrow) * CK + wc4;
+    const size_t tapStride = (size_t)g.CoutPad * CK;
+    auto load_wstep = [&](int chunk, int grp) {
+        const int t0 = grp * F8_TG, n = min(F8_TG, T - t0);
+        const float* src = wthread + ((size_t)chunk * T + t0) * tapStride;
 #pragma unroll
-        for (int u = 0; u < F8_WREG; ++u)
-            wr[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(t0 + min(u, n - 1)) * g.CoutPad + wrow) * CK + wc4);   // unconditional
+        for (int u = 0; u < F8_WREG; ++u) wr[u] = *reinterpret_cast<const u32x4*>(src + (size_t)min(u, n - 1) * tapStride);
     };
-    auto store_wgroup = [&](int buf, int n) {
-        float* dst = wbuf + buf * WBUF;
+    float* wthread_lds = wbuf + wrow * LDSROW + wc4;
+    auto store_wstep = [&](int buf) {                          // a clamped duplicate panel is harmless
 #pragma unroll
-        for (int u = 0; u < F8_WREG; ++u)
-            if (u < n) *reinterpret_cast<u32x4*>(dst + (u * NT + wrow) * LDSROW + wc4) = wr[u];
+        for (int u = 0; u < F8_WREG; ++u) *reinterpret_cast<u32x4*>(wthread_lds + buf * WBUF + u * (NT * LDSROW)) = wr[u];
     };
 
+    // Step protocol (a step = F8_TG taps of one chunk; step st reads weight buffer st % 3):
+    //   start of step st : store W(st+1) (registers, loaded during step st-1) into buffer (st+1) % 3 -- its previous content W(st-2)
+    //                      was last read in step st-2, and every wave that passed the barrier of step st-1 has finished step st-2;
+    //                      then request W(st+2) from global memory into the registers;
+    //   before the step's last 8-MFMA group: ONE barrier (the group's operands are already in registers, so nobody restarts cold);
+    //                      behind it W(st+1) is visible and the first fragments of step st+1 are prefetched during that last group.
+    // So a wave never waits for LDS data at a step boundary, and a wave whose SIMD partner sits in the barrier runs at full rate.
+    // Only a chunk boundary (new halo image) is a full stop: barrier, halo registers -> LDS, barrier, cold fragment reads.
     const long long ts0 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    long long tTap = 0, tSync = 0, tq = 0;
+    long long tTap = 0, tSync = 0, tq = 0, tStart = 0, tWst = 0;
     load_halo(0);
-    load_wgroup(0, 0, min(F8_TG, T));
+    load_wstep(0, 0);
     store_halo();
-    store_wgroup(0, min(F8_TG, T));
+    store_wstep(0);
+    // (chunk, group) of the steps st, st+1 (sc1, sg1) and st+2 (sc2, sg2), and the weight buffers of st / st+1 (rotating 0, 1, 2)
+    int chunk = 0, grp = 0, sc1 = 0, sg1 = 1, sc2, sg2;
+    if (sg1 == nGroups) { sg1 = 0; sc1 = 1; }
+    sc2 = sc1; sg2 = sg1 + 1;
+    if (sg2 == nGroups) { sg2 = 0; sc2 = sc1 + 1; }
+    int bufNext = 1;
+    if (nSteps > 1) load_wstep(sc1, sg1);
     __syncthreads();
-
     const long long ts1 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    int step = 0;
-    for (int chunk = 0; chunk < g.nChunks; ++chunk) {
-        for (int grp = 0; grp < nGroups; ++grp, ++step) {
-            const int t0 = grp * F8_TG, nTap = min(F8_TG, T - t0);
-            const bool lastGrp = grp + 1 == nGroups, more = !(lastGrp && chunk + 1 == g.nChunks);
-            const int nchunk = lastGrp ? chunk + 1 : chunk, nt0 = lastGrp ? 0 : t0 + F8_TG, nn = min(F8_TG, T - nt0);
-            if (more) load_wgroup(nchunk, nt0, nn);
-            const bool nextHalo = lastGrp && more;
-            if (nextHalo) load_halo((chunk + 1) * CK);
-            int kx = t0 % g.kw, ky = (t0 / g.kw) % g.kh, kz = t0 / (g.kw * g.kh);
-            int trow = (kz * g.HH + ky) * g.HWd + kx;                 // wave-uniform halo row offset of the tap
-            const float* wcur = wbuf + (step & 1) * WBUF + l31 * LDSROW + 4 * h;
-            if (g.dbg) tq = (long long)__builtin_readcyclecounter();
-            // fragments are prefetched one 8-MFMA group ahead ACROSS tap boundaries too: a wave that has the SIMD to itself (its
-            // partner waits at the step barrier) otherwise exposes the LDS latency of every tap's first reads and runs at 80 %
-            const float* ap = halo + (hidx_lane + trow) * LDSROW + 4 * h;
-            const float* bp = wcur;
-            float4 a = *reinterpret_cast<const float4*>(ap);
-            float4 b0 = *reinterpret_cast<const float4*>(bp);
-            float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
-            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
-            for (int t = 0; t < nTap; ++t) {
-                // halo row offset of the NEXT tap (wave-uniform counters)
-                int ntrow = trow + 1, nkx = kx + 1, nky = ky;
-                if (nkx == g.kw) {
-                    nkx = 0; ntrow += g.HWd - g.kw;
-                    if (++nky == g.kh) { nky = 0; ntrow += (g.HH - g.kh) * g.HWd; }
-                }
-                const float* apn = halo + (hidx_lane + ntrow) * LDSROW + 4 * h;
-                const float* bpn = bp + NT * LDSROW;
+
+    int kx = 0, ky = 0, trow = 0;                                 // tap (kz, ky, kx) of the NEXT tap to run and its halo row offset
+    const float* ap = halo + hidx_lane * LDSROW + 4 * h;
+    const float* bp = wbuf + l31 * LDSROW + 4 * h;
+    float4 a = *reinterpret_cast<const float4*>(ap);
+    float4 b0 = *reinterpret_cast<const float4*>(bp);
+    float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                           // lgkmcnt(0)
+    for (int st = 0; st < nSteps; ++st) {
+        const int t0 = grp * F8_TG, nTap = min(F8_TG, T - t0);
+        const bool lastOfChunk = grp + 1 == nGroups, more = st + 1 < nSteps;
+        const long long tb = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
+        if (more) store_wstep(bufNext);
+        if (g.dbg) tWst += (long long)__builtin_readcyclecounter() - tb;
+        if (st + 2 < nSteps) load_wstep(sc2, sg2);
+        const bool nextHalo = lastOfChunk && more;
+        if (nextHalo) load_halo((chunk + 1) * CK);
+        if (g.dbg) { tq = (long long)__builtin_readcyclecounter(); tStart += tq - tb; }
+        for (int t = 0; t < nTap; ++t) {
+            // halo row offset of the tap after this one (wave-uniform counters; wraps to tap 0 at the end of a chunk)
+            int ntrow = trow + 1, nkx = kx + 1, nky = ky;
+            if (nkx == g.kw) {
+                nkx = 0; ntrow += g.HWd - g.kw;
+                if (++nky == g.kh) { nky = 0; ntrow += (g.HH - g.kh) * g.HWd; }
+            }
+            const bool lastTap = t + 1 == nTap;
+            if (lastTap && lastOfChunk) { ntrow = 0; nkx = 0; nky = 0; }
+            const float* apn = halo + (hidx_lane + ntrow) * LDSROW + 4 * h;
+            const float* bpn = lastTap ? wbuf + bufNext * WBUF + l31 * LDSROW + 4 * h : bp + NT * LDSROW;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 an, b0n, b1n;
-                    if (q < 3) {
-                        an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
-                        b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
-                        b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
-                    } else {
-                        // UNCONDITIONAL, also after the step's last tap (a harmless read of the following LDS rows): with a guarded
-                        // prefetch the paths into the loop header carry different numbers of pending reads and hipcc falls back to
-                        // s_waitcnt lgkmcnt(0) in front of the first MFMA group of every tap
-                        an = *reinterpret_cast<const float4*>(apn);
-                        b0n = *reinterpret_cast<const float4*>(bpn);
-                        b1n = *reinterpret_cast<const float4*>(bpn + 32 * LDSROW);
+            for (int q = 0; q < 4; ++q) {
+                float4 an, b0n, b1n;
+                if (q < 3) {
+                    an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+                    b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+                    b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+                } else {
+                    if (lastTap) {                       // wave-uniform: the step's barrier, operands of this group already in registers
+                        if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tTap += tn - tq; tq = tn; }
+                        __syncthreads();
+                        if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tSync += tn - tq; tq = tn; }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
-                    a = an; b0 = b0n; b1 = b1n;
+                    // unconditional prefetch of the next tap's / next step's first fragments (stale but harmless at a chunk boundary
+                    // and after the last step: the values are reloaded or never used)
+                    an = *reinterpret_cast<const float4*>(apn);
+                    b0n = *reinterpret_cast<const float4*>(bpn);
+                    b1n = *reinterpret_cast<const float4*>(bpn + 32 * LDSROW);
                 }
-                trow = ntrow; kx = nkx; ky = nky;
-                ap = apn; bp = bpn;
-                // the next tap's first fragments were requested eight MFMAs ago: retire them HERE so that no read is pending on either
-                // edge into the loop header (hipcc then needs no wait in front of the first MFMA group, only the counted ones)
-                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+                a = an; b0 = b0n; b1 = b1n;
             }
-            if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tTap += tn - tq; tq = tn; }
-            if (more) store_wgroup((step + 1) & 1, nn);      // that buffer was last read in step-1, retired by its barrier
-            if (nextHalo) {
-                __syncthreads();                             // every wave is done with this chunk's halo image
-                store_halo();
-            }
-            __syncthreads();
-            if (g.dbg) tSync += (long long)__builtin_readcyclecounter() - tq;
+            trow = ntrow; kx = nkx; ky = nky;
+            ap = apn; bp = bpn;
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the prefetch was requested eight MFMAs ago
         }
+        if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tTap += tn - tq; tq = tn; }
+        if (nextHalo) {
+            __syncthreads();                             // every wave is done with this chunk's halo image
+            store_halo();
+            __syncthreads();
+            a = *reinterpret_cast<const float4*>(ap);    // cold reads from the new image (ap / bp already point at the next step)
+            b0 = *reinterpret_cast<const float4*>(bp);
+            b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tSync += tn - tq; tq = tn; }
+        }
+        chunk = sc1; grp = sg1; sc1 = sc2; sg1 = sg2;
+        if (++sg2 == nGroups) { sg2 = 0; ++sc2; }
+        bufNext = bufNext + 1 == F8_NWB ? 0 : bufNext + 1;
     }
+    const int step = nSteps;
     const long long ts2 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
 
     // ---- epilogue: D[row=voxel][col=co]; row = (r&3) + 8*(r>>2) + 4*h ----
@@ -601,7 +628,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
         unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
         const long long te = (long long)__builtin_readcyclecounter();
         d[0] = (unsigned long long)(ts1 - ts0); d[1] = (unsigned long long)tTap; d[2] = (unsigned long long)tSync;
-        d[3] = (unsigned long long)(te - ts2); d[4] = (unsigned long long)(te - ts0); d[5] = (unsigned long long)step;
+        d[3] = (unsigned long long)(te - ts2); d[4] = (unsigned long long)(te - ts0); d[5] = (unsigned long long)tStart; d[3] = (unsigned long long)tWst;
+        d[6] = rt_in; d[7] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1517,7 +1545,7 @@ static bool fwd8_plan(const ConvGeom& g, ConvGeom& g8, size_t& lds) {
     for (auto& c : cand) {
         const long long hv = (long long)(c[0] + g.kd - 1) * (c[1] + g.kh - 1) * (c[2] + g.kw - 1);
         if (hv * 8 > 512 * F8_HREG) continue;
-        const size_t l = ((size_t)hv * LDSROW + 2 * (size_t)F8_TG * NT * LDSROW) * sizeof(float) + (F8_MT + (size_t)hv) * sizeof(int);
+        const size_t l = ((size_t)hv * LDSROW + (size_t)F8_NWB * F8_TG * NT * LDSROW) * sizeof(float) + (F8_MT + (size_t)hv) * sizeof(int);
         if (l > 160 * 1024) continue;
         const double tiles = (double)cdiv(g.Do, c[0]) * cdiv(g.Ho, c[1]) * cdiv(g.Wo, c[2]);
         const double cost = tiles * ((double)hv * 0.15 + 256.0 * T);

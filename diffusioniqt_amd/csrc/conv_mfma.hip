@@ -1555,7 +1555,9 @@ static bool fwd8_plan(const ConvGeom& g, ConvGeom& g8, size_t& lds) {
     g8.tilesD = cdiv(g.Do, g8.TD); g8.tilesH = cdiv(g.Ho, g8.TH); g8.tilesW = cdiv(g.Wo, g8.TW);
     g8.HD = g8.TD + g.kd - 1; g8.HH = g8.TH + g.kh - 1; g8.HWd = g8.TW + g.kw - 1;
     const long long nwg8 = (long long)g.B * g8.tilesD * g8.tilesH * g8.tilesW * g.nNt;
-    if (nwg8 < (mode == 2 ? 1 : 512)) return false;              // needs at least two rounds of one workgroup per CU to pay (mode 2: always)
+    // one workgroup per CU: the launch has to fill whole rounds of 256 (128->192 @ 8x16^3 = 384 workgroups = 1.5 rounds ran 26 % slower
+    // than on the 4-wave kernel, whose two workgroups per CU halve the granularity); mode 2: always
+    if (mode != 2 && (nwg8 < 256 || (double)nwg8 / (double)((nwg8 + 255) / 256 * 256) < 0.94)) return false;
     g8.xBytes = (unsigned)xb; g8.yBytes = (unsigned)yb;
     return true;
 }

@@ -1111,6 +1111,13 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
     const int mtBegin = blockIdx.y * bg.tilesPerSplit;
     const int mtEnd = min(mtBegin + bg.tilesPerSplit, bg.MT);
 
+    const float rHWd = 1.f / (float)g.HWd, rHH = 1.f / (float)g.HH;
+    auto small_div = [](int a, int d, float rd) {        // a / d for 0 <= a < 2^16, d >= 1
+        int q = (int)((float)a * rd);
+        const int r = a - q * d;
+        q += (r >= d) - (r < 0);
+        return q;
+    };
     auto fill_tables = [&](int mt0, int slot) {
         int mt = mt0;
         const int tx = mt % g.tilesW; mt /= g.tilesW;
@@ -1120,7 +1127,10 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
         const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
         for (int hv = tid; hv < HV + MTILE; hv += NTHR) {
             if (hv < HV) {
-                const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+                // hv = (hz * HH + hy) * HWd + hx with hv < 2^16: quotients by float reciprocal + one correction step (exact), instead
+                // of four ~40-instruction integer divisions per entry
+                const int row = small_div(hv, g.HWd, rHWd), hx = hv - row * g.HWd;
+                const int hz = small_div(row, g.HH, rHH), hy = row - hz * g.HH;
                 const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
                 xsrc[slot * HV + hv] = (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
                                            ? ((b * g.D + iz) * g.H + iy) * g.W + ix : -1;
@@ -1140,11 +1150,22 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     // all loads are unconditional (clamped address) so hipcc emits them back to back; invalid pieces are zero-selected
     auto issue_loads = [&](int slot) {
+        // ALL table entries first, then the address arithmetic and the loads: written in one loop, hipcc serialises
+        // ds_read -> s_waitcnt lgkmcnt(0) -> address -> global_load per piece (nine LDS round trips: ~3.5k cycles per tile)
+        int sx[NRX], sy[NRY];
 #pragma unroll
         for (int r = 0; r < NRX; ++r) {
             const int idx = tid + NTHR * r;
-            const int hv = (idx < HV * 8) ? (idx >> 3) : 0, c4 = (idx & 7) * 4;
-            const int src = xsrc[slot * HV + hv];
+            sx[r] = xsrc[slot * HV + ((idx < HV * 8) ? (idx >> 3) : 0)];
+        }
+#pragma unroll
+        for (int r = 0; r < NRY; ++r) sy[r] = ysrc[slot * MTILE + (tid + NTHR * r) / (COB / 4)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < NRX; ++r) {
+            const int idx = tid + NTHR * r;
+            const int c4 = (idx & 7) * 4;
+            const int src = sx[r];
             const bool ok = idx < HV * 8 && src >= 0 && ci0 + c4 < g.Cin;
             const size_t off = ok ? (size_t)src * g.Cin + ci0 + c4 : 0;
             float4 v;
@@ -1163,8 +1184,8 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
 #pragma unroll
         for (int r = 0; r < NRY; ++r) {
             const int idx = tid + NTHR * r;                   // idx < 128 * COB / 4 always (NRY = 128*COB/1024)
-            const int v = idx / (COB / 4), c4 = (idx % (COB / 4)) * 4;
-            const int src = ysrc[slot * MTILE + v];
+            const int c4 = (idx % (COB / 4)) * 4;
+            const int src = sy[r];
             const int rem0 = g.Cout - (n0 + c4);
             const bool ok = src >= 0 && rem0 > 0;
             const size_t off = ok ? (size_t)src * g.Cout + n0 + c4 : 0;
@@ -1198,16 +1219,16 @@ __global__ __launch_bounds__(NTHR, NTHR / 256) void conv_bwd_weight2_kernel(cons
         }
     };
 
+    long long tsum[5] = {0, 0, 0, 0, 0};
+    long long tprev = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
+#define DIQT_ACC(i) do { if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tsum[i] += tn - tprev; tprev = tn; } } while (0)
+    const int mTW = g.TW - 1, mTH = g.TH - 1, sTH = bg.lTW, sTD = bg.lTW + bg.lTH;
     if (mtBegin < mtEnd) {
         fill_tables(mtBegin, 0);
         __syncthreads();
         issue_loads(0);
     }
-    long long tsum[5] = {0, 0, 0, 0, 0};
-    long long tprev = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
-#define DIQT_ACC(i) do { if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tsum[i] += tn - tprev; tprev = tn; } } while (0)
     int slot = 0;
-    const int mTW = g.TW - 1, mTH = g.TH - 1, sTH = bg.lTW, sTD = bg.lTW + bg.lTH;
     for (int mt0 = mtBegin; mt0 < mtEnd; ++mt0) {
         const bool haveNext = mt0 + 1 < mtEnd;
         __syncthreads();                 // all MFMA-phase reads of the previous tile are done

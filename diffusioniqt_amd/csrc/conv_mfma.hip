@@ -391,13 +391,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
                                                            const float* __restrict__ bias, const float* __restrict__ residual,
                                                            float* __restrict__ y, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const unsigned long long rt_in = g.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;      // diagnostic: 100 MHz wall clock at entry
     const int HV = g.HD * g.HH * g.HWd;
     float* halo = smem;                                              // [HV][36]
     float* wbuf = smem + (size_t)HV * LDSROW;                        // [F8_NWB][F8_TG][64][36]
     constexpr int WBUF = F8_TG * NT * LDSROW;
-    int* out_off = reinterpret_cast<int*>(wbuf + F8_NWB * WBUF);     // [256]
-    int* halo_src = out_off + F8_MT;                                 // [HV]
+    int* out_off = reinterpret_cast<int*>(wbuf + F8_NWB * WBUF);     // [2][256]   (slot = parity of the workgroup's tile count)
+    int* halo_src = out_off + 2 * F8_MT;                             // [2][HV]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -406,31 +405,43 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
     const int nGroups = (T + F8_TG - 1) / F8_TG;
     const int nSteps = g.nChunks * nGroups;
 
-    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = L % g.nNt;
-    int mt = L / g.nNt;
-    const int tx = mt % g.tilesW; mt /= g.tilesW;
-    const int ty = mt % g.tilesH; mt /= g.tilesH;
-    const int tz = mt % g.tilesD;
-    const int b = mt / g.tilesD;
-    const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
-    const int n0 = nt * NT;
+    // Persistent tile walk: workgroup w (XCD-contiguous numbering) runs the tiles w, w + G, w + 2G, ... (G = gridDim.x; the host makes
+    // G a multiple of nNt, so the 64-channel block n0 of a workgroup never changes).  A tile boundary is handled like a chunk boundary:
+    // the next tile's tables are filled two steps before the end (published by that step's barrier), its first halo chunk is
+    // prefetched into registers during the last step and the weight stream simply continues, so table fill, the first chunk's
+    // memory latency and the workgroup launch are off the MFMA path; what remains between two tiles is the epilogue and one full stop.
+    const unsigned G = gridDim.x;
+    const unsigned totalTiles = (unsigned)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
+    unsigned L = xcd_remap(blockIdx.x, G);
+    if (L >= totalTiles) return;
+    const int nMine = (int)((totalTiles - 1 - L) / G) + 1;
+    const int n0 = (int)(L % g.nNt) * NT;
 
-    if (tid < F8_MT) {
-        const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
-        const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
-        int off = (int)BUF_OOB;
-        if (od < g.Do && oh < g.Ho && ow < g.Wo) off = (((b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout * 4;
-        out_off[tid] = off;
-    }
-    for (int hv = tid; hv < HV; hv += 512) {
-        const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
-        const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
-        int src = (int)BUF_OOB;
-        if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) src = (((b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin * 4;
-        halo_src[hv] = src;
-    }
+    auto fill_tables = [&](unsigned Lt, int slot) {
+        int mt = (int)(Lt / g.nNt);
+        const int tx = mt % g.tilesW; mt /= g.tilesW;
+        const int ty = mt % g.tilesH; mt /= g.tilesH;
+        const int tz = mt % g.tilesD;
+        const int b = mt / g.tilesD;
+        const int d0 = tz * g.TD, h0 = ty * g.TH, w0 = tx * g.TW;
+        if (tid < F8_MT) {
+            const int tw = tid % g.TW, th = (tid / g.TW) % g.TH, td = tid / (g.TW * g.TH);
+            const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+            int off = (int)BUF_OOB;
+            if (od < g.Do && oh < g.Ho && ow < g.Wo) off = (((b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout * 4;
+            out_off[slot * F8_MT + tid] = off;
+        }
+        for (int hv = tid; hv < HV; hv += 512) {
+            const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+            const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
+            int src = (int)BUF_OOB;
+            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) src = (((b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin * 4;
+            halo_src[slot * HV + hv] = src;
+        }
+    };
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
 
     int hidx_lane;
     {
@@ -444,15 +455,17 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
 
     const int hc4 = (tid & 7) * 4;                  // this thread's channel quad inside a chunk (512 % 8 == 0)
     const int nHalo = HV * 8;
+    fill_tables(L, 0);
     __syncthreads();                                // tables visible
 
     u32x4 hr[F8_HREG];
-    auto load_halo = [&](int ci0) {                 // all pieces of a chunk in flight at once; unconditional loads (range-checked descriptor)
+    auto load_halo = [&](int ci0, int slot) {       // all pieces of a chunk in flight at once; unconditional loads (range-checked descriptor)
         const unsigned coff = (ci0 + hc4 < g.Cin) ? (unsigned)(ci0 + hc4) * 4u : BUF_OOB_C;
+        const int* tbl = halo_src + slot * HV;
 #pragma unroll
         for (int u = 0; u < F8_HREG; ++u) {
             const int idx = u * 512 + tid;
-            const unsigned t = (unsigned)halo_src[min(idx >> 3, HV - 1)] + coff;
+            const unsigned t = (unsigned)tbl[min(idx >> 3, HV - 1)] + coff;
             hr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, idx < nHalo ? t : BUF_OOB, 0, 0);
         }
     };
@@ -480,30 +493,69 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
 #pragma unroll
         for (int u = 0; u < F8_WREG; ++u) *reinterpret_cast<u32x4*>(wthread_lds + buf * WBUF + u * (NT * LDSROW)) = wr[u];
     };
+    const int co0 = n0 + l31, co1 = n0 + 32 + l31;
+    const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
+    const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
+    // epilogue of the finished tile: D[row=voxel][col=co]; row = (r&3) + 8*(r>>2) + 4*h
+    auto epilogue = [&](unsigned Lt, int slot) {
+        float cs0 = 0.f, cq0 = 0.f, cs1 = 0.f, cq1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned off = (unsigned)out_off[slot * F8_MT + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+            float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+            if (residual) {        // wave-uniform
+                v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+                v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+            if (g.stats && off != BUF_OOB) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
+            acc0[r] = 0.f; acc1[r] = 0.f;
+        }
+        if (g.stats) {             // block-uniform: fixed-order combine of lane halves, then of the 8 waves through LDS
+            cs0 += __shfl_xor(cs0, 32, 64); cq0 += __shfl_xor(cq0, 32, 64);
+            cs1 += __shfl_xor(cs1, 32, 64); cq1 += __shfl_xor(cq1, 32, 64);
+            float* red = halo;     // the tile's last MFMA operands are in registers and its trailing prefetch reads are never used
+            __syncthreads();       // ... but every wave has to be past them before the image is reused as scratch
+            if (h == 0) {
+                red[(wave * 4 + 0) * 32 + l31] = cs0; red[(wave * 4 + 1) * 32 + l31] = cq0;
+                red[(wave * 4 + 2) * 32 + l31] = cs1; red[(wave * 4 + 3) * 32 + l31] = cq1;
+            }
+            __syncthreads();
+            if (tid < 128) {       // q = tid >> 5: 0 sum(co0) 1 sumsq(co0) 2 sum(co1) 3 sumsq(co1)
+                const int q = tid >> 5, l = tid & 31;
+                float v = red[q * 32 + l];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) v += red[(w * 4 + q) * 32 + l];
+                const int co = n0 + (q >> 1) * 32 + l;
+                const int tpb = g.tilesD * g.tilesH * g.tilesW, mtile = (int)(Lt / g.nNt);
+                if (co < g.Cout) g.stats[(((size_t)(mtile / tpb) * tpb + mtile % tpb) * 2 + (q & 1)) * g.Cout + co] = v;
+            }
+        }
+    };
 
-    // Step protocol (a step = F8_TG taps of one chunk; step st reads weight buffer st % 3):
+    // Step protocol (a step = F8_TG taps of one chunk; step st reads weight buffer st % 3; the stream of steps runs on across tiles):
     //   start of step st : store W(st+1) (registers, loaded during step st-1) into buffer (st+1) % 3 -- its previous content W(st-2)
     //                      was last read in step st-2, and every wave that passed the barrier of step st-1 has finished step st-2;
     //                      then request W(st+2) from global memory into the registers;
     //   before the step's last 8-MFMA group: ONE barrier (the group's operands are already in registers, so nobody restarts cold);
     //                      behind it W(st+1) is visible and the first fragments of step st+1 are prefetched during that last group.
     // So a wave never waits for LDS data at a step boundary, and a wave whose SIMD partner sits in the barrier runs at full rate.
-    // Only a chunk boundary (new halo image) is a full stop: barrier, halo registers -> LDS, barrier, cold fragment reads.
-    const long long ts0 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    long long tTap = 0, tSync = 0, tq = 0, tStart = 0, tWst = 0;
-    load_halo(0);
+    // Only a chunk (or tile) boundary -- a new halo image -- is a full stop: barrier, halo registers -> LDS, barrier, cold reads.
+    load_halo(0, 0);
     load_wstep(0, 0);
     store_halo();
     store_wstep(0);
-    // (chunk, group) of the steps st, st+1 (sc1, sg1) and st+2 (sc2, sg2), and the weight buffers of st / st+1 (rotating 0, 1, 2)
-    int chunk = 0, grp = 0, sc1 = 0, sg1 = 1, sc2, sg2;
-    if (sg1 == nGroups) { sg1 = 0; sc1 = 1; }
-    sc2 = sc1; sg2 = sg1 + 1;
-    if (sg2 == nGroups) { sg2 = 0; sc2 = sc1 + 1; }
-    int bufNext = 1;
-    if (nSteps > 1) load_wstep(sc1, sg1);
+    int remaining = nMine * nSteps;                               // steps left in this workgroup's stream, the current one included
+    int chunk = 0, grp = 0, sc1 = 0, sg1 = 0, sc2, sg2;           // (chunk, group) of the steps st, st+1, st+2 (wrapping from tile to tile)
+    auto advance = [&](int& c, int& gq) { if (++gq == nGroups) { gq = 0; if (++c == g.nChunks) c = 0; } };
+    advance(sc1, sg1);
+    sc2 = sc1; sg2 = sg1;
+    advance(sc2, sg2);
+    int bufNext = 1, slot = 0, stepInTile = 0;
+    if (remaining > 1) load_wstep(sc1, sg1);
     __syncthreads();
-    const long long ts1 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
 
     int kx = 0, ky = 0, trow = 0;                                 // tap (kz, ky, kx) of the NEXT tap to run and its halo row offset
     const float* ap = halo + hidx_lane * LDSROW + 4 * h;
@@ -512,16 +564,14 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
     float4 b0 = *reinterpret_cast<const float4*>(bp);
     float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
     __builtin_amdgcn_s_waitcnt(0xc07f);                           // lgkmcnt(0)
-    for (int st = 0; st < nSteps; ++st) {
+    for (; remaining > 0; --remaining) {
         const int t0 = grp * F8_TG, nTap = min(F8_TG, T - t0);
-        const bool lastOfChunk = grp + 1 == nGroups, more = st + 1 < nSteps;
-        const long long tb = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
+        const bool lastOfChunk = grp + 1 == nGroups, lastOfTile = lastOfChunk && chunk + 1 == g.nChunks, more = remaining > 1;
         if (more) store_wstep(bufNext);
-        if (g.dbg) tWst += (long long)__builtin_readcyclecounter() - tb;
-        if (st + 2 < nSteps) load_wstep(sc2, sg2);
+        if (remaining > 2) load_wstep(sc2, sg2);
+        if (stepInTile == nSteps - 2 && remaining > 2) fill_tables(L + G, slot ^ 1);      // published by this step's barrier
         const bool nextHalo = lastOfChunk && more;
-        if (nextHalo) load_halo((chunk + 1) * CK);
-        if (g.dbg) { tq = (long long)__builtin_readcyclecounter(); tStart += tq - tb; }
+        if (nextHalo) load_halo(lastOfTile ? 0 : (chunk + 1) * CK, lastOfTile ? slot ^ 1 : slot);
         for (int t = 0; t < nTap; ++t) {
             // halo row offset of the tap after this one (wave-uniform counters; wraps to tap 0 at the end of a chunk)
             int ntrow = trow + 1, nkx = kx + 1, nky = ky;
@@ -541,11 +591,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
                     b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
                     b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
                 } else {
-                    if (lastTap) {                       // wave-uniform: the step's barrier, operands of this group already in registers
-                        if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tTap += tn - tq; tq = tn; }
-                        __syncthreads();
-                        if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tSync += tn - tq; tq = tn; }
-                    }
+                    if (lastTap) __syncthreads();        // wave-uniform: the step's barrier, operands of this group already in registers
                     // unconditional prefetch of the next tap's / next step's first fragments (stale but harmless at a chunk boundary
                     // and after the last step: the values are reloaded or never used)
                     an = *reinterpret_cast<const float4*>(apn);
@@ -567,69 +613,20 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
             ap = apn; bp = bpn;
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the prefetch was requested eight MFMAs ago
         }
-        if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tTap += tn - tq; tq = tn; }
+        if (lastOfTile) epilogue(L, slot);
         if (nextHalo) {
-            __syncthreads();                             // every wave is done with this chunk's halo image
+            __syncthreads();                             // every wave is done with this chunk's halo image (and the epilogue's scratch)
             store_halo();
             __syncthreads();
             a = *reinterpret_cast<const float4*>(ap);    // cold reads from the new image (ap / bp already point at the next step)
             b0 = *reinterpret_cast<const float4*>(bp);
             b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
             __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (g.dbg) { const long long tn = (long long)__builtin_readcyclecounter(); tSync += tn - tq; tq = tn; }
         }
+        if (lastOfTile) { L += G; slot ^= 1; stepInTile = 0; } else ++stepInTile;
         chunk = sc1; grp = sg1; sc1 = sc2; sg1 = sg2;
-        if (++sg2 == nGroups) { sg2 = 0; ++sc2; }
+        advance(sc2, sg2);
         bufNext = bufNext + 1 == F8_NWB ? 0 : bufNext + 1;
-    }
-    const int step = nSteps;
-    const long long ts2 = g.dbg ? (long long)__builtin_readcyclecounter() : 0;
-
-    // ---- epilogue: D[row=voxel][col=co]; row = (r&3) + 8*(r>>2) + 4*h ----
-    const int co0 = n0 + l31, co1 = n0 + 32 + l31;
-    const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
-    const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
-    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
-    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
-    float cs0 = 0.f, cq0 = 0.f, cs1 = 0.f, cq1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const unsigned off = (unsigned)out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-        float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-        if (residual) {        // wave-uniform
-            v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
-            v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
-        }
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
-        if (g.stats && off != BUF_OOB) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
-    }
-    if (g.stats) {             // block-uniform: fixed-order combine of lane halves, then of the 8 waves through LDS
-        cs0 += __shfl_xor(cs0, 32, 64); cq0 += __shfl_xor(cq0, 32, 64);
-        cs1 += __shfl_xor(cs1, 32, 64); cq1 += __shfl_xor(cq1, 32, 64);
-        float* red = halo;     // every wave passed the last barrier: the halo image is dead
-        if (h == 0) {
-            red[(wave * 4 + 0) * 32 + l31] = cs0; red[(wave * 4 + 1) * 32 + l31] = cq0;
-            red[(wave * 4 + 2) * 32 + l31] = cs1; red[(wave * 4 + 3) * 32 + l31] = cq1;
-        }
-        __syncthreads();
-        if (tid < 128) {       // q = tid >> 5: 0 sum(co0) 1 sumsq(co0) 2 sum(co1) 3 sumsq(co1)
-            const int q = tid >> 5, l = tid & 31;
-            float v = red[q * 32 + l];
-#pragma unroll
-            for (int w = 1; w < 8; ++w) v += red[(w * 4 + q) * 32 + l];
-            const int co = n0 + (q >> 1) * 32 + l;
-            const int tpb = g.tilesD * g.tilesH * g.tilesW, tIn = (tz * g.tilesH + ty) * g.tilesW + tx;
-            if (co < g.Cout) g.stats[(((size_t)b * tpb + tIn) * 2 + (q & 1)) * g.Cout + co] = v;
-        }
-    }
-    if (g.dbg && tid == 0) {     // diagnostic (DIQT_CONV_DBG=1): [prologue, tap loops, store + barriers, epilogue, lifetime, steps]
-        unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
-        const long long te = (long long)__builtin_readcyclecounter();
-        d[0] = (unsigned long long)(ts1 - ts0); d[1] = (unsigned long long)tTap; d[2] = (unsigned long long)tSync;
-        d[3] = (unsigned long long)(te - ts2); d[4] = (unsigned long long)(te - ts0); d[5] = (unsigned long long)tStart; d[3] = (unsigned long long)tWst;
-        d[6] = rt_in; d[7] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1566,7 +1563,7 @@ static bool fwd8_plan(const ConvGeom& g, ConvGeom& g8, size_t& lds) {
     for (auto& c : cand) {
         const long long hv = (long long)(c[0] + g.kd - 1) * (c[1] + g.kh - 1) * (c[2] + g.kw - 1);
         if (hv * 8 > 512 * F8_HREG) continue;
-        const size_t l = ((size_t)hv * LDSROW + (size_t)F8_NWB * F8_TG * NT * LDSROW) * sizeof(float) + (F8_MT + (size_t)hv) * sizeof(int);
+        const size_t l = ((size_t)hv * LDSROW + (size_t)F8_NWB * F8_TG * NT * LDSROW) * sizeof(float) + 2 * (F8_MT + (size_t)hv) * sizeof(int);
         if (l > 160 * 1024) continue;
         const double tiles = (double)cdiv(g.Do, c[0]) * cdiv(g.Ho, c[1]) * cdiv(g.Wo, c[2]);
         const double cost = tiles * ((double)hv * 0.15 + 256.0 * T);
@@ -1754,16 +1751,15 @@ static int conv3d_fwd_one(const float* x, const float* packed, const float* bias
         if (fwd8_plan(g, g8, lds8)) {
             g8.stats = stats;
             g8.dbg = nullptr;
-            if (dbg_on) {
-                const long long n8 = (long long)g8.B * g8.tilesD * g8.tilesH * g8.tilesW * g8.nNt;
-                if (n8 <= 65536) { g8.dbg = dbg_buf; g_dbg_ptr = dbg_buf; g_dbg_n = (unsigned)n8; }
-            }
             if (lds8 > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
                 DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
             }
             const unsigned nwg8 = (unsigned)((long long)g8.B * g8.tilesD * g8.tilesH * g8.tilesW * g8.nNt);
-            hipLaunchKernelGGL(conv_fwd8_kernel, dim3(nwg8), dim3(512), lds8, (hipStream_t)stream, x, packed, bias, residual, y, g8);
+            // persistent tile walk: one workgroup per CU runs all its tiles (needs a 64-channel block that stays with the workgroup)
+            static const bool nopersist = [] { const char* e = getenv("DIQT_CONV_W8_NOPERSIST"); return e && e[0] == '1'; }();
+            const unsigned grid8 = (!nopersist && nwg8 > 256u && 256 % g8.nNt == 0) ? 256u : nwg8;
+            hipLaunchKernelGGL(conv_fwd8_kernel, dim3(grid8), dim3(512), lds8, (hipStream_t)stream, x, packed, bias, residual, y, g8);
             return check_launch("conv3d_fwd(8 waves)");
         }
     }

@@ -1601,6 +1601,25 @@ extern "C" int diqt_conv3d_fwd_stats_blocks(int B, int D, int H, int W, int Cin,
     return g.tilesD * g.tilesH * g.tilesW;
 }
 
+// which kernel diqt_conv3d_fwd* dispatches this shape to (for profilers / bench.py, so that per-kernel numbers carry the names
+// rocprofv3 reports): 0 conv_fwd_kernel, 1 conv_fwd_smallcin_kernel, 2 conv1x1_fwd_kernel, 3 conv_fwd8_kernel, -1 bad shape
+extern "C" int diqt_conv3d_fwd_kernel_id(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                         int epd, int eph, int epw) {
+    ConvGeom g;
+    if (make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return -1;
+    const int T = kd * kh * kw;
+    if (smallcin_pad(Cin, T)) return 1;
+    const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
+    const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
+    const bool buf = Cin % 4 == 0 && xb < (1ull << 30) && yb < (1ull << 30);
+    if (!buf || fwd_ksplit(g) > 1) return 0;
+    ConvGeom g8;
+    size_t lds8;
+    if (fwd8_plan(g, g8, lds8)) return 3;
+    if (T == 1 && g.B == 1 && g.D == 1 && g.H == 1 && g.Wo == g.W && g.TW == MTILE) return 2;
+    return 0;
+}
+
 extern "C" int diqt_conv3d_fwd_ex(const float* x, const float* packed, const float* bias, const float* residual, float* y,
                                   float* stats, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin,
                                   int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {

@@ -228,12 +228,8 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0), stat
         e.record()
         # the tag names the kernel the C side dispatches to, so that bench.py's per-kernel numbers line up with rocprofv3's
         taps = kd * kh * kw
-        if taps > 1 and Cin <= 4:
-            tag = "conv_fwd_smallcin_kernel"
-        elif taps == 1 and not any(pad) and not any(epad) and n == 0 and Cin % 4 == 0:
-            tag = "conv1x1_fwd_kernel"
-        else:
-            tag = "conv_fwd_kernel"
+        kid = _lib.query("diqt_conv3d_fwd_kernel_id", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
+        tag = ("conv_fwd_kernel", "conv_fwd_smallcin_kernel", "conv1x1_fwd_kernel", "conv_fwd8_kernel")[kid if kid > 0 and n == 0 else 0]
         TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * taps, tag, (B, D, H, W, Cin, Cout, kd, kh, kw)))
     return y
 

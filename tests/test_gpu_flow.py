@@ -61,3 +61,36 @@ def test_train_and_inference_flow(tmp_path):
     # EMA weights (initialised by copy at the first update) are what sample() used; non-EMA path also runs
     out2 = trainer.sample(batch_size=2, start_image_or_video=lr, start_at_unet_number=2, use_non_ema=True)
     assert torch.isfinite(out2[0]).all()
+
+
+@pytest.mark.parametrize("precision", ["no", "bf16"])
+def test_training_converges_on_a_synthetic_relation(precision):
+    """End to end through ImagenTrainer on the HIP path (loss, backward, gradient accumulation 2, fused Adam, EMA): a dim-32 U-Net on
+    16^3 patches learns HR = LR + a fixed smooth field; the x_start loss must fall at least 4x within 80 optimiser steps and stay finite,
+    in fp32 and with the mixed-precision switch (tools/train_sanity.py runs the longer version: 0.218 -> 0.003 in 300 steps)."""
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256, Imagen, NullUnet
+    from diffusioniqt_amd.trainer import ImagenTrainer
+    S, B, steps = 16, 8, 80
+    g = torch.Generator().manual_seed(0)
+    zz, yy, xx = torch.meshgrid(*[torch.linspace(-1, 1, S)] * 3, indexing="ij")
+    field = (0.5 * torch.sin(3 * xx) * torch.cos(2 * yy) + 0.3 * zz)[None, None]
+    torch.manual_seed(1)
+    unet = SRUnet256(img_size=S, dim=32, dim_mults=(1, 2, 4), channels=1, num_resnet_blocks=(2, 2, 2), init_conv_kernel_size=3,
+                     lowres_cond=True, init_cross_embed=False, att_type='linear', attend_at_middle=False, attend_at_enc=[False] * 3,
+                     attend_at_enc_depth=[1] * 3, attend_at_enc_heads=[8] * 3, init_dim=32, memory_efficient=False, use_se_attn='True,',
+                     pixel_shuffle_upsample=True, boundary=False, batch_sample=False, batch_sample_factor=3, deep_feature=False)
+    configs = {'Data': {'norm': 'z-score'}, 'Train': {'batch_sample': False, 'patch_size_sub': S, 'pred_obj': 'x_start'}, 'Eval': {'repeat': 1}}
+    imagen = Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=-10.0, image_sizes=(S, S), channels=1, pred_objectives='x_start',
+                    timesteps=16, dynamic_thresholding=False, p2_loss_weight_gamma=0.0, cond_drop_prob=0.0).to('cuda')
+    ImagenTrainer.locked = False
+    trainer = ImagenTrainer(configs=configs, imagen=imagen, gradient_accumulation_steps=2, lr=3e-4, verbose=False,
+                            **({} if precision == "no" else {"precision": precision}))
+    losses = []
+    for _ in range(steps * 2):
+        lr = torch.randn(B, 1, S, S, S, generator=g) * 0.5
+        out = trainer((lr + field).to('cuda'), lowres_img=lr.to('cuda'), unet_number=2, max_batch_size=B)
+        trainer.update(unet_number=2)
+        losses.append(float(out[0]) if isinstance(out, tuple) else float(out))
+    assert all(np.isfinite(losses))
+    first, last = np.mean(losses[:10]), np.mean(losses[-10:])
+    assert last < 0.25 * first, (first, last)

@@ -380,6 +380,30 @@ def test_bgemm_large_tiles_all_layouts(ops, g_, M, N, K):
     close(Bd.grad, Br.grad, tol=1e-4, what="bgemm dB")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,expect", [(2, 40, 128, 3), (4, 24, 128, 3), (8, 64, 64, 3), (1, 32, 64, 0)])
+def test_conv3d_on_the_8_wave_kernel_ragged_tiles_and_persistent_walk(ops, B, Cin, Cout, expect):
+    """conv_fwd8_kernel (256-voxel tiles, 512 threads): ragged tile edges in all three axes (15 x 30 x 31), a ragged K-chunk, two Cout
+    blocks, exactly one round of workgroups (B = 2: 256) and the persistent tile walk (B = 4, 8: 512 tiles on 256 workgroups), with
+    bias, residual and the epilogue's per-tile column sums -- against float64 on the CPU.  The last case stays on conv_fwd_kernel."""
+    from diffusioniqt_amd import _lib
+    D, H, W = 15, 30, 31
+    assert _lib.query("diqt_conv3d_fwd_kernel_id", B, D, H, W, Cin, Cout, 3, 3, 3, 1, 1, 1, 0, 0, 0) == expect
+    gen = torch.Generator().manual_seed(B * 7 + Cin)
+    x = torch.randn(B, Cin, D, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) * 0.05
+    bias = torch.randn(Cout, generator=gen)
+    res = torch.randn(B, Cout, D, H, W, generator=gen)
+    ref = F.conv3d(x.double(), w.double(), bias.double(), padding=1) + res.double()
+    with torch.no_grad():
+        y = ops.conv3d(cl(x), w.to(DEV), bias.to(DEV), (1, 1, 1), residual=cl(res), want_stats=True)
+    close(cf(y), ref, what="conv on the 8-wave kernel")
+    st = getattr(y, "_diqt_stats", None)
+    assert st is not None
+    sums = st.partials.double().sum(dim=1).cpu()                                       # [B, 2, Cout]
+    close(sums[:, 0], ref.sum(dim=(2, 3, 4)), tol=1e-5, what="epilogue column sums")
+    close(sums[:, 1], (ref ** 2).sum(dim=(2, 3, 4)), tol=1e-5, what="epilogue column sums of squares")
+
+
 def test_gate_residual_emits_groupnorm_statistics(ops):
     """se_gate_residual attaches per-workgroup column sums of its OUTPUT; the next GroupNorm finalises its statistics from them
     (no pass over the tensor) and must produce what it produces from a statistics pass over the same tensor."""

@@ -1,24 +1,33 @@
 #!/bin/bash
 # Builds libdiqt_hip.so (gfx950) next to this script.  hipcc cross-compiles without a GPU.
+#   build.sh           recompiles a translation unit when the SHA-256 of (its source, common.h, include/diqt.h, the flags)
+#                      differs from the stamp written beside its object file (no reliance on mtimes)
+#   build.sh --force   deletes every object / stamp / library first: a provably clean build (what __graft_entry__.build() runs)
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-result"
+if [ "$1" = "--force" ]; then
+  rm -f *.o *.stamp libdiqt_hip.so
+fi
+stamp_of() { cat "$1" common.h ../../include/diqt.h | cat - <(echo "$FLAGS $HIPCC") | sha256sum | cut -d' ' -f1; }
 OBJS=""
 PIDS=""
-for f in conv_mfma conv_half elementwise bgemm conv_direct attention datapath; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/diqt.h -nt $f.o ]; then
-    rm -f $f.o
-    $HIPCC $FLAGS -c $f.hip -o $f.o &
+BUILT=""
+for f in conv_mfma conv_half elementwise bgemm conv_direct attention datapath lib; do
+  src=$f.hip; xflag=""
+  if [ $f = lib ]; then src=lib.cpp; xflag="-x hip"; fi
+  want=$(stamp_of $src)
+  if [ ! -f $f.o ] || [ ! -f $f.stamp ] || [ "$(cat $f.stamp)" != "$want" ]; then
+    rm -f $f.o $f.stamp
+    ( $HIPCC $FLAGS $xflag -c $src -o $f.o && echo "$want" > $f.stamp ) &
     PIDS="$PIDS $!"
+    BUILT="$BUILT $f"
   fi
   OBJS="$OBJS $f.o"
 done
-if [ ! -f lib.o ] || [ lib.cpp -nt lib.o ] || [ common.h -nt lib.o ]; then
-  rm -f lib.o
-  $HIPCC $FLAGS -x hip -c lib.cpp -o lib.o &
-  PIDS="$PIDS $!"
-fi
 for p in $PIDS; do wait $p || { echo "build FAILED"; exit 1; }; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libdiqt_hip.so $OBJS lib.o
-echo "built $(pwd)/libdiqt_hip.so"
+if [ -n "$BUILT" ] || [ ! -f libdiqt_hip.so ]; then
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o libdiqt_hip.so $OBJS
+fi
+echo "built $(pwd)/libdiqt_hip.so (compiled:${BUILT:- nothing, all stamps current})"

@@ -164,6 +164,48 @@ class supervisedIQT(Dataset):
         return hr[0], lr[0]
 
 
+class supervisedIQT_INF(Dataset):
+    """Mirror of data.py:139-202 — the sliding-window patch Dataset the reference's test scripts iterate
+    (``DataLoader(supervisedIQT_INF(configs, lr_file), batch_size, shuffle=False, collate_fn=my_collate)``, test_all.py:189-190).
+
+    Same constructor ``(config, lr_file)``, candidate order (i outermost, stride ``Eval.overlap``, data.py:157-160), 5 %
+    non-zero rejection (``None`` items, dropped by ``my_collate``) and ``[lr[1,P,P,P], tensor([i,j,k])]`` item contract; items
+    are host tensors like the reference's.  ``lr_file`` is a NIfTI / ``.npy`` path or an already decoded array (cropped to
+    ``[0:256]^3`` like data.py:155).  ``VolumeInference`` is the device-resident pipeline over the same candidates; this class
+    exists so the scripts' own loops run unchanged."""
+
+    def __init__(self, config, lr_file):
+        self.lr_file, self.config = lr_file, config
+        self.mean_lr, self.std_lr = config['Data']['mean'], config['Data']['std']
+        tr = config['Train']
+        self.patch_size = tr['patch_size_sub'] * tr['batch_sample_factor'] if tr['batch_sample'] else tr['patch_size_sub']
+        self.overlap = config['Eval']['overlap']
+        self.ratio = 0.05
+        self.total_voxel = self.patch_size ** 3
+        vol = load_volume(lr_file) if isinstance(lr_file, (str, bytes)) or hasattr(lr_file, '__fspath__') \
+            else (lr_file.detach().cpu().numpy() if torch.is_tensor(lr_file) else np.asarray(lr_file))
+        self.lr_data = vol[0:256, 0:256, 0:256]
+        P, n = self.patch_size, self.lr_data.shape
+        self.lr_idx = [[i, j, k] for i in range(0, n[0] - P + 1, self.overlap) for j in range(0, n[1] - P + 1, self.overlap)
+                       for k in range(0, n[2] - P + 1, self.overlap)]
+
+    def __len__(self):
+        return len(self.lr_idx)
+
+    def normalize(self, img):
+        return (torch.as_tensor(img, dtype=torch.float32) - self.mean_lr) / self.std_lr
+
+    def __getitem__(self, idx):
+        i, j, k = self.lr_idx[idx]
+        P = self.patch_size
+        self.lr = torch.tensor(np.asarray(self.lr_data[i:i + P, j:j + P, k:k + P]).astype(np.float32))
+        self.img_shape = self.lr.shape
+        if np.count_nonzero(self.lr) / self.total_voxel < self.ratio:
+            return None
+        self.lr = self.normalize(self.lr)
+        return [torch.unsqueeze(self.lr, 0), torch.tensor(self.lr_idx[idx])]
+
+
 class DevicePatchLoader:
     """``DataLoader(dataset, batch_size, shuffle, drop_last)`` (train.py:56,67) over a ``supervisedIQT``: same index order —
     including the two draws a DataLoader epoch takes from torch's default generator — one crop launch per batch."""

@@ -150,6 +150,7 @@ class BucketedGradReducer:
                 cur, cur_hi, cap = [], arena.offsets[i], int(bucket_cap_mb * (1 << 18))
         self.bucket_of = {i: b for b, (_, _, idx) in enumerate(self.buckets) for i in idx}
         self._launched = set()
+        self.stragglers_seen = 0
         for i, p in enumerate(arena.params):
             if p.requires_grad:
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -171,9 +172,14 @@ class BucketedGradReducer:
                 self._launch(b)
         return hook
 
-    def _launch(self, b):
+    def _launch(self, b, only=None):
         lo, hi, idx = self.buckets[b]
-        self.arena.collect(idx)                 # this micro-step's gradients of the bucket join the accumulated ones
+        # this micro-step's gradients of the bucket join the accumulated ones.  Parameters outside the learned ``used`` set keep
+        # ``p.grad = None``: should one of them receive a gradient after all (a straggler), autograd hands over a fresh tensor
+        # instead of adding in place into a range RCCL is reducing, and finalize_backward() reduces the bucket once more.
+        if only is None:
+            only = idx if self.used is None else [j for j in idx if j in self.used]
+        self.arena.collect(only)
         buf = self.arena.grad[lo:hi]
         if buf.is_cuda:
             h = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
@@ -193,12 +199,25 @@ class BucketedGradReducer:
         for b in range(len(self.buckets)):
             if b not in self._launched:
                 self._launch(b)
+        self._wait()
+        if self.used is None:
+            self.used = set(self._seen)
+        stragglers = sorted(self._seen - self.used)
+        if stragglers:
+            # a parameter outside the learned set received a gradient (the graph changed): its contribution arrived after the
+            # bucket's collective.  The bucket holds avg(A) on every rank; adding the local late gradients s_r and averaging
+            # again gives avg(A) + avg(s) -- exactly what one collective over everything would have produced.
+            self.stragglers_seen += len(stragglers)
+            for b in sorted({self.bucket_of[i] for i in stragglers}):
+                self._launch(b, only=[i for i in stragglers if self.bucket_of[i] == b])
+            self._wait()
+            self.used |= set(stragglers)
+
+    def _wait(self):
         for h, buf in self._handles:
             h.wait()
             if not buf.is_cuda:
                 buf.div_(self.world)
-        if self.used is None:
-            self.used = set(self._seen)
         self._handles = []
 
 
@@ -208,11 +227,41 @@ def broadcast_arena(arena: FlatArena, src=0, process_group=None):
         dist.broadcast(arena.flat, src=src, group=process_group)
 
 
-def shard_batch(t, world, rank_):
-    """``split_batches=True`` (trainer.py:297): every rank takes its contiguous 1/world slice of a global batch."""
+def broadcast_tensors(tensors, src=0, process_group=None):
+    """In-place broadcast of each tensor from ``src`` (optimiser moments, step counters on resume)."""
+    if world_size() > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src, group=process_group)
+
+
+def broadcast_ints(values, device, src=0, process_group=None):
+    """Host integers from ``src`` to every rank; returns the list every rank agrees on."""
+    if world_size() == 1:
+        return [int(v) for v in values]
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=src, group=process_group)
+    return [int(v) for v in t.tolist()]
+
+
+def shard_batch(t, world, rank_, full=None, initial=None):
+    """``split_batches=True`` (trainer.py:297): every rank takes its contiguous 1/world slice of a global batch.
+
+    The reference's loaders keep the last partial batch of an epoch (``drop_last=False``, train.py:56/67).  accelerate's
+    ``BatchSamplerShard`` (``split_batches=True``, ``even_batches=True``) completes such a batch to the full batch size with
+    samples of the epoch's FIRST batch (cycled if that is short too) before slicing it, so every rank still gets
+    ``full / world`` samples and joins every collective.  ``full`` = the loader's batch size, ``initial`` = the first batch
+    of the pass; without them the batch is completed to the next multiple of ``world`` from its own head."""
     if world == 1 or not torch.is_tensor(t):
         return t
     b = t.shape[0]
-    assert b % world == 0, f"global batch {b} is not divisible by world size {world}"
-    per = b // world
+    target = full if (full is not None and full % world == 0 and b < full) else -(-b // world) * world
+    if b != target:
+        src = initial if (torch.is_tensor(initial) and initial.shape[0] > 0) else t
+        pieces, have = [t], b
+        while have < target:
+            take = min(src.shape[0], target - have)
+            pieces.append(src[:take].to(t.device))
+            have += take
+        t = torch.cat(pieces, dim=0)
+    per = target // world
     return t[rank_ * per:(rank_ + 1) * per]

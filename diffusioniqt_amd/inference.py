@@ -81,6 +81,9 @@ class VolumeInference:
         # overlapping blocks are written one launch at a time in candidate order (later blocks overwrite, as in the script);
         # non-overlapping patches go out in one launch per batch
         per_call = 1 if self.block_mode else self.batch
+        # cropped interiors (width P - 2*(overlap//2), stride overlap) of neighbouring windows still overlap when the stride is
+        # below half a patch: one scatter launch per patch, in candidate order, keeps "later overwrites" deterministic
+        serial_scatter = (not self.block_mode) and self.overlap < P and P - 2 * (self.overlap // 2) > self.overlap
         for lo in range(0, kept.shape[0], per_call):
             o = np.ascontiguousarray(kept[lo:lo + per_call])
             idx = torch.from_numpy(o).to(dev)
@@ -91,8 +94,13 @@ class VolumeInference:
                 y = merge_sub_volumes(y.float(), original_shape=(1, 1, P, P, P))
             else:
                 y = self.sample_fn(x)
-            ops.patch_scatter(y.float().contiguous(), idx, torch.from_numpy(np.ascontiguousarray(margins[lo:lo + per_call])).to(dev),
-                              pred, P)
+            y = y.float().contiguous()
+            mg = torch.from_numpy(np.ascontiguousarray(margins[lo:lo + per_call])).to(dev)
+            if serial_scatter:
+                for j in range(o.shape[0]):
+                    ops.patch_scatter(y[j:j + 1], idx[j:j + 1], mg[j:j + 1], pred, P)
+            else:
+                ops.patch_scatter(y, idx, mg, pred, P)
         min_raw = float(ops.min_value(vol).item())
         min_val = (np.float32(min_raw) - mean32) / std32                                  # monotone map: min of the normalised volume
         ops.background_reset(pred, vol, self.mean, self.std, float(min_val))             # test_all.py:300

@@ -274,12 +274,16 @@ class EMA(nn.Module):
         if (step % self.update_every) != 0:
             return
         ema_flat, online_flat = self._flat()
-        if step <= self.update_after_step or not self.initted.item():
+        # ema_pytorch 0.1.4 control flow: warm-up copies leave ``initted`` untouched; the first update past the warm-up
+        # copies the online weights, sets ``initted`` and then lerps (a no-op on identical weights), later ones only lerp
+        if step <= self.update_after_step:
             ema_flat.copy_(online_flat)                      # plain copy (no arithmetic)
             ops.bump_weight_epoch()
+            return
+        if not self.initted.item():
+            ema_flat.copy_(online_flat)
+            ops.bump_weight_epoch()
             self.initted.data.copy_(torch.tensor([True]))
-            if step <= self.update_after_step:
-                return
         ops.ema_lerp(ema_flat, online_flat, 1. - self.get_current_decay())     # HIP kernel; raises on CPU tensors
 
     def forward(self, *args, **kwargs):
@@ -427,6 +431,12 @@ class ImagenTrainer(nn.Module):
         unet._diqt_arena = arena
         optimizer.attach(arena)
         D.broadcast_arena(arena)                         # rank-0 weights to every replica (trainer.py:487)
+        if self.is_distributed:
+            # only rank 0 reads the checkpoint folder (can_checkpoint): a resumed run must hand its Adam moments, bias-correction
+            # step, ``steps`` and the accumulation phase to every replica too, or they step differently from the first update on
+            # and hit the checkpoint barrier on different micro-steps
+            D.broadcast_tensors([optimizer.exp_avg, optimizer.exp_avg_sq, self.steps])
+            optimizer.step_count, self._micro_step = D.broadcast_ints([optimizer.step_count, self._micro_step], arena.flat.device)
         reducer = D.BucketedGradReducer(arena) if self.is_distributed else None
         self._arena = arena
         self.unet_being_trained = _ReplicaUnet(unet, reducer)
@@ -529,12 +539,16 @@ class ImagenTrainer(nn.Module):
         else:
             self.repeat = self.configs['Eval']['repeat']
             preds, condi1, condi2, hrs, ssims, psnrs = [], [], [], [], [], []
+        full_bs = getattr(dl_iter, 'batch_size', None)
         for r in range(self.repeat):
+            first = None
             for i, data in enumerate(dl_iter):
                 hr_data, lr_data = data[0], data[1]
                 if self.split_batches and self.is_distributed and not self.configs['Train']['batch_sample']:
-                    hr_data = D.shard_batch(hr_data, self.world_size, self.rank)
-                    lr_data = D.shard_batch(lr_data, self.world_size, self.rank)
+                    if first is None:
+                        first = (hr_data, lr_data)           # completes a short last batch (drop_last=False), see D.shard_batch
+                    hr_data = D.shard_batch(hr_data, self.world_size, self.rank, full=full_bs, initial=first[0])
+                    lr_data = D.shard_batch(lr_data, self.world_size, self.rank, full=full_bs, initial=first[1])
                 if self.configs['Train']['batch_sample']:
                     new_batch = (hr_data.shape[-1] // self.configs['Train']['patch_size_sub']) ** 3
                     c, h = hr_data.shape[1], self.configs['Train']['patch_size_sub']

@@ -139,3 +139,131 @@ def test_trainer_data_parallel_world2_matches_single_process_reference_trace():
     [p.join(60) for p in procs]
     for r in results:
         assert r[1] and r[2], r
+
+
+def test_shard_batch_completes_a_short_last_batch_like_accelerate_even_batches():
+    """drop_last=False loaders (train.py:56/67) end an epoch on a short batch: it is completed to the full batch size from the
+    epoch's first batch (accelerate BatchSamplerShard, split_batches + even_batches), never asserted on."""
+    from diffusioniqt_amd.distributed import shard_batch
+    first = torch.arange(8.).view(8, 1)
+    last = torch.arange(100., 103.).view(3, 1)                    # 3 of 8 samples left
+    got = [shard_batch(last, 4, r, full=8, initial=first).flatten().tolist() for r in range(4)]
+    assert got == [[100., 101.], [102., 0.], [1., 2.], [3., 4.]]
+    assert [shard_batch(first, 4, r, full=8, initial=first).flatten().tolist() for r in range(4)] == \
+        [[0., 1.], [2., 3.], [4., 5.], [6., 7.]]
+    # degenerate: the first batch is short too -> cycled
+    tiny = torch.tensor([[7.], [8.]])
+    got = torch.cat([shard_batch(tiny[:1], 4, r, full=4, initial=tiny) for r in range(4)]).flatten().tolist()
+    assert got == [7., 7., 8., 7.]
+    # no loader batch size known: next multiple of world, from the batch's own head
+    assert shard_batch(last, 2, 1).flatten().tolist() == [102., 100.]
+    assert shard_batch(last, 1, 0) is last
+
+
+def _straggler_worker(rank, world, port, out):
+    _setup(rank, world, port)
+    from diffusioniqt_amd import distributed as D
+    D.init_from_env(device_type="cpu")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.Tanh(), torch.nn.Linear(300, 5))
+    late = torch.nn.Linear(5, 5)                         # joins the graph only from iteration 1 on
+    params = list(net.parameters()) + list(late.parameters())
+    arena = D.FlatArena(params)
+    D.broadcast_arena(arena)
+    red = D.BucketedGradReducer(arena, bucket_cap_mb=0.02, first_bucket_mb=0.0001)
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(3, 8, 40, generator=g)
+    per = 8 // world
+    full = [p.detach().clone().requires_grad_() for p in params]
+    ok = []
+    for it in range(3):
+        red.prepare_backward(sync=True)
+        arena.begin_backward()
+        xs = X[it, rank * per:(rank + 1) * per]
+        y = net(xs)
+        if it >= 1:
+            y = late(y)
+        y.pow(2).mean().backward()
+        red.finalize_backward()
+        arena.collect()
+        h = torch.nn.functional.linear(torch.tanh(torch.nn.functional.linear(X[it], full[0], full[1])), full[2], full[3])
+        if it >= 1:
+            h = torch.nn.functional.linear(h, full[4], full[5])
+        gs = torch.autograd.grad(h.pow(2).mean(), full if it >= 1 else full[:4])
+        ref = torch.zeros_like(arena.grad)
+        for gq, o, p in zip(gs, arena.offsets, params):
+            ref[o:o + p.numel()] = gq.reshape(-1)
+        ok.append(bool(torch.allclose(arena.grad, ref, atol=1e-6)))
+        arena.grad.zero_()
+    out.put((rank, ok, red.stragglers_seen, sorted(red.used)))
+    dist.destroy_process_group()
+
+
+def test_reducer_reduces_late_parameters_instead_of_racing_world2_gloo():
+    """A parameter outside the learned ``used`` set that receives a gradient later is reduced in a second pass of its bucket
+    (and joins the set) — no in-place add into a range whose collective is in flight, no silent replica divergence."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_straggler_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    results = [q.get(timeout=120) for _ in range(2)]
+    [p.join(60) for p in procs]
+    for r in results:
+        assert r[1] == [True, True, True], r
+        assert r[2] == 2 and r[3] == list(range(6)), r          # weight + bias of `late` seen once as stragglers, then used
+
+
+def _resume_worker(rank, world, port, ckdir, out):
+    _setup(rank, world, port)
+    from tests.cpu_doubles import cpu_op_doubles
+    from tests.test_host_trainer import make_trainer, T
+    from tests.conftest import load_golden
+    g = load_golden('trainerA_trace')
+    with cpu_op_doubles():
+        trainer, unet = make_trainer(checkpoint_path=ckdir, checkpoint_every=1000)      # only rank 0 reads the folder
+        trainer.training = True
+        for i in range(4, 6):                                                            # micro-steps 5 and 6 of the trace
+            sl = slice(rank, rank + 1)
+            times = T(g['times'][i])[sl]
+            trainer.imagen.noise_schedulers[1].sample_random_times = lambda b, device, t=times: t.clone()
+            trainer.forward(T(g['hr'][i])[sl], lowres_img=T(g['lowres'][i])[sl], unet_number=2, max_batch_size=1,
+                            noise=T(g['noise'][i])[sl])
+        opt = trainer.optim1
+        idx = unet.names.index('final_conv.weight')
+        w = unet.plist[idx].detach().flatten()
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        m = [torch.zeros_like(opt.exp_avg) for _ in range(world)]
+        dist.all_gather(m, opt.exp_avg)
+        out.put((rank, torch.equal(ws[0], ws[1]), torch.equal(m[0], m[1]) and float(m[0].abs().max()) > 0, opt.step_count,
+                 int(trainer.steps[1]), trainer._micro_step))
+    dist.destroy_process_group()
+
+
+def test_resume_under_world2_hands_optimizer_state_to_every_replica(tmp_path):
+    """Rank 0 alone loads the checkpoint folder (trainer.py:368-370); wrap_unet must broadcast Adam's moments / step, ``steps``
+    and the accumulation phase with the weights, or the replicas diverge at the first optimiser step after a resume."""
+    from tests.cpu_doubles import cpu_op_doubles
+    from tests.test_host_trainer import make_trainer, T
+    from tests.conftest import load_golden
+    g = load_golden('trainerA_trace')
+    ckdir = str(tmp_path / 'ck')
+    with cpu_op_doubles():
+        trainer, unet = make_trainer()
+        trainer.training = True
+        for i in range(4):                               # one optimiser step
+            times = T(g['times'][i])
+            trainer.imagen.noise_schedulers[1].sample_random_times = lambda b, device, t=times: t.clone()
+            trainer.forward(T(g['hr'][i]), lowres_img=T(g['lowres'][i]), unet_number=2, max_batch_size=2, noise=T(g['noise'][i]))
+        trainer.save(os.path.join(ckdir, 'checkpoint.4.pt'))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, ckdir, q)) for r in range(2)]
+    [p.start() for p in procs]
+    results = [q.get(timeout=300) for _ in range(2)]
+    [p.join(60) for p in procs]
+    for r in results:
+        assert r[1] and r[2], r
+        assert r[3:] == (1, 6, 2), r                      # Adam step count, `steps`, micro-step phase agree on both ranks

@@ -83,6 +83,28 @@ def test_unet_attention_variants_match_reference_golden(kind):
             close(named[k[5:]].grad, T(g[k]), 2e-3, k)
 
 
+@pytest.mark.parametrize('kind', ['linear', 'softmax'])
+def test_unet_boundary_merged_volume_attention_factor3_matches_reference_golden(kind):
+    """27 sub-volumes (factor 3) with neighbour-halo convs (boundary=True) and attention over the MERGED 24^3
+    volume at encoder level 0 + the middle (/root/reference/imagen_pytorch3D.py:1610-1622, 1635-1641, 37-46) — forward and
+    gradients of the HIP path against the fixture the real reference produced (oracle/make_golden_r2.py)."""
+    g = load_golden(f'unetA_boundary_attn_{kind}')
+    unet, sd, cfg = build(g, 11)
+    assert list(unet.state_dict().keys()) == [str(k) for k in g['keys']]
+    unet.eval()
+    y = unet(T(g['x']).to(DEV), T(g['times']).to(DEV), T(g['log_snr']).to(DEV), lowres_cond_img=T(g['lowres']).to(DEV))
+    rel = close(y, T(g['y']), 5e-4, f"boundary + merged attention ({kind}) fwd")
+    assert rel <= 5e-5, rel
+    (y ** 2).mean().backward()
+    named = dict(unet.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith('grad:'):
+            close(named[k[5:]].grad, T(g[k]), 2e-3, k)
+            n += 1
+    assert n >= 6
+
+
 @pytest.mark.parametrize('tag', ['local', 'mlp'])
 def test_unet_vit3d_attention_matches_reference_golden(tag):
     g = load_golden(f'unetA_attn_vit_{tag}')
@@ -153,6 +175,32 @@ def test_unet_config2_shape_vs_oracle_fresh_inputs():
         y = unet(x.to(DEV), t.to(DEV), ls.to(DEV), lowres_cond_img=lr.to(DEV))
         yr = O.unet_forward(sd, O.unet_config(**kw), x, t, ls, lowres_cond_img=lr)
     rel = close(y, yr, 2e-4, "config-2 unet")
+    assert rel <= 2e-5, rel
+
+
+@pytest.mark.parametrize("B", [2, 4])
+def test_unet_config2_at_32cubed_routes_through_conv_fwd8_vs_oracle(B):
+    """The exact BASELINE config-2 network at its real 32^3 patch size: B=2 fills exactly one round of 256 workgroups of the
+    8-wave ``conv_fwd8_kernel`` (the headline's dominant kernel), B=4 takes its persistent tile walk.  Whole-U-Net composition
+    on the GPU vs ``oracle.unet_forward`` on the host, same tolerances as the 16^3 case."""
+    from bench import unet_kwargs
+    from diffusioniqt_amd import _lib
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256
+    assert _lib.query("diqt_conv3d_fwd_kernel_id", B, 32, 32, 32, 64, 64, 3, 3, 3, 1, 1, 1, 0, 0, 0) == 3, \
+        "the 64->64 3x3x3 conv at 32^3 no longer dispatches to conv_fwd8_kernel: this test would not cover it"
+    kw = unet_kwargs(32)
+    unet = SRUnet256(**kw)
+    sd = O.hash_fill_state_dict(unet.state_dict(), 7)
+    unet.load_state_dict(sd)
+    unet = unet.to(DEV).eval()
+    gen = torch.Generator().manual_seed(4242 + B)
+    x, lr = torch.randn(B, 1, 32, 32, 32, generator=gen), torch.randn(B, 1, 32, 32, 32, generator=gen)
+    t = torch.rand(B, generator=gen)
+    ls = O.alpha_cosine_log_snr(t)
+    with torch.no_grad():
+        y = unet(x.to(DEV), t.to(DEV), ls.to(DEV), lowres_cond_img=lr.to(DEV))
+        yr = O.unet_forward(sd, O.unet_config(**kw), x, t, ls, lowres_cond_img=lr)
+    rel = close(y, yr, 2e-4, f"config-2 unet at 32^3, B={B}")
     assert rel <= 2e-5, rel
 
 

@@ -92,6 +92,24 @@ def test_unet_attention_variants(kind):
             assert (got - ref).abs().max().item() <= 5e-4 * scale + 1e-7, k
 
 
+@pytest.mark.parametrize('kind', ['linear', 'softmax'])
+def test_unet_boundary_with_merged_volume_attention_factor3(kind):
+    """batch_sample_factor=3 + boundary=True + attention on the merged 24^3 volume at encoder level 0 and the middle
+    (imagen_pytorch3D.py:1610-1622, 1635-1641; fixture: oracle/make_golden_r2.py from the real reference)."""
+    g = load_golden(f'unetA_boundary_attn_{kind}')
+    sd = build_sd(g, seed=11)
+    cfg = cfg_of(g)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y = O.unet_forward(sdg, cfg, T(g['x']), T(g['times']), T(g['log_snr']), lowres_cond_img=T(g['lowres']))
+    assert torch.allclose(y, T(g['y']), atol=5e-5, rtol=1e-4), (y - T(g['y'])).abs().max()
+    (y ** 2).mean().backward()
+    for k in g:
+        if k.startswith('grad:'):
+            ref, got = T(g[k]), sdg[k[5:]].grad
+            scale = ref.abs().max().item() + 1e-12
+            assert (got - ref).abs().max().item() <= 5e-4 * scale + 1e-7, k
+
+
 @pytest.mark.parametrize('tag', ['local', 'mlp'])
 def test_unet_vit3d_attention(tag):
     """att_type='vit' (ViT3D, imagen_pytorch3D.py:871-910), local (conv) and MLP feed-forward."""

@@ -62,3 +62,66 @@ def test_device_pipeline_shards_over_ranks():
     fill = float((np.float32(0.) - np.float32(g['mean'])) / np.float32(g['std']))
     merged = torch.where(a != fill, a, b)
     _check(merged.cpu().numpy(), g, 'plain32')
+
+
+def test_supervisedIQT_INF_dataset_drives_the_script_loop():
+    """compat/data.supervisedIQT_INF (data.py:139-202) iterated the way test_all.py:189-263 does — DataLoader(shuffle=False,
+    collate_fn=my_collate), whole-patch placement — reproduces the reference loop's stitched volume bit for bit."""
+    import os
+    import sys
+    from torch.utils.data import DataLoader
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'compat'))
+    import data as compat_data                                                 # what `from data import ...` resolves to
+    g = load_golden('volume_inference')
+    cfg = _cfg(g, 'plain32')
+    vol = synthetic_volume()
+    ds = compat_data.supervisedIQT_INF(cfg, vol)
+    assert len(ds) == 512 and ds.lr_idx[1] == [0, 0, 32] and ds.lr_idx[8] == [0, 32, 0]
+    assert ds[0] is None                                                       # an empty corner: rejected (< 5 % non-zero)
+    mean32, std32 = np.float32(cfg['Data']['mean']), np.float32(cfg['Data']['std'])
+    pred = np.full(vol.shape, (np.float32(0.) - mean32) / std32, dtype=np.float32)
+    kept = 0
+    for batch in DataLoader(ds, batch_size=cfg['Eval']['batch_size'], shuffle=False, collate_fn=compat_data.my_collate):
+        if batch is None:
+            continue
+        x, idx = batch
+        assert x.shape[1:] == (1, 32, 32, 32) and idx.shape[1] == 3
+        y = fake_sampler(x.numpy())
+        for q, (i, j, k) in enumerate(idx.tolist()):
+            pred[i:i + 32, j:j + 32, k:k + 32] = y[q, 0]
+        kept += x.shape[0]
+    lowres = ((vol - mean32) / std32).astype(np.float32)
+    pred[lowres == lowres.min()] = lowres.min()
+    assert 0 < kept < 512
+    _check(pred, g, 'plain32')
+
+
+@pytest.mark.gpu
+def test_device_pipeline_overlapping_windows_are_deterministic():
+    """Eval.overlap (the stride) below half a patch: cropped interiors of neighbouring windows overlap; the device pipeline
+    must reproduce the serial candidate-order loop ("later overwrites", test_all.py:267-296 crop rule) exactly."""
+    from diffusioniqt_amd.inference import VolumeInference, sliding_window_origins, crop_margins
+    rng = np.random.default_rng(0)
+    n, P, stride = 64, 32, 8
+    vol = rng.integers(1, 1000, size=(n, n, n)).astype(np.float32)
+    cfg = {'Data': {'mean': 300.0, 'std': 200.0, 'norm': 'z-score'},
+           'Train': {'batch_sample': False, 'boundary': False, 'patch_size_sub': P, 'batch_sample_factor': 3},
+           'Eval': {'batch_size': 16, 'overlap': stride}}
+    calls = {'n': 0}
+
+    def sampler(x):                     # differs per call, so which window wrote a voxel last is visible in the result
+        calls['n'] += 1
+        return x * 0.5 + 0.125 * torch.arange(x.shape[0], device=x.device, dtype=x.dtype).view(-1, 1, 1, 1, 1) + calls['n']
+    got = VolumeInference(cfg, sample_fn=sampler)(torch.from_numpy(vol).cuda()).cpu().numpy()
+    mean32, std32 = np.float32(300.0), np.float32(200.0)
+    org = sliding_window_origins((n, n, n), P, stride)
+    mg = crop_margins(org, (n, n, n), P, stride)
+    ref = np.full((n, n, n), (np.float32(0.) - mean32) / std32, dtype=np.float32)
+    for b0 in range(0, org.shape[0], 16):
+        for q, ((i, j, k), m) in enumerate(zip(org[b0:b0 + 16], mg[b0:b0 + 16])):
+            x = ((vol[i:i + P, j:j + P, k:k + P] - mean32) / std32).astype(np.float32)
+            y = (x * np.float32(0.5) + np.float32(0.125) * np.float32(q) + np.float32(b0 // 16 + 1)).astype(np.float32)
+            ref[i + m[0]:i + P - m[1], j + m[2]:j + P - m[3], k + m[4]:k + P - m[5]] = y[m[0]:P - m[1], m[2]:P - m[3], m[4]:P - m[5]]
+    lowres = ((vol - mean32) / std32).astype(np.float32)
+    ref[lowres == lowres.min()] = lowres.min()
+    assert np.array_equal(got, ref)

@@ -1,37 +1,46 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the DiffusionIQT hot path on MI355X.
+"""bench.py — benchmarks of the DiffusionIQT hot path on MI355X.  Prints ONE JSON line on rank 0.
 
-Workload (BASELINE.json configs[1], SURVEY.md §8 "C2"): Family-A SRUnet256(dim=64, dim_mults=(1,2,4),
-2 resnet blocks/level, SE, no attention, deep_feature=False — the train.py kwargs) on 32^3 1-channel
-patches, batch 8 per GPU, fp32.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4|C5] [--mode both|sample|train|volume]
 
-  --mode sample (default): one "step" = one DDPM ancestral sampler step over the batch = one U-Net eval
-                           (186.06 GFLOP/patch) + one fused posterior-step kernel.  value = patches denoised / s.
-  --mode train           : one "step" = one ImagenTrainer micro-step (Imagen.forward + backward + grad
-                           all-reduce on sync steps + fused Adam every 4th + EMA), 558 GFLOP/patch.
-Default mode 'both' times sample steps as the headline value and reports the train rate beside it.
+--config C2 (default; BASELINE.json configs[1], SURVEY.md §8 "C2" — the headline): Family-A SRUnet256(dim=64, dim_mults=(1,2,4),
+    2 resnet blocks/level, SE, no attention, deep_feature=False — the train.py kwargs) on 32^3 1-channel patches, batch 8 per GPU,
+    fp32.  One "step" = one DDPM ancestral sampler step over the batch = one U-Net eval (186.06 GFLOP/patch) + one fused
+    posterior-step kernel; `value` = patches denoised / s.  Beside it: `train` (ImagenTrainer micro-steps: fwd + bwd + bucketed
+    grad all-reduce on sync steps + fused Adam every 4th + EMA, 558 GFLOP/patch), `edm` (ElucidatedImagen stochastic Heun on the
+    same U-Net), `unet3d_edm` (Family B: Unet3D + ElucidatedImagen.sample, the pairing BASELINE.json's metric string names),
+    `api_sample` (the same sampling through trainer.sample(), the reference's call), autocast lines (reduced precision, never `value`).
+--config C4: SRUnet256 img 64, dim 128, LinearAttention at every level + middle, one 64^3 volume per GPU: U-Net evals (6133 GFLOP).
+--config C5: 2-stage ElucidatedImagen cascade 32^3 -> 64^3 of Unet3D dim 64, batch 8 per GPU, K-step (default 64) Heun sampler per
+    stage under torch.autocast(float16): one "step" = one whole cascaded sample of the batch.
 
-N > 1 (launched with torch.distributed.run, one rank per GPU): every rank holds its own batch of 8 patches
-(weak scaling); sampling shards patches with no data-path collective, training all-reduces gradients over RCCL.
+N > 1: `python bench.py --gpus N` starts N ranks ITSELF (child processes with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set before
+anything touches the GPU; the parent never initialises HIP and exits with the children's status).  Launched under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the ranks it was given.  Every rank holds its own
+batch (weak scaling); sampling shards patches with no data-path collective, training all-reduces gradients over RCCL (xGMI).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (conv_fwd_kernel: MFMA f32 implicit-GEMM
-conv), timed live with HIP events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle
-(oracle/iqt_oracle.py, a port of the reference algorithm — the reference itself cannot travel to the GPU box)
-timed on the host cores on a bounded sample of the same workload.
+`roofline` is for the dominant kernel of the headline loop.  The timed region runs WITHOUT instrumentation; the per-kernel
+numbers come from a second, instrumented pass of the same steps (HIP events on the launch stream around every conv launch).
+`cpu_baseline` is the CPU oracle (oracle/iqt_oracle.py, a port of the reference algorithm — the reference itself cannot travel
+to the GPU box) timed on the host cores on a bounded sample of the same workload, rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-GFLOP_PER_PATCH_EVAL = 186.06      # SURVEY.md §8d (FlopCounterMode on the reference, 2*MAC)
+GFLOP_PER_PATCH_EVAL = 186.06      # SURVEY.md §8d (FlopCounterMode on the reference, 2*MAC), C2
+GFLOP_C4_EVAL = 6133.0             # SURVEY.md §8d, C4 at 64^3
+GFLOP_C5_STAGE = (169.4, 1902.1)   # SURVEY.md §8 C5, per patch and eval: stage 1 @32^3, stage 2 @64^3
+GFLOP_U3_EVAL = 190.1              # Unet3D dim 64, mults (1,2,4), 2 resnet blocks, attention at the last level + middle, 32^3
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16/fp16 MFMA (spec)
 
 
 def unet_kwargs(size):
@@ -42,17 +51,74 @@ def unet_kwargs(size):
                 pixel_shuffle_upsample=True, boundary=False, batch_sample=False, batch_sample_factor=3, deep_feature=False)
 
 
-def pmc_traffic(batch, size):
-    """HBM bytes per average conv_fwd launch of one C2 sampler step, from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE and WRITE_SIZE collected separately; FETCH_SIZE doubled for gfx950, MI355X_MICROARCH.md).  The counters
-    cannot be read from inside this process, so this is the profiled value of the same command, or None off-config."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
-    if batch != 8 or size != 32 or not os.path.exists(path):
+def c4_kwargs(size=64):
+    return dict(img_size=size, dim=128, init_dim=128, dim_mults=(1, 2, 4), channels=1, num_resnet_blocks=(2, 2, 2),
+                init_conv_kernel_size=3, lowres_cond=True, init_cross_embed=False, att_type='linear', attn_dim_head=64,
+                attend_at_middle=True, attend_at_enc=[True, True, True], attend_at_enc_depth=[1, 1, 1],
+                attend_at_enc_heads=[8, 8, 8], memory_efficient=False, use_se_attn='True,', pixel_shuffle_upsample=True,
+                boundary=False, batch_sample=True, batch_sample_factor=1, deep_feature=True)
+
+
+def unet3d_kwargs(**over):
+    kw = dict(dim=64, dim_mults=(1, 2, 4), channels=1, cond_on_text=False, text_embed_dim=None, lowres_cond=True,
+              layer_attns=(False, False, True), layer_cross_attns=False, attend_at_middle=True, num_resnet_blocks=2,
+              attn_pool_text=False)
+    kw.update(over)
+    return kw
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the parent only spawns (no HIP call: a process that has initialised the GPU must not fork/exec workers)
+# ---------------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv, rehearse):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this host driver
+        if rehearse:
+            env.update(DIQT_DIST_BACKEND="gloo", DIQT_SHARE_DEVICE="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:                                 # one rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
+def latest_profile(pattern_fn):
+    """Newest profiles/rNN_* file for which ``pattern_fn(name)`` holds (the committed rocprofv3 --pmc summaries)."""
+    d = os.path.join(ROOT, "profiles")
+    names = sorted((n for n in os.listdir(d) if pattern_fn(n)), reverse=True) if os.path.isdir(d) else []
+    return os.path.join(d, names[0]) if names else None
+
+
+def pmc_traffic(kernel, batch, size):
+    """HBM bytes per average launch of ``kernel`` in one C2 sampler step, from the committed rocprofv3 --pmc passes of this
+    command (FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled for gfx950, MI355X_MICROARCH.md).
+    The counters cannot be read from inside this process, so this is the profiled value of the same command, or None off-config."""
+    path = latest_profile(lambda n: n.endswith("_pmc_hbm_traffic.json"))
+    if batch != 8 or size != 32 or path is None:
         return None
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]
-        return next(v["hbm_bytes_per_launch"] for name, v in k.items() if "conv_fwd8_kernel" in name)
+        return next(v["hbm_bytes_per_launch"] for name, v in k.items() if kernel in name)
     except Exception:
         return None
 
@@ -60,44 +126,31 @@ def pmc_traffic(batch, size):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["sample", "train", "both"], default="both")
-    ap.add_argument("--batch", type=int, default=8, help="patches per GPU")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["C2", "C4", "C5"], default="C2")
+    ap.add_argument("--mode", choices=["sample", "train", "both", "volume"], default="both")
+    ap.add_argument("--batch", type=int, default=None, help="patches per GPU (default 8; C4: 1)")
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--no-family-b", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="headline loops only (no EDM / autocast / Family-B lines): the command profiled under profiles/")
+    ap.add_argument("--no-extras", action="store_true", help="headline loops only: the command profiled under profiles/")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N ranks on ONE card with gloo collectives (plumbing rehearsal on a 1-GPU box; never a measurement)")
     args = ap.parse_args()
 
-    from diffusioniqt_amd import distributed as D, ops, _lib
-    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256, Imagen, NullUnet
-    from diffusioniqt_amd.trainer import ImagenTrainer
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.rehearse))
+
+    import torch
     import torch.distributed as dist
+    from diffusioniqt_amd import distributed as D, ops, _lib
 
     world, rank, device = D.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     _lib.load()
-    B, S, K, W = args.batch, args.size, args.steps, args.warmup
-
-    torch.manual_seed(42)                                   # train.py:29 set_seed(42): reference init under seed 42
-    unet = SRUnet256(**unet_kwargs(S))
-    configs = {'Data': {'norm': 'z-score'}, 'Train': {'batch_sample': False, 'patch_size_sub': S, 'pred_obj': 'x_start'},
-               'Eval': {'repeat': 1}}
-    min_bound = (0. - 271.64814106698583) / 377.117173547721
-    imagen = Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=min_bound, image_sizes=(S, S), channels=1,
-                    pred_objectives='x_start', timesteps=max(K + W, 2), dynamic_thresholding=False,
-                    p2_loss_weight_gamma=0.0, cond_drop_prob=0.0).to(device)
-    trainer = ImagenTrainer(configs=configs, imagen=imagen, gradient_accumulation_steps=4, verbose=False)
-    trainer.prepare_for = 2
-    trainer.validate_and_set_unet_being_trained(2)
-    unet = imagen.unets[1]
-
-    g = torch.Generator().manual_seed(42 + rank)            # data.py:259-261 style synthetic z-scored patches
-    hr = torch.randn(B, 1, S, S, S, generator=g).to(device)
-    lr = torch.randn(B, 1, S, S, S, generator=g).to(device)
+    rehearsal = os.environ.get("DIQT_SHARE_DEVICE") == "1"
 
     def sync_all():
         torch.cuda.synchronize()
@@ -106,6 +159,7 @@ def main():
         torch.cuda.synchronize()
 
     def timed(fn, n_warm, n_steps):
+        """W untimed warm-up calls, then exactly n_steps calls bracketed by barrier + synchronize; MAX over ranks."""
         for _ in range(n_warm):
             fn()
         sync_all()
@@ -120,10 +174,200 @@ def main():
             dt = float(t.item())
         return dt
 
-    # ---------------- sampling: K ancestral steps, inputs resident in HBM ----------------
+    def instrumented(fn, n):
+        """Per-kernel HIP-event timing of n more calls, OUTSIDE any timed region -> {tag: (ms, flops, launches)}."""
+        if args.no_kernel_timer:
+            return {}
+        sync_all()
+        ops.TIMER.reset()
+        ops.TIMER.enabled = True
+        for _ in range(n):
+            fn()
+        sync_all()
+        ops.TIMER.enabled = False
+        return ops.TIMER.summary()
+
+    def roofline_of(summ, peak, prefer=None, traffic=None, step_ms=None, n_steps=1):
+        convs = {k: v for k, v in summ.items() if k.startswith("conv")}
+        if not convs:
+            return None
+        dom = prefer if prefer in convs else max(convs, key=lambda k: convs[k][0])
+        ms, flops, n = convs[dom]
+        ach = flops / (ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                    traffic=traffic, launches=n, avg_launch_ms=round(ms / n, 4), flops_per_launch=round(flops / n / 1e9, 3),
+                    flops_unit="GFLOP (algorithmic, 2*MAC) per average launch",
+                    timing="HIP events around every launch in a separate instrumented pass (not inside the timed region)")
+        if step_ms:
+            roof["share_of_step"] = round(ms / n_steps / step_ms, 3)
+        ams, afl = sum(v[0] for v in convs.values()), sum(v[1] for v in convs.values())
+        roof["all_conv_kernels"] = dict(achieved=round(afl / (ams * 1e-3) / 1e12, 2), frac=round(afl / (ams * 1e-3) / 1e12 / peak, 4))
+        if step_ms:
+            roof["all_conv_kernels"]["share_of_step"] = round(ams / n_steps / step_ms, 3)
+        return roof
+
+    ranks_seen = [world]
+    if world > 1:
+        t = torch.tensor([dist.get_world_size()], device=device, dtype=torch.int64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        ranks_seen = [int(x.item()) for x in got]
+
+    common = {"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+    if world > 1:
+        common["dist"] = dict(backend=dist.get_backend(), world_size_seen_by_rank=ranks_seen)
+    if rehearsal:
+        common["rehearsal"] = f"{world} ranks share ONE GPU with gloo collectives: plumbing check, NOT a measurement"
+
+    if args.config == "C4":
+        out = bench_c4(args, torch, ops, device, world, timed, instrumented, roofline_of)
+    elif args.config == "C5":
+        out = bench_c5(args, torch, ops, device, world, timed, instrumented, roofline_of)
+    else:
+        out = bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented, roofline_of, sync_all)
+    if rank == 0:
+        print(json.dumps({**out, **common}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def bench_c4(args, torch, ops, device, world, timed, instrumented, roofline_of):
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256
+    K, W, B, S = args.steps or 10, args.warmup if args.warmup is not None else 3, args.batch or 1, 64
+    torch.manual_seed(0)
+    unet = SRUnet256(**c4_kwargs(S)).to(device).eval()
+    x = torch.randn(B, 1, S, S, S, device=device)
+    lr, t = torch.randn_like(x), torch.rand(B, device=device)
+    assert B == 1, "C4's merged-volume attention takes one volume per call (batch_sample_factor=1)"
+
+    def step():
+        with torch.no_grad():
+            unet(x, None, t, lowres_cond_img=lr)
+    dt = timed(step, W, K)
+    ms = 1e3 * dt / K
+    summ = instrumented(step, 3)
+    res = {"metric": "64³ volumes/sec — U-Net evals (C4: dim 128, LinearAttention at every stage)", "value": round(world * B * K / dt, 3),
+           "unit": "volumes/s", "steps": K, "warmup": W, "ms_per_step": round(ms, 3), "dtype": "f32",
+           "config": {"workload": "C4: SRUnet256 img 64 dim 128 mults (1,2,4), LinearAttention at every level + middle, deep_feature, "
+                                  f"batch_sample factor 1, {B} volume/GPU; one step = one U-Net eval = {GFLOP_C4_EVAL} GFLOP",
+                      "global_batch": world * B, "patch": "64^3", "parallelism": f"dp{world}"},
+           "whole_step_tflops": round(GFLOP_C4_EVAL * B / ms, 2), "whole_step_frac_of_f32_mfma_peak": round(GFLOP_C4_EVAL * B / ms / PEAK_F32_MFMA_TFLOPS, 4),
+           "roofline": roofline_of(summ, PEAK_F32_MFMA_TFLOPS, step_ms=ms, n_steps=3), "cpu_baseline": None}
+
+    def step_h():
+        with torch.autocast('cuda', dtype=torch.float16):
+            step()
+    dth = timed(step_h, 2, max(3, K // 2))
+    res["autocast_fp16"] = dict(ms_per_step=round(1e3 * dth / max(3, K // 2), 3), note="reduced precision, NOT the headline")
+    return res
+
+
+def bench_c5(args, torch, ops, device, world, timed, instrumented, roofline_of):
+    from diffusioniqt_amd.imagen_video import Unet3D
+    from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
+    n_steps = args.steps or 64                 # Heun steps per stage (the config names 64)
+    K, W, B = 1, args.warmup if args.warmup is not None else 0, args.batch or 8
+    torch.manual_seed(5)
+    kw = unet3d_kwargs(layer_attns=False)
+    u1, u2 = Unet3D(**{**kw, 'lowres_cond': False}), Unet3D(**kw)
+    for u in (u1, u2):                         # the reference zero-initialises final convs: make the output depend on the net
+        for p in u.final_conv.parameters():
+            torch.nn.init.normal_(p, std=0.05)
+    elu = ElucidatedImagen(unets=(u1, u2), image_sizes=(32, 64), channels=1, condition_on_text=False, auto_normalize_img=False,
+                           cond_drop_prob=0.0, num_sample_steps=n_steps, temporal_downsample_factor=(2, 1)).to(device)
+    evals = 2 * n_steps - 1
+    tflop_per_sample = evals * sum(GFLOP_C5_STAGE) / 1e3
+    last = {}
+
+    def cascade():
+        with torch.autocast('cuda', dtype=torch.float16):
+            last["out"] = elu.sample(batch_size=B, video_frames=64, use_tqdm=False)
+
+    def short():                               # warm-up / instrumented pass: 2 Heun steps per stage (3 evals each)
+        elu.num_sample_steps = (2, 2)
+        try:
+            cascade()
+        finally:
+            elu.num_sample_steps = (n_steps, n_steps)
+    short()
+    dt = timed(cascade, W, K)
+    assert tuple(last["out"].shape) == (B, 1, 64, 64, 64) and torch.isfinite(last["out"]).all()
+    summ = instrumented(short, 1)
+    ms = 1e3 * dt / K
+    res = {"metric": "cascaded 32³→64³ samples/sec (2-stage ElucidatedImagen, fp16 MFMA)", "value": round(world * B * K / dt, 4),
+           "unit": "samples/s", "steps": K, "warmup": W, "ms_per_step": round(ms, 1), "dtype": "f16 (torch.autocast: conv / linear / attention products on fp16 MFMA with fp32 accumulate; everything else fp32)",
+           "config": {"workload": f"C5: ElucidatedImagen((Unet3D dim 64 @32^3, Unet3D dim 64 @64^3 lowres_cond), image_sizes (32,64), temporal_downsample_factor (2,1)), "
+                                  f"sample(batch_size={B}, video_frames=64), {n_steps} Heun steps per stage = {evals} U-Net evals per stage; one step = one cascaded sample of the batch "
+                                  f"= {tflop_per_sample:.1f} TFLOP/sample", "global_batch": world * B, "patch": "32^3 -> 64^3", "parallelism": f"dp{world}"},
+           "unet_evals_per_s": round(world * 2 * evals * K / dt, 2),
+           "whole_step_tflops": round(tflop_per_sample * B / (ms * 1e-3), 1),
+           "whole_step_frac_of_f16_mfma_peak": round(tflop_per_sample * B / (ms * 1e-3) / PEAK_F16_MFMA_TFLOPS, 4),
+           "roofline": roofline_of(summ, PEAK_F16_MFMA_TFLOPS), "cpu_baseline": None}
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented, roofline_of, sync_all):
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256, Imagen, NullUnet
+    from diffusioniqt_amd.trainer import ImagenTrainer
+    B, S = args.batch or 8, args.size
+    K, W = args.steps or 16, args.warmup if args.warmup is not None else 3
+
+    torch.manual_seed(42)                                   # train.py:29 set_seed(42): reference init under seed 42
+    unet = SRUnet256(**unet_kwargs(S))
+    configs = {'Data': {'norm': 'z-score', 'mean': 271.64814106698583, 'std': 377.117173547721},
+               'Train': {'batch_sample': False, 'patch_size_sub': S, 'batch_sample_factor': 3, 'pred_obj': 'x_start'},
+               'Eval': {'repeat': 1, 'overlap': S, 'batch_size': 4 * B}}
+    min_bound = (0. - 271.64814106698583) / 377.117173547721
+    n_t = max(K + W, 2)
+    imagen = Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=min_bound, image_sizes=(S, S), channels=1,
+                    pred_objectives='x_start', timesteps=n_t, dynamic_thresholding=False,
+                    p2_loss_weight_gamma=0.0, cond_drop_prob=0.0).to(device)
+    trainer = ImagenTrainer(configs=configs, imagen=imagen, gradient_accumulation_steps=4, verbose=False)
+    trainer.prepare_for = 2
+    trainer.validate_and_set_unet_being_trained(2)
+    unet = imagen.unets[1]
+
+    g = torch.Generator().manual_seed(42 + rank)            # data.py:259-261 style synthetic z-scored patches
+    hr = torch.randn(B, 1, S, S, S, generator=g).to(device)
+    lr = torch.randn(B, 1, S, S, S, generator=g).to(device)
     result = {}
+
+    # ---------------- whole-volume inference, patches sharded over ranks with no collective (strong scaling, --mode volume) ----
+    if args.mode == "volume":
+        from diffusioniqt_amd.inference import VolumeInference
+        N = 128 if args.size == 32 else 4 * args.size
+        ax = torch.linspace(-1, 1, N, device=device)
+        zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+        head = ((zz / 0.8) ** 2 + (yy / 0.7) ** 2 + (xx / 0.6) ** 2) < 1
+        vol = torch.where(head, 600 + 300 * torch.sin(9 * xx) * torch.cos(7 * yy) + 200 * zz, torch.zeros_like(xx)).float()
+        kept = [0]
+
+        def sample_fn(x):
+            kept[0] += x.shape[0]
+            return trainer.sample(batch_size=x.shape[0], start_image_or_video=x, start_at_unet_number=2, use_non_ema=True)[0]
+        infer = VolumeInference(configs, sample_fn)
+
+        def one_volume():
+            kept[0] = 0
+            pred = infer(vol, patch_slice=(rank, world) if world > 1 else None)
+            assert torch.isfinite(pred).all()
+        dt = timed(one_volume, 1, 1)
+        tot = torch.tensor([kept[0]], device=device, dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(tot)
+        nk = int(tot.item())
+        return {"metric": "3D patches/sec (32³, 1ch) — whole-volume sliding-window inference, patch-steps/s", "value": round(nk * n_t / dt, 2),
+                "unit": "patch-steps/s", "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * dt, 1), "dtype": "f32", "scaling": "strong",
+                "config": {"workload": f"C2 U-Net, {N}^3 synthetic volume, {nk} kept 32^3 windows sharded over ranks (no collective), {n_t}-step "
+                                       f"ancestral sampling through trainer.sample, stitching + background reset on the device",
+                           "global_batch": nk, "patch": f"{S}^3", "parallelism": f"replicas{world}"}, "roofline": None, "cpu_baseline": None}
+
+    # ---------------- sampling: K ancestral steps, inputs resident in HBM ----------------
     sched = imagen.noise_schedulers[1]
-    sched.num_timesteps = K + W
+    sched.num_timesteps = n_t
     ts = list(sched.get_sampling_timesteps(B, device='cpu'))
     coefs = torch.stack([torch.stack(sched.posterior_coefficients(t, tn)) for t, tn in ts]).to(device)
     conds = torch.stack([sched.get_condition(t) for t, _ in ts]).to(device)
@@ -131,89 +375,65 @@ def main():
     unet.eval()
 
     def sample_step():
-        i = state["i"]
+        i = state["i"] % len(ts)
         with torch.no_grad():
             pred = unet(state["img"], None, conds[i], lowres_cond_img=lr)
             noise = torch.randn_like(pred)
-            state["img"], _ = ops.ddpm_step(state["img"], pred, noise, coefs[i, 0], coefs[i, 1], coefs[i, 2],
-                                            min_bound, 0.0, 0)
-        state["i"] = i + 1
+            state["img"], _ = ops.ddpm_step(state["img"], pred, noise, coefs[i, 0], coefs[i, 1], coefs[i, 2], min_bound, 0.0, 0)
+        state["i"] += 1
 
     roof = None
     if args.mode in ("sample", "both"):
-        for _ in range(W):
-            sample_step()
-        sync_all()
-        ops.TIMER.enabled = not args.no_kernel_timer
-        ops.TIMER.reset()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            sample_step()
-        sync_all()
-        dt = time.perf_counter() - t0
-        ops.TIMER.enabled = False
-        if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = timed(sample_step, W, K)
         result["sample"] = dict(ms_per_step=1e3 * dt / K, patches_per_s=world * B * K / dt)
-        summ = ops.TIMER.summary()
-        dom = max((k for k in ("conv_fwd8_kernel", "conv_fwd_kernel") if k in summ), key=lambda k: summ[k][0], default=None)
-        if dom is not None:
-            ms, flops, n = summ[dom]
-            roof = dict(bound="mfma", kernel=dom, achieved=round(flops / (ms * 1e-3) / 1e12, 2),
-                        peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=pmc_traffic(B, S), launches=n, avg_launch_ms=round(ms / n, 4),
-                        share_of_step=round(ms / (1e3 * dt), 3),
-                        flops_per_launch=round(flops / n / 1e9, 3), flops_unit="GFLOP (algorithmic, 2*MAC) per average launch")
-            # every MFMA conv launch of the step together (conv_fwd8 + conv_fwd + conv1x1 + small-Cin), for comparison across rounds
-            ams = sum(v[0] for k, v in summ.items() if k.startswith("conv"))
-            afl = sum(v[1] for k, v in summ.items() if k.startswith("conv"))
-            roof["all_conv_kernels"] = dict(achieved=round(afl / (ams * 1e-3) / 1e12, 2), frac=round(afl / (ams * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                            share_of_step=round(ams / (1e3 * dt), 3))
         assert torch.isfinite(state["img"]).all()
+        state["img"] = torch.randn(B, 1, S, S, S, device=device)
+        n_i = min(K, 8)
+        summ = instrumented(sample_step, n_i)
+        roof = roofline_of(summ, PEAK_F32_MFMA_TFLOPS, prefer="conv_fwd8_kernel", step_ms=result["sample"]["ms_per_step"], n_steps=n_i)
+        if roof is not None:
+            roof["traffic"] = pmc_traffic(roof["kernel"], B, S)
+            roof["traffic_note"] = "HBM bytes per average launch from the committed rocprofv3 --pmc passes of this command (profiles/), not re-measured in this run"
 
-    # ---------------- the same sampler step under torch.autocast(fp16): conv / linear forwards on the fp16 MFMA kernel (fp32
-    #                  accumulate), everything else fp32 -- the reference's mixed-precision switch.  Reported
-    #                  beside the fp32 headline, never as `value` ----
     if args.mode in ("sample", "both") and not args.no_extras:
-        state["i"] = 0
+        # the same sampling through the reference's own call, trainer.sample (EMA swap, per-step host lists): a check that the
+        # hand-rolled loop above is what the API delivers
+        lr_api = lr.clone()
 
+        def api_sample():
+            trainer.sample(batch_size=B, start_image_or_video=lr_api, start_at_unet_number=2, use_tqdm=False)
+        dt = timed(api_sample, 1, 1)
+        result["api_sample"] = dict(timesteps=n_t, ms_per_step=1e3 * dt / n_t, patch_steps_per_s=world * B * n_t / dt)
+
+        # ---- the same sampler step under torch.autocast(fp16): conv / linear forwards on the fp16 MFMA kernel (fp32 accumulate) ----
         def sample_step_fp16():
             with torch.autocast('cuda', dtype=torch.float16):
                 sample_step()
-
         ka = max(4, K // 2)
-        dt = timed(sample_step_fp16, min(W, 2), min(ka, K + W - min(W, 2)))
-        ka = min(ka, K + W - min(W, 2))
+        dt = timed(sample_step_fp16, 2, ka)
         result["autocast_fp16"] = dict(ms_per_step=1e3 * dt / ka, patches_per_s=world * B * ka / dt, steps=ka)
 
-    # ---------------- EDM (Karras) stochastic Heun sampler on the same U-Net: one call of ElucidatedImagen.sample with
-    #                  n = max(4, K // 2) steps = 2n - 1 U-Net evals (elucidated_imagen.py:382-532); reported beside the headline ----
-    if args.mode in ("sample", "both") and not args.no_extras:
+        # ---- EDM (Karras) stochastic Heun sampler on the same U-Net: n steps = 2n - 1 U-Net evals (elucidated_imagen.py:382-532) ----
         from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
         n_edm = max(4, K // 2)
         elu = ElucidatedImagen(unets=(NullUnet(), unet), image_sizes=(S, S), channels=1, condition_on_text=False,
-                               auto_normalize_img=False, cond_drop_prob=0.0, num_sample_steps=n_edm,
-                               dynamic_thresholding=False).to(device)
+                               auto_normalize_img=False, cond_drop_prob=0.0, num_sample_steps=n_edm, dynamic_thresholding=False).to(device)
         unet.eval()
 
         def edm_sample():
             elu.sample(batch_size=B, video_frames=S, start_image_or_video=lr.clamp(-1, 1), start_at_unet_number=2, use_tqdm=False)
-
         dt = timed(edm_sample, 1, 1)
         result["edm"] = dict(heun_steps=n_edm, unet_evals=2 * n_edm - 1, ms_per_heun_step=1e3 * dt / n_edm,
-                             heun_steps_per_s=n_edm / dt, patch_steps_per_s=world * B * n_edm / dt,
-                             patch_evals_per_s=world * B * (2 * n_edm - 1) / dt)
+                             patch_steps_per_s=world * B * n_edm / dt, patch_evals_per_s=world * B * (2 * n_edm - 1) / dt)
 
-    # ---------------- Family B: pseudo-3D Unet3D, dim 64, mults (1,2,4), mid + last-level attention, 32^3,
-    #                  same batch: one eval (sampling path: fused MQA attention) and one fwd+bwd; reported beside the headline ----
-    if args.mode == "both" and not args.no_family_b and not args.no_extras:
+    # ---------------- Family B: Unet3D + ElucidatedImagen.sample — the pairing BASELINE.json's metric names ----
+    if args.mode == "both" and not args.no_extras:
         from diffusioniqt_amd.imagen_video import Unet3D
+        from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
         torch.manual_seed(43)
-        u3 = Unet3D(dim=64, dim_mults=(1, 2, 4), channels=1, cond_on_text=False, text_embed_dim=None, lowres_cond=True,
-                    layer_attns=(False, False, True), layer_cross_attns=False, attend_at_middle=True, num_resnet_blocks=2,
-                    attn_pool_text=False).to(device)
+        u3 = Unet3D(**unet3d_kwargs()).to(device)
+        for p in u3.final_conv.parameters():
+            torch.nn.init.normal_(p, std=0.05)
         tb = torch.randn(B, device=device) * 0.5
         ltb = torch.full((B,), 0.2, device=device)
 
@@ -224,16 +444,28 @@ def main():
         def u3_train():
             u3.zero_grad(set_to_none=True)
             u3(hr, tb, lowres_cond_img=lr, lowres_noise_times=ltb).square().mean().backward()
-
         u3.eval()
         dte = timed(u3_eval, 2, 4) / 4
+        summ3 = instrumented(u3_eval, 2)
+        n3 = max(4, K // 2)
+        elu3 = ElucidatedImagen(unets=(NullUnet(), u3), image_sizes=(S, S), channels=1, condition_on_text=False, auto_normalize_img=False,
+                                cond_drop_prob=0.0, num_sample_steps=n3).to(device)
+
+        def u3_edm():
+            elu3.sample(batch_size=B, video_frames=S, start_image_or_video=lr.clamp(-1, 1), start_at_unet_number=2, use_tqdm=False)
+        dts = timed(u3_edm, 1, 1)
         u3.train()
         dtt = timed(u3_train, 1, 2) / 2
-        result["unet3d"] = dict(eval_ms=1e3 * dte, eval_patches_per_s=world * B / dte, fwd_bwd_ms=1e3 * dtt,
-                                fwd_bwd_patches_per_s=world * B / dtt)
-        del u3
+        result["unet3d_edm"] = dict(eval_ms=1e3 * dte, eval_patches_per_s=world * B / dte,
+                                    eval_tflops=GFLOP_U3_EVAL * B / (1e3 * dte), eval_frac_of_f32_mfma_peak=GFLOP_U3_EVAL * B / (1e3 * dte) / PEAK_F32_MFMA_TFLOPS,
+                                    heun_steps=n3, unet_evals=2 * n3 - 1, ms_per_heun_step=1e3 * dts / n3, patch_steps_per_s=world * B * n3 / dts,
+                                    patch_evals_per_s=world * B * (2 * n3 - 1) / dts, fwd_bwd_ms=1e3 * dtt, fwd_bwd_patches_per_s=world * B / dtt,
+                                    fwd_bwd_frac_of_f32_mfma_peak=3 * GFLOP_U3_EVAL * B / (1e3 * dtt) / PEAK_F32_MFMA_TFLOPS)
+        result["unet3d_roofline"] = roofline_of(summ3, PEAK_F32_MFMA_TFLOPS, step_ms=1e3 * dte, n_steps=2)
+        del u3, elu3
 
     # ---------------- training: K micro-steps through ImagenTrainer.forward ----------------
+    ddp = None
     if args.mode in ("train", "both"):
         trainer.training = True
         unet.train()
@@ -242,107 +474,151 @@ def main():
             trainer.forward(hr, lowres_img=lr, unet_number=2, max_batch_size=B)
 
         kt = K if args.mode == "train" else max(4, K // 2)
-        ops.TIMER.reset()
-        dt = timed(train_step, W, kt)
-        result["train"] = dict(ms_per_step=1e3 * dt / kt, steps_per_s=kt / dt, patches_per_s=world * B * kt / dt,
-                               steps=kt)
-        if not args.no_kernel_timer:
-            # roofline of the training step's own dominant kernel (weight gradients), HIP events around every launch of a few
-            # extra micro-steps outside the timed region (the events would perturb it)
-            ops.TIMER.reset()
-            ops.TIMER.enabled = True
-            for _ in range(4):
-                train_step()
-            sync_all()
-            ops.TIMER.enabled = False
-            summ_t = ops.TIMER.summary()
-            if "conv_bwd_weight_kernel" in summ_t:
-                ms, flops, n = summ_t["conv_bwd_weight_kernel"]
-                result["train"]["bwd_weight_tflops"] = flops / (ms * 1e-3) / 1e12
-                result["train"]["bwd_weight_frac_of_f32_mfma_peak"] = flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
-                result["train"]["bwd_weight_avg_launch_ms"] = ms / n
+        kt = (kt + 3) // 4 * 4                               # whole accumulation cycles: one all-reduce + Adam per 4 micro-steps
+        dt = timed(train_step, max(W, 4) // 4 * 4, kt)
+        result["train"] = dict(ms_per_step=1e3 * dt / kt, steps_per_s=kt / dt, patches_per_s=world * B * kt / dt, steps=kt)
+        summ_t = instrumented(train_step, 4)
+        tr = roofline_of({k: v for k, v in summ_t.items() if k.startswith("conv_bwd_weight")}, PEAK_F32_MFMA_TFLOPS,
+                         step_ms=result["train"]["ms_per_step"], n_steps=4)
+        if tr is not None:
+            tr.pop("all_conv_kernels", None)
+            result["train_roofline"] = tr
+        if world > 1:
+            ddp = ddp_stats(torch, dist, ops, trainer, train_step, sync_all, device, world)
         if not args.no_extras:
-            # the same micro-steps with ImagenTrainer's mixed-precision switch (precision='bf16', trainer.py:293-311): forward and
-            # backward-data on the bf16 MFMA kernel, weight gradients / optimiser / master weights fp32.  Beside the fp32 line.
+            # the same micro-steps with ImagenTrainer's mixed-precision switch (precision='bf16', trainer.py:293-311)
             trainer.mixed_precision = 'bf16'
-            dtb = timed(train_step, 2, kt)
+            dtb = timed(train_step, 4, kt)
             trainer.mixed_precision = 'no'
             result["train_bf16"] = dict(ms_per_step=1e3 * dtb / kt, patches_per_s=world * B * kt / dtb, steps=kt)
 
     # ---------------- CPU baseline: the oracle on the host cores, bounded sample ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import iqt_oracle as O
-        ncores = os.cpu_count() or 1
-        sd = {k: v.detach().cpu() for k, v in unet.state_dict().items()}
-        cfg = O.unet_config(**unet_kwargs(S))
-        nb = 2
-        x_c, lr_c = torch.randn(nb, 1, S, S, S), torch.randn(nb, 1, S, S, S)
-        t_c = torch.full((nb,), 0.5)
-        with torch.no_grad():
-            # torch-CPU convs do not scale to every hardware thread of the host: probe a few thread counts on one
-            # eval each and keep the fastest (the count actually used is reported as `cores`)
-            best = (1e30, 1)
-            for nt in sorted({min(ncores, c) for c in (8, 16, 32, 64, 128)}):
-                torch.set_num_threads(nt)
-                O.unet_forward(sd, cfg, x_c[:1], t_c[:1], O.alpha_cosine_log_snr(t_c[:1]), lowres_cond_img=lr_c[:1])
-                tp = time.perf_counter()
-                O.unet_forward(sd, cfg, x_c[:1], t_c[:1], O.alpha_cosine_log_snr(t_c[:1]), lowres_cond_img=lr_c[:1])
-                tp = time.perf_counter() - tp
-                if tp < best[0]:
-                    best = (tp, nt)
-                if tp > 8.0:
-                    break
-            torch.set_num_threads(best[1])
-            O.unet_forward(sd, cfg, x_c, t_c, O.alpha_cosine_log_snr(t_c), lowres_cond_img=lr_c)      # warm-up
-            n_it, t0 = 0, time.perf_counter()
-            while (time.perf_counter() - t0 < 10.0 or n_it < 2) and time.perf_counter() - t0 < 40.0:
-                pred = O.unet_forward(sd, cfg, x_c, t_c, O.alpha_cosine_log_snr(t_c), lowres_cond_img=lr_c)
-                mean, _, logvar = O.q_posterior(pred.clamp(min=min_bound), x_c, t_c, t_c - 0.01)
-                x_c = mean + (0.5 * logvar).exp() * torch.randn_like(x_c)
-                n_it += 1
-            dtc = time.perf_counter() - t0
-        cpu = dict(value=round(nb * n_it / dtc, 3), unit="patches/s", cores=torch.get_num_threads(), kind="port",
-                   sample=f"{n_it} DDPM sampler steps (U-Net eval + posterior step) of {nb} 32^3 patches, oracle/iqt_oracle.py "
-                          f"on torch-CPU fp32, anomaly detection off")
+        cpu = cpu_baseline(torch, unet, S, min_bound)
 
-    if rank == 0:
-        primary = "sample" if "sample" in result else "train"
-        out = {
-            "metric": ("3D patches/sec (32³, 1ch) — sample steps/sec x batch (one U-Net eval per patch and step: DDPM ancestral; EDM Heun in `edm`, "
-                       "train-steps/sec in `train`)") if primary == "sample" else "3D patches/sec (32³, 1ch) — train micro-steps",
-            "value": round(result[primary]["patches_per_s"], 2), "unit": "patches/s",
-            "n_gpus": world, "steps": K if primary == "sample" else result["train"]["steps"], "warmup": W,
-            "ms_per_step": round(result[primary]["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2: SRUnet256 dim=64 mults=(1,2,4) 32^3 1ch, batch {B}/GPU, DDPM ancestral sampler step "
-                                   f"(1 U-Net eval = {GFLOP_PER_PATCH_EVAL} GFLOP/patch) + ImagenTrainer micro-step",
-                       "global_batch": world * B, "patch": f"{S}^3", "parallelism": f"dp{world}"},
-            "roofline": roof,
-            "cpu_baseline": cpu,
-        }
-        if "train" in result:
-            out["train"] = {k: round(v, 3) for k, v in result["train"].items()}
-            out["train"]["note"] = "ImagenTrainer.forward micro-step: fwd+bwd (558 GFLOP/patch), grad all-reduce + fused Adam every 4th, EMA"
-        if "train_bf16" in result:
-            out["train_bf16"] = {k: round(v, 3) for k, v in result["train_bf16"].items()}
-            out["train_bf16"]["note"] = ("same micro-steps with ImagenTrainer(precision='bf16'): forward + backward-data on the bf16 MFMA kernel, "
-                                         "weight gradients / Adam / master weights fp32; reduced precision, NOT the headline")
-        if "sample" in result:
-            out["sample_steps_per_s"] = round(1e3 / result["sample"]["ms_per_step"], 3)
-        if "unet3d" in result:
-            out["unet3d"] = {k: round(v, 3) for k, v in result["unet3d"].items()}
-            out["unet3d"]["note"] = "Family B: Unet3D dim 64, mults (1,2,4), 2 resnet blocks, attention at the last level + middle, 32^3 (190 GFLOP/patch/eval)"
-        if "autocast_fp16" in result:
-            out["autocast_fp16"] = {k: round(v, 3) for k, v in result["autocast_fp16"].items()}
-            out["autocast_fp16"]["note"] = ("same DDPM sampler step under torch.autocast(float16): conv/linear forwards on v_mfma_f32_32x32x16_f16 "
-                                            "(fp32 accumulate), all else fp32; reduced precision, NOT the headline")
-        if "edm" in result:
-            out["edm"] = {k: round(v, 3) for k, v in result["edm"].items()}
-            out["edm"]["note"] = "ElucidatedImagen.sample (stochastic Heun, 2 U-Net evals per step except the last) driving the same C2 U-Net"
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    if rank != 0:
+        return {}
+    primary = "sample" if "sample" in result else "train"
+    r3 = lambda d: {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()}
+    out = {
+        "metric": ("3D patches/sec (32³, 1ch) — sample steps/sec x batch (one U-Net eval per patch and step: DDPM ancestral; EDM Heun in `edm` / "
+                   "`unet3d_edm`, train-steps/sec in `train`)") if primary == "sample" else "3D patches/sec (32³, 1ch) — train micro-steps",
+        "value": round(result[primary]["patches_per_s"], 2), "unit": "patches/s",
+        "steps": K if primary == "sample" else result["train"]["steps"], "warmup": W,
+        "ms_per_step": round(result[primary]["ms_per_step"], 3), "dtype": "f32",
+        "config": {"workload": f"C2: SRUnet256 dim=64 mults=(1,2,4) 32^3 1ch, batch {B}/GPU, DDPM ancestral sampler step "
+                               f"(1 U-Net eval = {GFLOP_PER_PATCH_EVAL} GFLOP/patch) + ImagenTrainer micro-step",
+                   "global_batch": world * B, "patch": f"{S}^3", "parallelism": f"dp{world}"},
+        "roofline": roof if primary == "sample" else result.get("train_roofline"),
+        "cpu_baseline": cpu,
+    }
+    if "sample" in result:
+        out["sample_steps_per_s"] = round(1e3 / result["sample"]["ms_per_step"], 3)
+        out["whole_step_frac_of_f32_mfma_peak"] = round(GFLOP_PER_PATCH_EVAL * B / result["sample"]["ms_per_step"] / PEAK_F32_MFMA_TFLOPS, 4)
+    if "train" in result:
+        out["train"] = r3(result["train"])
+        out["train"]["whole_step_frac_of_f32_mfma_peak"] = round(3 * GFLOP_PER_PATCH_EVAL * B / result["train"]["ms_per_step"] / PEAK_F32_MFMA_TFLOPS, 4)
+        out["train"]["note"] = "ImagenTrainer.forward micro-step: fwd+bwd (558 GFLOP/patch), grad all-reduce + fused Adam every 4th, EMA"
+        if "train_roofline" in result:
+            out["train"]["roofline"] = result["train_roofline"]
+        if ddp is not None:
+            out["train"]["ddp"] = ddp
+    if "train_bf16" in result:
+        out["train_bf16"] = r3(result["train_bf16"])
+        out["train_bf16"]["note"] = ("same micro-steps with ImagenTrainer(precision='bf16'): forward + backward-data on the bf16 MFMA kernel, "
+                                     "weight gradients / Adam / master weights fp32; reduced precision, NOT the headline")
+    if "api_sample" in result:
+        out["api_sample"] = r3(result["api_sample"])
+        out["api_sample"]["note"] = "the same sampling through trainer.sample() (EMA swap, per-step host lists): the API delivers the hand-rolled loop's rate"
+    if "unet3d_edm" in result:
+        out["unet3d_edm"] = r3(result["unet3d_edm"])
+        out["unet3d_edm"]["roofline"] = result.get("unet3d_roofline")
+        out["unet3d_edm"]["note"] = (f"Family B: Unet3D dim 64, mults (1,2,4), 2 resnet blocks, attention at the last level + middle, 32^3 "
+                                     f"({GFLOP_U3_EVAL} GFLOP/patch/eval) driven by ElucidatedImagen.sample (stochastic Heun), and one fwd+bwd")
+    if "autocast_fp16" in result:
+        out["autocast_fp16"] = r3(result["autocast_fp16"])
+        out["autocast_fp16"]["note"] = ("same DDPM sampler step under torch.autocast(float16): conv/linear forwards on v_mfma_f32_32x32x16_f16 "
+                                        "(fp32 accumulate), all else fp32; reduced precision, NOT the headline")
+    if "edm" in result:
+        out["edm"] = r3(result["edm"])
+        out["edm"]["note"] = "ElucidatedImagen.sample (stochastic Heun, 2 U-Net evals per step except the last) driving the same C2 U-Net"
+    return out
+
+
+def ddp_stats(torch, dist, ops, trainer, train_step, sync_all, device, world):
+    """What the gradient exchange costs and how much of it backward hides: per-micro-step times split by sync / no_sync, the
+    all-reduce of the whole gradient arena alone, and the fused Adam alone."""
+    arena = trainer._arena
+    nbytes = arena.numel * 4
+    scratch = torch.zeros_like(arena.grad)
+    avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
+
+    def clock(fn, n):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync_all()
+        return 1e3 * (time.perf_counter() - t0) / n
+    alone = clock(lambda: dist.all_reduce(scratch, op=avg), 5)
+    opt = trainer.optim1
+    g = opt.param_groups[0]
+    lr_keep, g['lr'] = g['lr'], 0.0
+
+    def adam():
+        ops.adam_step(arena.flat, scratch, opt.exp_avg, opt.exp_avg_sq, 0.0, g['betas'][0], g['betas'][1], g['eps'], 0.0, 1, zero_grad=False)
+    adam_ms = clock(adam, 5)
+    g['lr'] = lr_keep
+    per = {True: [], False: []}
+    while trainer._micro_step % 4 != 0:
+        train_step()
+    for _ in range(8):
+        sync = (trainer._micro_step + 1) % 4 == 0
+        per[sync].append(clock(train_step, 1))
+    t_sync, t_nosync = sum(per[True]) / len(per[True]), sum(per[False]) / len(per[False])
+    exposed = max(0.0, t_sync - t_nosync - adam_ms)
+    return dict(allreduce_bytes_per_optimizer_step=nbytes, allreduce_bytes_per_micro_step=nbytes / 4, buckets=len(trainer.unet_being_trained.reducer.buckets),
+                allreduce_alone_ms=round(alone, 3), allreduce_alone_busbw_GBps=round(2 * (world - 1) / world * nbytes / (alone * 1e-3) / 1e9, 1),
+                sync_micro_step_ms=round(t_sync, 3), nosync_micro_step_ms=round(t_nosync, 3), adam_ms=round(adam_ms, 3),
+                exposed_allreduce_ms=round(exposed, 3), overlap_fraction=round(min(1.0, max(0.0, 1.0 - exposed / alone)), 3) if alone > 0 else None,
+                note="overlap_fraction = share of the stand-alone all-reduce time hidden behind backward on synchronised micro-steps")
+
+
+def cpu_baseline(torch, unet, S, min_bound):
+    from oracle import iqt_oracle as O
+    ncores = os.cpu_count() or 1
+    sd = {k: v.detach().cpu() for k, v in unet.state_dict().items()}
+    cfg = O.unet_config(**unet_kwargs(S))
+    nb = 2
+    x_c, lr_c = torch.randn(nb, 1, S, S, S), torch.randn(nb, 1, S, S, S)
+    t_c = torch.full((nb,), 0.5)
+    with torch.no_grad():
+        # torch-CPU convs do not scale to every hardware thread of the host: probe a few thread counts on one
+        # eval each and keep the fastest (the count actually used is reported as `cores`)
+        best = (1e30, 1)
+        for nt in sorted({min(ncores, c) for c in (8, 16, 32, 64, 128)}):
+            torch.set_num_threads(nt)
+            O.unet_forward(sd, cfg, x_c[:1], t_c[:1], O.alpha_cosine_log_snr(t_c[:1]), lowres_cond_img=lr_c[:1])
+            tp = time.perf_counter()
+            O.unet_forward(sd, cfg, x_c[:1], t_c[:1], O.alpha_cosine_log_snr(t_c[:1]), lowres_cond_img=lr_c[:1])
+            tp = time.perf_counter() - tp
+            if tp < best[0]:
+                best = (tp, nt)
+            if tp > 8.0:
+                break
+        torch.set_num_threads(best[1])
+        O.unet_forward(sd, cfg, x_c, t_c, O.alpha_cosine_log_snr(t_c), lowres_cond_img=lr_c)      # warm-up
+        n_it, t0 = 0, time.perf_counter()
+        while (time.perf_counter() - t0 < 10.0 or n_it < 2) and time.perf_counter() - t0 < 40.0:
+            pred = O.unet_forward(sd, cfg, x_c, t_c, O.alpha_cosine_log_snr(t_c), lowres_cond_img=lr_c)
+            mean, _, logvar = O.q_posterior(pred.clamp(min=min_bound), x_c, t_c, t_c - 0.01)
+            x_c = mean + (0.5 * logvar).exp() * torch.randn_like(x_c)
+            n_it += 1
+        dtc = time.perf_counter() - t0
+    return dict(value=round(nb * n_it / dtc, 3), unit="patches/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_it} DDPM sampler steps (U-Net eval + posterior step) of {nb} 32^3 patches, oracle/iqt_oracle.py "
+                       f"on torch-CPU fp32, anomaly detection off")
 
 
 if __name__ == "__main__":

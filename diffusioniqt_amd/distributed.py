@@ -26,16 +26,20 @@ def init_from_env(device_type=None):
     Returns (world_size, rank, device)."""
     world, rank, local = env_world()
     use_cuda = torch.cuda.is_available() if device_type is None else device_type == "cuda"
-    device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    # rehearsal on a one-GPU box (bench.py --rehearse): DIQT_SHARE_DEVICE=1 maps every rank onto the cards that exist and
+    # DIQT_DIST_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one device).  Never set in production.
+    share = os.environ.get("DIQT_SHARE_DEVICE") == "1"
+    backend = os.environ.get("DIQT_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+    device = torch.device("cuda", local % torch.cuda.device_count() if share else local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kwargs = {}
-        if use_cuda:
+        if use_cuda and backend == "nccl":
             kwargs["device_id"] = device
-        dist.init_process_group(backend="nccl" if use_cuda else "gloo", rank=rank, world_size=world, **kwargs)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return world, rank, device
 
 
@@ -181,12 +185,10 @@ class BucketedGradReducer:
             only = idx if self.used is None else [j for j in idx if j in self.used]
         self.arena.collect(only)
         buf = self.arena.grad[lo:hi]
-        if buf.is_cuda:
-            h = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
-        else:
-            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        native_avg = dist.get_backend(self.pg) == "nccl"        # RCCL averages in the collective; gloo sums, divided after the wait
+        h = dist.all_reduce(buf, op=dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._launched.add(b)
-        self._handles.append((h, buf))
+        self._handles.append((h, buf, native_avg))
 
     def prepare_backward(self, sync=True):
         self.sync = sync
@@ -214,9 +216,9 @@ class BucketedGradReducer:
             self.used |= set(stragglers)
 
     def _wait(self):
-        for h, buf in self._handles:
+        for h, buf, native_avg in self._handles:
             h.wait()
-            if not buf.is_cuda:
+            if not native_avg:
                 buf.div_(self.world)
         self._handles = []
 

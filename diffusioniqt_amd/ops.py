@@ -282,7 +282,9 @@ class _Conv3dFn(Function):
             if TIMER.enabled:
                 e.record()
                 Do, Ho, Wo = dy.shape[1:4]
-                TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_bwd_weight_kernel",
+                # rocprofv3's name of the kernel diqt_conv3d_bwd_weight dispatches 3x3x3-class filters to; the interval also holds
+                # the fixed-order slab reduce (conv_reduce_dw_kernel) that finishes the gradient
+                TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_bwd_weight2_kernel",
                                       (B, D, H, W, Cin, Cout, kd, kh, kw)))
         return dx, dw, db, None, (dy if ctx.has_res else None), None, None
 

@@ -478,10 +478,11 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
         dt = timed(train_step, max(W, 4) // 4 * 4, kt)
         result["train"] = dict(ms_per_step=1e3 * dt / kt, steps_per_s=kt / dt, patches_per_s=world * B * kt / dt, steps=kt)
         summ_t = instrumented(train_step, 4)
-        tr = roofline_of({k: v for k, v in summ_t.items() if k.startswith("conv_bwd_weight")}, PEAK_F32_MFMA_TFLOPS,
-                         step_ms=result["train"]["ms_per_step"], n_steps=4)
+        wg = {k: v for k, v in summ_t.items() if k.startswith("conv_bwd_weight") or k.startswith("conv_wgrad")}
+        tr = roofline_of(wg, PEAK_F32_MFMA_TFLOPS, prefer="conv_wgrad3_kernel", step_ms=result["train"]["ms_per_step"], n_steps=4)
         if tr is not None:
-            tr.pop("all_conv_kernels", None)
+            tr["all_weight_gradient_kernels"] = tr.pop("all_conv_kernels")
+            tr["note"] = "launch interval = the weight-gradient kernel + its fixed-order split-K slab sum (conv_reduce_dw3_kernel)"
             result["train_roofline"] = tr
         if world > 1:
             ddp = ddp_stats(torch, dist, ops, trainer, train_step, sync_all, device, world)

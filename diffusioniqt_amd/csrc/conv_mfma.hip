@@ -21,6 +21,7 @@
 //   LDS and issues one MFMA per (tap, 2 voxels).  Partial slabs go to the workspace in the packed
 //   layout and are reduced in a fixed order (deterministic) by conv_reduce_dw_kernel.
 #include "common.h"
+#include "conv_wgrad.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -1356,6 +1357,73 @@ __global__ void conv_reduce_dw_kernel(const float* __restrict__ slabs, float* __
         }
 }
 
+// Split-K sum of the version-3 weight gradient (conv_wgrad.hip): its slabs are already in dw[co][ci][tap] order, one per
+// workgroup (128 for a 64 -> 64 layer), so this is a streaming sum.  A 512-thread block owns 64 float4 of dW; its 8 waves each sum a
+// contiguous eighth of the slabs with eight 1-KiB loads in flight, the eighths are combined in a fixed order through LDS.
+// Deterministic: the order of every addition is fixed by (ksplit, position) alone.
+__global__ __launch_bounds__(512) void conv_reduce_dw3_kernel(const float* __restrict__ slabs, float* __restrict__ dw, size_t n4,
+                                                              int ksplit, int Cout, int CoutPad, const float* __restrict__ bias_part,
+                                                              float* __restrict__ dbias, int biasParts) {
+    __shared__ float4 part[8][64];
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const size_t e = (size_t)blockIdx.x * 64 + lane;
+    const int k0 = sg * ksplit / 8, k1 = (sg + 1) * ksplit / 8;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n4) {
+        const float4* p = reinterpret_cast<const float4*>(slabs) + e;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * n4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < k1; ++k) {
+            const float4 v = p[(size_t)k * n4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    part[sg][lane] = s;
+    __syncthreads();
+    if (sg == 0 && e < n4) {
+        float4 v = part[0][lane];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { const float4 u = part[q][lane]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        reinterpret_cast<float4*>(dw)[e] = v;
+    }
+    // bias gradient: sum of the per-slice partial rows.  One block, but every row is a dependent-latency load if a thread walks
+    // them one by one (128 rows: 28 us, three times the slab sum above) -- the 8 waves take an eighth of the rows each, 8 loads in flight.
+    if (dbias && blockIdx.x == gridDim.x - 1) {
+        __shared__ float bpart[8][64];
+        for (int c0 = 0; c0 < Cout; c0 += 64) {
+            const int c = c0 + lane;
+            const int y0 = sg * biasParts / 8, y1 = (sg + 1) * biasParts / 8;
+            float sb = 0.f;
+            if (c < Cout) {
+                int y = y0;
+                for (; y + 8 <= y1; y += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = bias_part[(size_t)(y + u) * CoutPad + c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sb += v[u];
+                }
+                for (; y < y1; ++y) sb += bias_part[(size_t)y * CoutPad + c];
+            }
+            __syncthreads();
+            bpart[sg][lane] = sb;
+            __syncthreads();
+            if (sg == 0 && c < Cout) {
+                float v = bpart[0][lane];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) v += bpart[q][lane];
+                dbias[c] = v;
+            }
+        }
+    }
+}
+
 // column sums: out[c] = sum_rows x[row][c]; stage 1 -> partial[block][C], stage 2 -> out
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ x,
                                                             float* __restrict__ partial, size_t rows, int C) {
@@ -1452,6 +1520,14 @@ static unsigned long long* g_dbg_ptr = nullptr;   // diagnostic cycle-stamp buff
 static unsigned g_dbg_n = 0;
 
 // diagnostic only (not part of include/diqt.h): copies the cycle stamps of the last DIQT_CONV_DBG=1 launch to the host
+extern "C" int diqt_debug_wgrad3_stamps(unsigned long long* host_out, unsigned max_waves) {
+    if (!wgrad3_dbg_ptr || !wgrad3_dbg_n) return 0;
+    const unsigned n = wgrad3_dbg_n < max_waves ? wgrad3_dbg_n : max_waves;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host_out, wgrad3_dbg_ptr, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    return (int)n;
+}
+
 extern "C" int diqt_debug_conv_stamps(unsigned long long* host_out, unsigned max_wg) {
     if (!g_dbg_ptr || !g_dbg_n) return 0;
     const unsigned n = g_dbg_n < max_wg ? g_dbg_n : max_wg;
@@ -1961,6 +2037,12 @@ extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, in
     int ks2 = 0;
     size_t lds2;
     if (bw2_plan(bg.g, b2, splitCo, ks2, lds2) && ks2 * (splitCo ? 1 : BW2_KPAR_A) > ksplit) ksplit = ks2 * (splitCo ? 1 : BW2_KPAR_A);
+    {
+        W3Geom g3;
+        int v3 = 0, ks3 = 0;
+        size_t lds3 = 0;
+        if (wgrad3_plan(g3, v3, ks3, lds3, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw) && ks3 > ksplit) ksplit = ks3;
+    }
     const size_t slab = (size_t)bg.g.nChunks * kd * kh * kw * bg.g.CoutPad * CK * sizeof(float);
     const size_t colsum = (size_t)1024 * Cout * sizeof(float);
     size_t need = (size_t)ksplit * slab + (size_t)ksplit * bg.g.CoutPad * sizeof(float);   // + bias partials (v2)
@@ -1979,6 +2061,27 @@ extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, in
         if (sc > need) need = sc;
     }
     return need > colsum ? need : colsum;
+}
+
+// which kernel diqt_conv3d_bwd_weight dispatches this shape to (for profilers / bench.py, so that per-kernel numbers carry the names
+// rocprofv3 reports): 3 conv_wgrad3_kernel, 2 conv_bwd_weight2_kernel, 1 conv_bwd_weight_kernel, 0 one of the GEMM / column-sum
+// paths (1x1x1 filters, <= 4 input channels, Cout == 1), -1 bad shape
+extern "C" int diqt_conv3d_bwd_weight_kernel_id(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
+                                                int pw, int epd, int eph, int epw) {
+    BwGeom bg;
+    int ksplit;
+    if (bw_plan(bg, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, ksplit)) return -1;
+    if (Cout == 1 && kd * kh * kw == 1) return 0;
+    if (sc_plan(bg.g).ok || pw_plan(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw).ok) return 0;
+    W3Geom g3;
+    int v3 = 0, ks3 = 0;
+    size_t lds3 = 0;
+    if (wgrad3_plan(g3, v3, ks3, lds3, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return 3;
+    BwGeom2 b2;
+    bool splitCo;
+    int ks2;
+    size_t lds2;
+    return bw2_plan(bg.g, b2, splitCo, ks2, lds2) ? 2 : 1;
 }
 
 extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, void* workspace,
@@ -2085,7 +2188,19 @@ extern "C" int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw
     size_t lds2 = 0;
     float* bias_part = nullptr;      // v2 kernel: per-split-K bias-gradient partials behind the slabs
     int bias_parts = 0;
-    if (bw2_plan(g, b2, splitCo, ks2, lds2)) {
+    W3Geom g3;
+    int v3 = 0, ks3 = 0;
+    size_t lds3 = 0;
+    if (aligned16(x) && aligned16(dy) && aligned16(dw) && wgrad3_plan(g3, v3, ks3, lds3, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) {
+        // version 3 (conv_wgrad.hip): one wave per SIMD, LDS-DMA double-buffered tiles; same slab layout and reduce
+        if (dbias) { bias_part = slabs + (size_t)ks3 * Cout * Cin * T; bias_parts = ks3; }
+        rc = wgrad3_launch(x, dy, slabs, bias_part, g3, v3, ks3, lds3, stream);
+        if (rc) return rc;
+        const size_t n4 = (size_t)Cout * Cin * T / 4;          // Cin % 4 == 0 (wgrad3_plan)
+        hipLaunchKernelGGL(conv_reduce_dw3_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(512), 0, s, slabs, dw, n4, ks3, Cout, g.CoutPad,
+                           bias_part, bias_part ? dbias : nullptr, bias_parts);
+        return check_launch("conv_reduce_dw3");
+    } else if (bw2_plan(g, b2, splitCo, ks2, lds2)) {
         void (*k2)(const float*, const float*, float*, float*, BwGeom2) =
             splitCo ? (vec4 ? conv_bwd_weight2_kernel<true, 8, 16, BW2_MAXT_B, true, 256> : conv_bwd_weight2_kernel<false, 8, 16, BW2_MAXT_B, true, 256>)
                     : (b2.maxtA == 3

@@ -282,10 +282,11 @@ class _Conv3dFn(Function):
             if TIMER.enabled:
                 e.record()
                 Do, Ho, Wo = dy.shape[1:4]
-                # rocprofv3's name of the kernel diqt_conv3d_bwd_weight dispatches 3x3x3-class filters to; the interval also holds
-                # the fixed-order slab reduce (conv_reduce_dw_kernel) that finishes the gradient
-                TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_bwd_weight2_kernel",
-                                      (B, D, H, W, Cin, Cout, kd, kh, kw)))
+                # tagged with rocprofv3's name of the kernel diqt_conv3d_bwd_weight dispatches to; the interval also holds the
+                # fixed-order split-K slab sum that finishes the gradient
+                kid = _lib.query("diqt_conv3d_bwd_weight_kernel_id", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
+                tag = ("conv_bwd_weight_gemm", "conv_bwd_weight_kernel", "conv_bwd_weight2_kernel", "conv_wgrad3_kernel")[max(kid, 0)]
+                TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, tag, (B, D, H, W, Cin, Cout, kd, kh, kw)))
         return dx, dw, db, None, (dy if ctx.has_res else None), None, None
 
 

@@ -121,6 +121,12 @@ int diqt_conv3d_fwd_ws(const float* x, const float* packed, const float* bias, c
 long long diqt_conv3d_lds_bytes(int D, int H, int W, int kd, int kh, int kw, int pd, int ph, int pw,
                                 int epd, int eph, int epw);
 
+/* Which kernel diqt_conv3d_bwd_weight dispatches a shape to (profilers / bench.py: per-kernel numbers under rocprofv3's names):
+ * 3 conv_wgrad3_kernel (one wave per SIMD, LDS-DMA double-buffered tiles), 2 conv_bwd_weight2_kernel, 1 conv_bwd_weight_kernel,
+ * 0 a GEMM / column-sum path (1x1x1 filters, <= 4 input channels, Cout == 1), -1 bad shape. */
+int diqt_conv3d_bwd_weight_kernel_id(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                     int epd, int eph, int epw);
+
 /* dW[Cout][Cin][kd][kh][kw] (OIDHW, overwritten) and dbias[Cout] (may be NULL) from x and dY.
  * Deterministic: split-K partial slabs in `workspace` are reduced in a fixed order.                  */
 size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout,

@@ -65,6 +65,16 @@ CONV_CASES = [
     (2, (16, 16, 16), 128, 64, (1, 1, 1), (0, 0, 0)),      # 1x1x1 with many voxels: dW through the split-K GEMM (x on the M side)
     (1, (16, 16, 16), 64, 192, (1, 1, 1), (0, 0, 0)),      # ... dY on the M side
     (2, (8, 16, 16), 72, 40, (1, 1, 1), (0, 0, 0)),        # ... channel counts that are not multiples of the tile
+    # weight gradient, version 3 (conv_wgrad3_kernel): split-K ranges of SEVERAL 64-voxel tiles per workgroup, i.e. the in-loop
+    # LDS-DMA of the next tile into the other buffer, tile-walk wrap-around over w / h / d / batch, the shared middle tap
+    (2, (32, 32, 32), 32, 32, (3, 3, 3), (1, 1, 1)),       # 1024 tiles on 256 workgroups: 4 tiles each
+    (2, (16, 16, 16), 96, 40, (3, 3, 3), (1, 1, 1)),       # 3 input-channel blocks, ragged Cout, 2 tiles each
+    (1, (9, 13, 22), 32, 32, (3, 3, 3), (1, 1, 1)),        # ragged extents in every axis (tiles 2x4x8 hang over)
+    (2, (18, 18, 18), 16, 16, (3, 3, 3), (0, 0, 0)),       # un-padded conv: no halo outside the volume
+    (4, (8, 32, 32), 64, 64, (1, 3, 3), (0, 1, 1)),        # (1,3,3): co-half x ci-half waves, 1x8x8 tiles, 2 tiles each
+    (3, (5, 20, 12), 24, 72, (1, 3, 3), (0, 1, 1)),        # ... ragged channels (Cin < 32: one half-empty ci half) and extents
+    (4, (32, 16, 16), 64, 48, (3, 1, 1), (1, 0, 0)),       # (3,1,1) temporal conv: 8x2x4 tiles
+    (2, (12, 6, 10), 36, 20, (3, 1, 1), (1, 0, 0)),        # ... ragged
 ]
 
 

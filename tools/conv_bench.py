@@ -13,10 +13,12 @@ B, S, Cin, Cout = (int(v) for v in sys.argv[3:7]) if len(sys.argv) > 6 else (8, 
 _lib.load()
 dev = "cuda"
 x = torch.randn(B, S, S, S, Cin, device=dev)
-w = (torch.randn(Cout, Cin, 3, 3, 3, device=dev) * 0.02).requires_grad_()
+KS = tuple(int(v) for v in os.environ.get("KSHAPE", "3,3,3").split(","))      # filter extents (padding = k // 2)
+PADS = tuple(k // 2 for k in KS)
+w = (torch.randn(Cout, Cin, *KS, device=dev) * 0.02).requires_grad_()
 bias = torch.zeros(Cout, device=dev, requires_grad=True)
 dy = torch.randn(B, S, S, S, Cout, device=dev)
-flops = 2.0 * B * S ** 3 * Cin * Cout * 27
+flops = 2.0 * B * S ** 3 * Cin * Cout * KS[0] * KS[1] * KS[2]
 
 
 def timeit(fn, n):
@@ -34,11 +36,11 @@ def timeit(fn, n):
 
 if mode in ("fwd", "both"):
     with torch.no_grad():
-        ms = timeit(lambda: ops.conv3d(x, w, bias, (1, 1, 1)), iters)
+        ms = timeit(lambda: ops.conv3d(x, w, bias, PADS), iters)
     print(f"conv fwd  B={B} {S}^3 {Cin}->{Cout}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
 if mode in ("fwdh",):           # fp16 / bf16 operand kernel (LP=fp16|bf16)
     with torch.no_grad(), ops.low_precision(os.environ.get("LP", "fp16")):
-        ms = timeit(lambda: ops.conv3d(x, w, bias, (1, 1, 1)), iters)
+        ms = timeit(lambda: ops.conv3d(x, w, bias, PADS), iters)
     print(f"conv fwd {os.environ.get('LP', 'fp16')}  B={B} {S}^3 {Cin}->{Cout}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
     if os.environ.get("DIQT_CONVH_DBG") == "1":
         import ctypes
@@ -52,7 +54,7 @@ if mode in ("fwdh",):           # fp16 / bf16 operand kernel (LP=fp16|bf16)
         print("p10/p90 lifetime:", int(np.percentile(st[:, 4], 10)), int(np.percentile(st[:, 4], 90)))
 if mode in ("bwdw", "both"):
     xr = x.clone()
-    y = ops.conv3d(xr, w, bias, (1, 1, 1))
+    y = ops.conv3d(xr, w, bias, PADS)
 
     def bw():
         w.grad = None
@@ -68,6 +70,20 @@ if os.environ.get("DIQT_CONV_DBG") == "1" and mode == "bwdw":
     for _ in range(20):
         bw()
     torch.cuda.synchronize()
+    lib.diqt_debug_wgrad3_stamps.restype = ctypes.c_int
+    buf = np.zeros((65536, 8), dtype=np.uint64)
+    n3 = lib.diqt_debug_wgrad3_stamps(buf.ctypes.data_as(ctypes.c_void_p), 65536)
+    if n3 > 0:                      # version-3 kernel: one record per wave
+        st = buf[:n3].astype(np.int64).reshape(-1, 4, 8)
+        print(f"conv_wgrad3: {st.shape[0]} workgroups, {int(np.median(st[:, :, 7]))} tiles each; medians per wave (cycles):")
+        print("   wave taps   lifetime     k-loops  wait+barrier  prologue  epilogue   clock MHz   k-loop per tile / MFMA floor")
+        for wv in range(4):
+            r = st[:, wv]
+            clk = np.median(r[:, 0] / np.maximum(r[:, 5], 1) * 100.0)
+            floor = r[:, 6] * 16 * 64
+            print(f"   {wv}    {np.median(r[:, 6]) / 2:4.1f}  {np.median(r[:, 0]):10.0f}  {np.median(r[:, 1]):10.0f}  {np.median(r[:, 2]):10.0f}  "
+                  f"{np.median(r[:, 3]):8.0f}  {np.median(r[:, 4]):8.0f}  {clk:9.0f}   {np.median(r[:, 1] / r[:, 7]):8.0f} / {np.median(floor):6.0f}")
+        sys.exit(0)
     buf = np.zeros((65536, 8), dtype=np.uint64)
     n = lib.diqt_debug_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p), 65536)
     st = buf[:n, :6].astype(np.int64).reshape(-1, 8, 6)
@@ -82,7 +98,7 @@ if os.environ.get("DIQT_CONV_DBG") == "1":
     lib = _lib.load()
     with torch.no_grad():
         for _ in range(50):
-            ops.conv3d(x, w, bias, (1, 1, 1))
+            ops.conv3d(x, w, bias, PADS)
     torch.cuda.synchronize()
     buf = np.zeros((65536, 8), dtype=np.uint64)
     n = lib.diqt_debug_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p), 65536)

@@ -38,8 +38,8 @@ __device__ __forceinline__ float attn_bias_mask(float v, int j, int M, int E, in
 template <int ND>           // dim_head = 32 * ND
 __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                                const float* __restrict__ rel, const float* __restrict__ null_bias,
-                                                               float* __restrict__ out, int n, int h, int E, int ns, int causal,
-                                                               float scale) {
+                                                               float* __restrict__ out, float* __restrict__ lse, int n, int h, int E,
+                                                               int ns, int causal, float scale) {
     constexpr int D = 32 * ND, ROW = D + 4, NPF = AKT * (2 * D / 4) / 256;    // float4 pieces of a K|V tile per thread
     __shared__ __attribute__((aligned(16))) float KVs[2][2][AKT * ROW];       // [buffer][K | V][key][ROW]
     const int g = blockIdx.y;
@@ -67,8 +67,27 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
         for (int i = 0; i < 16; ++i) o[c][i] = 0.f;
     float mrun = -INFINITY, lrun = 0.f;
     const float nbv = null_bias ? null_bias[qh] : 0.f;
+    // A lone extra key (the learned null key: E == 1, every IQT call) is taken by the VALU instead of opening a 32-key MFMA tile
+    // for one row: the temporal attentions (n = 32 frames: 33 keys) halve their matrix work, the 8x8 spatial ones go from 3 tiles to 2.
+    const int kbase = (E == 1) ? 1 : 0;                    // kernel-uniform: first key handled by the tile loop
+    if (kbase) {
+        float s0 = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < D / 8; ++gq) {
+            const float4 kk = *reinterpret_cast<const float4*>(kvg + 8 * gq + 4 * hf);
+            s0 = fmaf(qreg[4 * gq], kk.x, s0); s0 = fmaf(qreg[4 * gq + 1], kk.y, s0);
+            s0 = fmaf(qreg[4 * gq + 2], kk.z, s0); s0 = fmaf(qreg[4 * gq + 3], kk.w, s0);
+        }
+        s0 += __shfl_xor(s0, 32, 64);
+        mrun = s0 + nbv;                                   // its probability against the running maximum is exp(0) = 1
+        lrun = 1.f;
+#pragma unroll
+        for (int c = 0; c < ND; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[c][i] = kvg[D + 32 * c + (i & 3) + 8 * (i >> 2) + 4 * hf];
+    }
 
-    // K | V tile of keys [32t, 32t+32): kv row = [k(D) | v(D)].  The next tile is loaded global -> registers BEFORE this tile's
+    // K | V tile of keys [kbase + 32t, kbase + 32t + 32): kv row = [k(D) | v(D)].  The next tile is loaded global -> registers BEFORE this tile's
     // MFMAs and written to the other LDS buffer after them: one barrier per tile and no memory round trip between tiles.
     // Loads are unconditional (clamped key, zero-selected): a guarded load becomes an exec-masked branch with its own wait.
     float4 pre[NPF];
@@ -77,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
         for (int u = 0; u < NPF; ++u) {
             const int e = u * 256 + tid;
             const int key = e / (2 * D / 4), c4 = (e % (2 * D / 4)) * 4;
-            const int j = t * AKT + key;
+            const int j = kbase + t * AKT + key;
             const float4 v = *reinterpret_cast<const float4*>(kvg + (size_t)min(j, M - 1) * 2 * D + c4);
             pre[u] = j < M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -91,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
             else *reinterpret_cast<float4*>(&KVs[buf][1][key * ROW + (c4 - D)]) = pre[u];
         }
     };
-    const int ntiles = (M + AKT - 1) / AKT;
+    const int ntiles = (M - kbase + AKT - 1) / AKT;
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -114,11 +133,11 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
         }
         // ---- bias, mask, online softmax (per lane = per query; rows of s are keys) ----
         float tmax = -INFINITY;
-        const bool plain = !causal && !rel && t * AKT >= E && (t + 1) * AKT <= M;     // every key of the tile is an unbiased self key
+        const bool plain = !causal && !rel && kbase + t * AKT >= E && kbase + (t + 1) * AKT <= M;     // every key of the tile is an unbiased self key
         if (!plain) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                s[i] = attn_bias_mask(s[i], t * AKT + (i & 3) + 8 * (i >> 2) + 4 * hf, M, E, ns, h, qi, qh, causal, rel, nbv);
+                s[i] = attn_bias_mask(s[i], kbase + t * AKT + (i & 3) + 8 * (i >> 2) + 4 * hf, M, E, ns, h, qi, qh, causal, rel, nbv);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
@@ -155,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
     // ---- epilogue: O^T rows are head-dim indices, columns are queries: out[g, r, dd] = o / l ----
     if (rvalid) {
         const float inv = 1.f / lrun;
+        if (lse && hf == 0) lse[(size_t)g * R + r] = mrun + __logf(lrun);      // log-sum-exp of the row: what the backward recomputes P from
         float* og = out + ((size_t)g * R + r) * D;
 #pragma unroll
         for (int c = 0; c < ND; ++c)
@@ -388,12 +408,31 @@ extern "C" int diqt_mqa_attention_fwd(const float* q, const float* kv, const flo
     DIQT_REQUIRE(G <= 65535, DIQT_E_SHAPE, "mqa_attention_fwd: G > 65535");
     const dim3 grid((unsigned)(((long long)n * h + AQ - 1) / AQ), G);
     if (d == 64)
-        hipLaunchKernelGGL(mqa_flash_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, n, h, n_extra,
+        hipLaunchKernelGGL(mqa_flash_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, (float*)nullptr, n, h,
+                           n_extra, n_self, causal, scale);
+    else
+        hipLaunchKernelGGL(mqa_flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, (float*)nullptr, n, h,
+                           n_extra, n_self, causal, scale);
+    return check_launch("mqa_attention_fwd");
+}
+
+extern "C" int diqt_mqa_attention_fwd_lse(const float* q, const float* kv, const float* rel, const float* null_bias, float* out, float* lse,
+                                          int G, int n, int h, int d, int n_extra, int n_self, int causal, float scale, void* stream) {
+    DIQT_REQUIRE(q && kv && out && lse, DIQT_E_ALIGN, "mqa_attention_fwd_lse: null pointer");
+    DIQT_REQUIRE(G > 0 && n > 0 && h > 0 && n_extra >= 0 && n_self >= 0 && n_extra + n_self > 0, DIQT_E_SHAPE, "mqa_attention_fwd_lse: bad shape");
+    DIQT_REQUIRE(d == 32 || d == 64, DIQT_E_UNSUPPORTED, "mqa_attention_fwd_lse: dim_head %d (32 or 64 are built)", d);
+    DIQT_REQUIRE(!(causal || rel) || n_self == n, DIQT_E_SHAPE, "mqa_attention_fwd_lse: causal / relative bias need n_self == n");
+    DIQT_REQUIRE(!null_bias || n_extra >= 1, DIQT_E_SHAPE, "mqa_attention_fwd_lse: null bias without a null key");
+    DIQT_REQUIRE(aligned16(q) && aligned16(kv) && aligned16(out), DIQT_E_ALIGN, "mqa_attention_fwd_lse: pointers must be 16-byte aligned");
+    DIQT_REQUIRE(G <= 65535, DIQT_E_SHAPE, "mqa_attention_fwd_lse: G > 65535");
+    const dim3 grid((unsigned)(((long long)n * h + AQ - 1) / AQ), G);
+    if (d == 64)
+        hipLaunchKernelGGL(mqa_flash_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, lse, n, h, n_extra,
                            n_self, causal, scale);
     else
-        hipLaunchKernelGGL(mqa_flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, n, h, n_extra,
+        hipLaunchKernelGGL(mqa_flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, lse, n, h, n_extra,
                            n_self, causal, scale);
-    return check_launch("mqa_attention_fwd");
+    return check_launch("mqa_attention_fwd_lse");
 }
 
 extern "C" int diqt_cast_to_h(const float* x, void* y, size_t n, int bf16, void* stream) {
@@ -423,4 +462,531 @@ extern "C" int diqt_mqa_attention_fwd_h(const float* q, const void* kv, const fl
     hipLaunchKernelGGL(k, grid, dim3(512), 0, (hipStream_t)stream, q, static_cast<const unsigned short*>(kv), rel, null_bias, out, n, h,
                        n_extra, n_self, causal, scale, round_out ? 1 : 0);
     return check_launch("mqa_attention_fwd_h");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Fused multi-query attention BACKWARD (training path of Attention.forward, /root/reference/imagen_video.py:410-525): the
+// [G, n*h, E+n] score / probability tensors are never written -- both kernels recompute S from q, k and the row log-sum-exp
+// the forward saved (diqt_mqa_attention_fwd_lse).  With P = softmax(S), S = scale q k^T + bias:
+//     dP = dO V^T,  delta = rowsum(dO . O),  dS = P . (dP - delta),  dQ = scale dS K,  dK = scale dS^T Q,  dV = P^T dO,
+//     d rel[i - j + n - 1][head] += dS,  d null_bias[head] += dS[null key].
+//  * mqa_flash_bwd_dq_kernel: the forward's transposed formulation, a wave owns 32 query rows as COLUMNS:
+//       S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T   (dS^T goes from the accumulator registers straight into the B operand).
+//    It also writes delta for the second kernel and accumulates the bias-gradient tables: per WAVE in LDS (no two lanes of
+//    one update instruction hit the same entry: the two lane halves -- keys 4 apart -- update one after the other), over all the
+//    batch entries a workgroup walks (persistent in g), then one row per wave in the workspace, summed in a fixed order.
+//  * mqa_flash_bwd_dkv_kernel: a wave owns 32 KEYS as columns and walks query tiles staged in its private LDS region
+//       S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS   (P and dS again straight from the accumulators);
+//    all heads' query rows feed the one shared K/V head.  Short sequences (<= 64 keys: the temporal and 8x8 spatial attentions)
+//    split the QUERY tiles over the 4 waves instead and combine the partial sums through LDS in a fixed order.
+// Deterministic: no atomics across waves, fixed summation orders.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int acc_row(int i, int hf) { return (i & 3) + 8 * (i >> 2) + 4 * hf; }
+
+template <int ND>
+__global__ __launch_bounds__(256, 2) void mqa_flash_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                                  const float* __restrict__ rel, const float* __restrict__ null_bias,
+                                                                  const float* __restrict__ out, const float* __restrict__ dout,
+                                                                  const float* __restrict__ lse, float* __restrict__ dq,
+                                                                  float* __restrict__ delta, float* __restrict__ tbl_part,
+                                                                  float* __restrict__ dnull_part, int G, int n, int h, int E, int ns,
+                                                                  int causal, float scale) {
+    constexpr int D = 32 * ND, ROW = D + 4, NPF = AKT * (2 * D / 4) / 256;
+    __shared__ __attribute__((aligned(16))) float KVs[2][2][AKT * ROW];
+    extern __shared__ float tbl_all[];                     // [4 waves][(2 ns - 1) * h] when rel
+    const int M = E + ns, R = n * h;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int r = blockIdx.x * AQ + wave * 32 + l31;
+    const bool rvalid = r < R;
+    const int rc = rvalid ? r : R - 1;
+    const int qi = rc / h, qh = rc % h;
+    const int TBL = rel ? (2 * ns - 1) * h : 0;
+    float* tbl = tbl_all + wave * TBL;
+    for (int e = lane; e < TBL; e += 64) tbl[e] = 0.f;
+    const float nbv = null_bias ? null_bias[qh] : 0.f;
+    const int kbase = (E == 1) ? 1 : 0;
+    const int ntiles = (M - kbase + AKT - 1) / AKT;
+    float dnb = 0.f;                                       // d null_bias contribution of this lane's query row (lane half 0 only)
+
+    for (int g = blockIdx.y; g < G; g += gridDim.y) {
+        const float* qg = q + ((size_t)g * R + rc) * D;
+        const float* og = out + ((size_t)g * R + rc) * D;
+        const float* dog = dout + ((size_t)g * R + rc) * D;
+        const float* kvg = kv + (size_t)g * M * 2 * D;
+        float qreg[D / 2], doreg[D / 2];
+        float dl = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < D / 8; ++gq) {
+            const float4 v = *reinterpret_cast<const float4*>(qg + 8 * gq + 4 * hf);
+            const float4 w = *reinterpret_cast<const float4*>(dog + 8 * gq + 4 * hf);
+            const float4 ov = *reinterpret_cast<const float4*>(og + 8 * gq + 4 * hf);
+            qreg[4 * gq] = v.x * scale; qreg[4 * gq + 1] = v.y * scale; qreg[4 * gq + 2] = v.z * scale; qreg[4 * gq + 3] = v.w * scale;
+            doreg[4 * gq] = w.x; doreg[4 * gq + 1] = w.y; doreg[4 * gq + 2] = w.z; doreg[4 * gq + 3] = w.w;
+            dl = fmaf(w.x, ov.x, dl); dl = fmaf(w.y, ov.y, dl); dl = fmaf(w.z, ov.z, dl); dl = fmaf(w.w, ov.w, dl);
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        const float L = lse[(size_t)g * R + rc];
+        if (rvalid && hf == 0) delta[(size_t)g * R + r] = dl;
+        f32x16 dqt[ND];
+#pragma unroll
+        for (int c = 0; c < ND; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dqt[c][i] = 0.f;
+
+        if (kbase) {                                       // the lone null key by VALU (see the forward)
+            float s0 = 0.f, dp0 = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < D / 8; ++gq) {
+                const float4 kk = *reinterpret_cast<const float4*>(kvg + 8 * gq + 4 * hf);
+                const float4 vv = *reinterpret_cast<const float4*>(kvg + D + 8 * gq + 4 * hf);
+                s0 = fmaf(qreg[4 * gq], kk.x, s0); s0 = fmaf(qreg[4 * gq + 1], kk.y, s0);
+                s0 = fmaf(qreg[4 * gq + 2], kk.z, s0); s0 = fmaf(qreg[4 * gq + 3], kk.w, s0);
+                dp0 = fmaf(doreg[4 * gq], vv.x, dp0); dp0 = fmaf(doreg[4 * gq + 1], vv.y, dp0);
+                dp0 = fmaf(doreg[4 * gq + 2], vv.z, dp0); dp0 = fmaf(doreg[4 * gq + 3], vv.w, dp0);
+            }
+            s0 += __shfl_xor(s0, 32, 64);
+            dp0 += __shfl_xor(dp0, 32, 64);
+            const float p0 = __expf(s0 + nbv - L);
+            const float ds0 = rvalid ? p0 * (dp0 - dl) : 0.f;
+            if (hf == 0) dnb += ds0;
+#pragma unroll
+            for (int c = 0; c < ND; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dqt[c][i] = ds0 * kvg[32 * c + acc_row(i, hf)];
+        }
+
+        float4 pre[NPF];
+        auto load_tile = [&](int t) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int e = u * 256 + tid;
+                const int key = e / (2 * D / 4), c4 = (e % (2 * D / 4)) * 4;
+                const int j = kbase + t * AKT + key;
+                const float4 v = *reinterpret_cast<const float4*>(kvg + (size_t)min(j, M - 1) * 2 * D + c4);
+                pre[u] = j < M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto store_tile = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int e = u * 256 + tid;
+                const int key = e / (2 * D / 4), c4 = (e % (2 * D / 4)) * 4;
+                if (c4 < D) *reinterpret_cast<float4*>(&KVs[buf][0][key * ROW + c4]) = pre[u];
+                else *reinterpret_cast<float4*>(&KVs[buf][1][key * ROW + (c4 - D)]) = pre[u];
+            }
+        };
+        __syncthreads();                                   // the previous batch entry's last tile is retired
+        if (ntiles > 0) { load_tile(0); store_tile(0); }
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            const float* Ks = KVs[t & 1][0];
+            const float* Vs = KVs[t & 1][1];
+            if (t + 1 < ntiles) load_tile(t + 1);
+            // ---- S^T = K Q^T and dP^T = V dO^T (rows = keys of the tile, columns = queries) ----
+            f32x16 s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            const float* kp = Ks + l31 * ROW + 4 * hf;
+            const float* vp4 = Vs + l31 * ROW + 4 * hf;
+#pragma unroll
+            for (int gq = 0; gq < D / 8; ++gq) {
+                const float4 a = *reinterpret_cast<const float4*>(kp + 8 * gq);
+                const float4 b = *reinterpret_cast<const float4*>(vp4 + 8 * gq);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * gq], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, doreg[4 * gq], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * gq + 1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, doreg[4 * gq + 1], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * gq + 2], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, doreg[4 * gq + 2], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * gq + 3], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, doreg[4 * gq + 3], dp, 0, 0, 0);
+            }
+            // ---- P^T = exp(S^T + bias - L), dS^T = P^T (dP^T - delta); bias-gradient tables ----
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = kbase + t * AKT + acc_row(i, hf);
+                const float sv = attn_bias_mask(s[i], j, M, E, ns, h, qi, qh, causal, rel, nbv);
+                const float p = (sv == -INFINITY) ? 0.f : __expf(sv - L);
+                s[i] = rvalid ? p * (dp[i] - dl) : 0.f;
+            }
+            if (rel || (null_bias && !kbase)) {            // kernel-uniform
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (hf == half && rvalid) {        // rows beyond R are clamped onto the last row: they must not take part in its update
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int j = kbase + t * AKT + acc_row(i, hf);
+                            if (j >= E && j < M) {
+                                if (rel) {
+                                    const int idx = max(0, min(qi - (j - E) + ns - 1, 2 * ns - 2));
+                                    tbl[idx * h + qh] += s[i];          // masked entries carry dS = 0
+                                }
+                            } else if (j == E - 1 && null_bias) dnb += s[i];
+                        }
+                    }
+                }
+            }
+            // ---- dQ^T += K^T dS^T : step i uses the key pair held in register i of the two lane halves ----
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float* kq = Ks + acc_row(i, hf) * ROW + l31;
+#pragma unroll
+                for (int c = 0; c < ND; ++c) dqt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kq[32 * c], s[i], dqt[c], 0, 0, 0);
+            }
+            if (t + 1 < ntiles) store_tile((t + 1) & 1);
+            __syncthreads();
+        }
+        if (rvalid) {
+            float* dqg = dq + ((size_t)g * R + r) * D;
+#pragma unroll
+            for (int c = 0; c < ND; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    const int dd = 32 * c + 8 * (i >> 2) + 4 * hf;
+                    *reinterpret_cast<float4*>(dqg + dd) = make_float4(dqt[c][i] * scale, dqt[c][i + 1] * scale, dqt[c][i + 2] * scale, dqt[c][i + 3] * scale);
+                }
+        }
+    }
+    // ---- bias-gradient partials of this wave: one row of the workspace each ----
+    const size_t wrow = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    if (TBL) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // this wave's own LDS updates are done (in-order LDS queue)
+        for (int e = lane; e < TBL; e += 64) tbl_part[wrow * TBL + e] = tbl[e];
+    }
+    if (dnull_part && hf == 0) dnull_part[wrow * 32 + l31] = dnb;
+}
+
+// drel[idx][head] = sum over the per-wave rows; dnull[head] = sum over rows and over the lanes whose query row has that head.
+// Fixed summation orders.  Blocks 0 .. nTblBlocks-1 own 64 table entries each (4 waves x a quarter of the rows, 8 loads in flight);
+// the last block sums the null-bias partials (every thread its own entries into a private LDS column, then columns in thread order).
+__global__ __launch_bounds__(256) void attn_bias_reduce_kernel(const float* __restrict__ tbl_part, const float* __restrict__ dnull_part,
+                                                               float* __restrict__ drel, float* __restrict__ dnull, int rows, int TBL,
+                                                               int gx, int h, int R, int nTblBlocks) {
+    extern __shared__ float red_sm[];                      // max(4 * 64, 256 * h) floats
+    if ((int)blockIdx.x < nTblBlocks) {
+        const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+        const int e = blockIdx.x * 64 + lane;
+        const int k0 = sg * rows / 4, k1 = (sg + 1) * rows / 4;
+        float s = 0.f;
+        if (e < TBL) {
+            int k = k0;
+            for (; k + 8 <= k1; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = tbl_part[(size_t)(k + u) * TBL + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < k1; ++k) s += tbl_part[(size_t)k * TBL + e];
+        }
+        red_sm[sg * 64 + lane] = s;
+        __syncthreads();
+        if (sg == 0 && e < TBL) drel[e] = ((red_sm[lane] + red_sm[64 + lane]) + red_sm[128 + lane]) + red_sm[192 + lane];
+        return;
+    }
+    if (dnull) {
+        for (int hh = 0; hh < h; ++hh) red_sm[threadIdx.x * h + hh] = 0.f;
+        const int total = rows * 32;
+        for (int e2 = threadIdx.x; e2 < total; e2 += 256) {
+            const int row = e2 / 32, l = e2 % 32;          // row = (by * gx + bx) * 4 + wave
+            const int bx = (row / 4) % gx, wave = row % 4;
+            const int r = bx * AQ + wave * 32 + l;
+            if (r < R) red_sm[threadIdx.x * h + r % h] += dnull_part[e2];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < h) {
+            float sacc = 0.f;
+            for (int t2 = 0; t2 < 256; ++t2) sacc += red_sm[t2 * h + threadIdx.x];
+            dnull[threadIdx.x] = sacc;
+        }
+    }
+}
+
+template <int ND>
+__global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                                   const float* __restrict__ rel, const float* __restrict__ null_bias,
+                                                                   const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                   const float* __restrict__ delta, float* __restrict__ dkv, int n, int h,
+                                                                   int E, int ns, int causal, float scale, int KW) {
+    constexpr int D = 32 * ND, ROW = D + 4, NPQ = 32 * D / 4 / 64;       // float4 pieces of a 32-row tile per lane
+    extern __shared__ __attribute__((aligned(16))) float smem_dkv[];
+    const int g = blockIdx.y;
+    const int M = E + ns, R = n * h;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int QW = 4 / KW;                                 // waves that share a key tile and split the query tiles
+    const int kt = blockIdx.x * KW + wave % KW, qw = wave / KW;
+    // a lone null key (E == 1) is taken by the VALU (below) instead of costing a 32-key tile of its own
+    const int kbase = (E == 1) ? 1 : 0;
+    const int j = kbase + kt * 32 + l31;                   // this lane's key (column)
+    const bool jvalid = j < M;
+    const int jc = jvalid ? j : M - 1;
+    const float* kvg = kv + ((size_t)g * M + jc) * 2 * D;
+    float* Qs = smem_dkv + (size_t)wave * (2 * 32 * ROW + 128);      // wave-private: Q tile, dO tile, lse, delta, p0, ds0 of 32 query rows
+    float* dOs = Qs + 32 * ROW;
+    float* Ls = dOs + 32 * ROW;
+    float* Dls = Ls + 32;
+    float* P0s = Dls + 32;
+    float* dS0s = P0s + 32;
+
+    // K^T and V^T operands (k-index dd = 8 gq + 4 hf + e, like qreg in the forward); K carries the soft-max scale
+    float kreg[D / 2], vreg[D / 2];
+#pragma unroll
+    for (int gq = 0; gq < D / 8; ++gq) {
+        const float4 a = *reinterpret_cast<const float4*>(kvg + 8 * gq + 4 * hf);
+        const float4 b = *reinterpret_cast<const float4*>(kvg + D + 8 * gq + 4 * hf);
+        kreg[4 * gq] = a.x * scale; kreg[4 * gq + 1] = a.y * scale; kreg[4 * gq + 2] = a.z * scale; kreg[4 * gq + 3] = a.w * scale;
+        vreg[4 * gq] = b.x; vreg[4 * gq + 1] = b.y; vreg[4 * gq + 2] = b.z; vreg[4 * gq + 3] = b.w;
+    }
+    f32x16 dkt[ND], dvt[ND];
+#pragma unroll
+    for (int c = 0; c < ND; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dkt[c][i] = 0.f; dvt[c][i] = 0.f; }
+    const bool doNull = kbase && kt == 0;                  // wave-uniform: the waves of key tile 0 also own the null key row
+    const float* kv0 = kv + (size_t)g * M * 2 * D;         // the null key / value row
+    float dkn = 0.f, dvn = 0.f;                            // d k_null[lane], d v_null[lane] (lane = head-dim index, lanes < D)
+
+    const int nqt = (R + 31) / 32;
+    const bool active = kbase + kt * 32 < M || doNull;     // wave-uniform
+    typedef float f32x4v __attribute__((ext_vector_type(4)));      // plain vector registers (HIP's float4 class kept these arrays in scratch)
+    f32x4v pq[NPQ], pdo[NPQ];
+    float pl = 0.f, pdl = 0.f;
+    auto load_q = [&](int qt) __attribute__((always_inline)) {      // next query tile -> registers (unconditional, clamped rows)
+        const int r0 = qt * 32;
+#pragma unroll
+        for (int u = 0; u < NPQ; ++u) {
+            const int e = u * 64 + lane;
+            const int row = e / (D / 4), c4 = (e % (D / 4)) * 4;
+            const int rr = min(r0 + row, R - 1);
+            pq[u] = *reinterpret_cast<const f32x4v*>(q + ((size_t)g * R + rr) * D + c4);
+            pdo[u] = *reinterpret_cast<const f32x4v*>(dout + ((size_t)g * R + rr) * D + c4);
+        }
+        const int rr = min(r0 + l31, R - 1);
+        pl = lse[(size_t)g * R + rr];
+        pdl = delta[(size_t)g * R + rr];
+    };
+    // causal: a query tile whose largest token index is below the key tile's smallest self-key index sees only masked scores
+    auto tile_live = [&](int qt) __attribute__((always_inline)) { return !(causal && !doNull && (kt * 32 + kbase - E) > (min(qt * 32 + 31, R - 1)) / h); };
+    int qt = qw;
+    if (active) {
+        while (qt < nqt && !tile_live(qt)) qt += QW;
+        if (qt < nqt) load_q(qt);
+    }
+    if (active)
+    while (qt < nqt) {
+        const int r0 = qt * 32;
+        // ---- registers -> the wave-private LDS tile (no workgroup barrier: the LDS queue of a wave is in order) ----
+#pragma unroll
+        for (int u = 0; u < NPQ; ++u) {
+            const int e = u * 64 + lane;
+            const int row = e / (D / 4), c4 = (e % (D / 4)) * 4;
+            *reinterpret_cast<f32x4v*>(Qs + row * ROW + c4) = pq[u];
+            *reinterpret_cast<f32x4v*>(dOs + row * ROW + c4) = pdo[u];
+        }
+        if (lane < 32) { Ls[lane] = pl; Dls[lane] = pdl; }
+        int qn = qt + QW;
+        while (qn < nqt && !tile_live(qn)) qn += QW;
+        if (qn < nqt) load_q(qn);                          // in flight during this tile's MFMAs
+        const float* qp = Qs + l31 * ROW + 4 * hf;
+        const float* dop = dOs + l31 * ROW + 4 * hf;
+        if (doNull) {
+            // scores of the null key for the 32 rows: lane (row l31, half hf) sums its half of the head dimension
+            float s0 = 0.f, dp0 = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < D / 8; ++gq) {
+                const float4 a = *reinterpret_cast<const float4*>(qp + 8 * gq);
+                const float4 b = *reinterpret_cast<const float4*>(dop + 8 * gq);
+                const float4 kk = *reinterpret_cast<const float4*>(kv0 + 8 * gq + 4 * hf);
+                const float4 vv = *reinterpret_cast<const float4*>(kv0 + D + 8 * gq + 4 * hf);
+                s0 = fmaf(a.x, kk.x, s0); s0 = fmaf(a.y, kk.y, s0); s0 = fmaf(a.z, kk.z, s0); s0 = fmaf(a.w, kk.w, s0);
+                dp0 = fmaf(b.x, vv.x, dp0); dp0 = fmaf(b.y, vv.y, dp0); dp0 = fmaf(b.z, vv.z, dp0); dp0 = fmaf(b.w, vv.w, dp0);
+            }
+            s0 += __shfl_xor(s0, 32, 64);
+            dp0 += __shfl_xor(dp0, 32, 64);
+            const int rr = r0 + l31;
+            const float nbv0 = null_bias ? null_bias[min(rr, R - 1) % h] : 0.f;
+            const float p0 = rr < R ? __expf(s0 * scale + nbv0 - Ls[l31]) : 0.f;
+            if (hf == 0) { P0s[l31] = p0; dS0s[l31] = p0 * (dp0 - Dls[l31]); }
+            // lane = head-dim index: column sums over the 32 rows
+            if (lane < D) {
+#pragma unroll 8
+                for (int rq = 0; rq < 32; ++rq) {
+                    dvn = fmaf(P0s[rq], dOs[rq * ROW + lane], dvn);
+                    dkn = fmaf(dS0s[rq], Qs[rq * ROW + lane], dkn);
+                }
+            }
+        }
+        if (kbase + kt * 32 < M) {                         // wave-uniform: this wave has self keys (a lone-null-key launch may not)
+        // ---- S = Q K^T, dP = dO V^T (rows = queries of the tile, columns = this wave's keys) ----
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int gq = 0; gq < D / 8; ++gq) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + 8 * gq);
+            const float4 b = *reinterpret_cast<const float4*>(dop + 8 * gq);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kreg[4 * gq], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, vreg[4 * gq], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kreg[4 * gq + 1], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, vreg[4 * gq + 1], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kreg[4 * gq + 2], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, vreg[4 * gq + 2], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kreg[4 * gq + 3], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, vreg[4 * gq + 3], dp, 0, 0, 0);
+        }
+        // ---- P = exp(S + bias - L[row]), dS = P (dP - delta[row]) ----
+        f32x16 ds;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = acc_row(i, hf), rr = r0 + row;
+            const int rcl = min(rr, R - 1);
+            const int qi = rcl / h, qh = rcl % h;
+            const float nbv = null_bias ? null_bias[qh] : 0.f;
+            const float sv = attn_bias_mask(s[i], j, M, E, ns, h, qi, qh, causal, rel, nbv);
+            const float p = (sv == -INFINITY || rr >= R) ? 0.f : __expf(sv - Ls[row]);
+            s[i] = p;
+            ds[i] = p * (dp[i] - Dls[row]);
+        }
+        // ---- dV^T += dO^T P, dK^T += Q^T dS : step i contracts the query pair held in register i of the two lane halves ----
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = acc_row(i, hf);
+            const float* dor = dOs + row * ROW + l31;
+            const float* qr = Qs + row * ROW + l31;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                dvt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(dor[32 * c], s[i], dvt[c], 0, 0, 0);
+                dkt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[32 * c], ds[i], dkt[c], 0, 0, 0);
+            }
+        }
+        }
+        qt = qn;
+    }
+    // ---- combine the partial sums of the waves that share a key tile (fixed order: query split 1, 2, 3 onto 0) ----
+    if (QW > 1) {
+        __syncthreads();                                   // every wave is done with its staging region
+        float* red = smem_dkv;                             // region of wave w (qw > 0) at (w - KW): [2 ND][16][64] + [2][64] floats
+        const size_t per = (size_t)2 * ND * 16 * 64 + 128;
+        if (qw > 0) {
+            float* dst = red + (size_t)(wave - KW) * per;
+#pragma unroll
+            for (int c = 0; c < ND; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { dst[((c * 2) * 16 + i) * 64 + lane] = dkt[c][i]; dst[((c * 2 + 1) * 16 + i) * 64 + lane] = dvt[c][i]; }
+            dst[2 * ND * 16 * 64 + lane] = dkn;
+            dst[2 * ND * 16 * 64 + 64 + lane] = dvn;
+        }
+        __syncthreads();
+        if (qw == 0) {
+            for (int w2 = 1; w2 < QW; ++w2) {
+                const float* src = red + (size_t)(w2 * KW + wave - KW) * per;
+#pragma unroll
+                for (int c = 0; c < ND; ++c)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { dkt[c][i] += src[((c * 2) * 16 + i) * 64 + lane]; dvt[c][i] += src[((c * 2 + 1) * 16 + i) * 64 + lane]; }
+                dkn += src[2 * ND * 16 * 64 + lane];
+                dvn += src[2 * ND * 16 * 64 + 64 + lane];
+            }
+        }
+    }
+    if (qw == 0 && jvalid && kbase + kt * 32 < M) {
+        float* og = dkv + ((size_t)g * M + j) * 2 * D;
+#pragma unroll
+        for (int c = 0; c < ND; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                const int dd = 32 * c + 8 * (i >> 2) + 4 * hf;
+                // S = scale q k^T: kreg carried the scale for S, the gradient wrt k takes it once more
+                *reinterpret_cast<float4*>(og + dd) = make_float4(dkt[c][i] * scale, dkt[c][i + 1] * scale, dkt[c][i + 2] * scale, dkt[c][i + 3] * scale);
+                *reinterpret_cast<float4*>(og + D + dd) = make_float4(dvt[c][i], dvt[c][i + 1], dvt[c][i + 2], dvt[c][i + 3]);
+            }
+    }
+    if (qw == 0 && doNull && lane < D) {
+        float* og = dkv + (size_t)g * M * 2 * D;
+        og[lane] = dkn * scale;
+        og[D + lane] = dvn;
+    }
+}
+
+static int attn_bwd_rows(int G, int n, int h) {
+    const int gx = (int)(((long long)n * h + AQ - 1) / AQ), gy = G < 256 ? G : 256;
+    return gy * gx * 4;
+}
+
+extern "C" size_t diqt_mqa_attention_bwd_workspace_bytes(int G, int n, int h, int d, int n_extra, int n_self, int has_rel) {
+    if (G <= 0 || n <= 0 || h <= 0 || n_self < 0) return 0;
+    const size_t rows = (size_t)attn_bwd_rows(G, n, h);
+    const size_t tbl = has_rel ? (size_t)(2 * n_self - 1) * h : 0;
+    return ((size_t)G * n * h + rows * tbl + rows * 32) * sizeof(float);
+}
+
+// Backward of diqt_mqa_attention_fwd_lse.  dq: [G, n*h, d]; dkv: [G, n_extra + n_self, 2d] (every row written); drel: [2 n_self - 1, h]
+// or NULL; dnull: [h] or NULL (both only with rel / null_bias given).  workspace: diqt_mqa_attention_bwd_workspace_bytes.
+extern "C" int diqt_mqa_attention_bwd(const float* q, const float* kv, const float* rel, const float* null_bias, const float* out,
+                                      const float* dout, const float* lse, float* dq, float* dkv, float* drel, float* dnull,
+                                      void* workspace, size_t workspace_bytes, int G, int n, int h, int d, int n_extra, int n_self,
+                                      int causal, float scale, void* stream) {
+    DIQT_REQUIRE(q && kv && out && dout && lse && dq && dkv && workspace, DIQT_E_ALIGN, "mqa_attention_bwd: null pointer");
+    DIQT_REQUIRE(G > 0 && n > 0 && h > 0 && n_extra >= 0 && n_self >= 0 && n_extra + n_self > 0, DIQT_E_SHAPE, "mqa_attention_bwd: bad shape");
+    DIQT_REQUIRE(d == 32 || d == 64, DIQT_E_UNSUPPORTED, "mqa_attention_bwd: dim_head %d (32 or 64 are built)", d);
+    DIQT_REQUIRE(!(causal || rel) || n_self == n, DIQT_E_SHAPE, "mqa_attention_bwd: causal / relative bias need n_self == n");
+    DIQT_REQUIRE(!null_bias || n_extra >= 1, DIQT_E_SHAPE, "mqa_attention_bwd: null bias without a null key");
+    DIQT_REQUIRE(!rel || drel, DIQT_E_ALIGN, "mqa_attention_bwd: relative bias without a gradient buffer");
+    DIQT_REQUIRE(!null_bias || dnull, DIQT_E_ALIGN, "mqa_attention_bwd: null bias without a gradient buffer");
+    DIQT_REQUIRE(aligned16(q) && aligned16(kv) && aligned16(out) && aligned16(dout) && aligned16(dq) && aligned16(dkv) && aligned16(workspace),
+                 DIQT_E_ALIGN, "mqa_attention_bwd: pointers must be 16-byte aligned");
+    DIQT_REQUIRE(G <= 65535, DIQT_E_SHAPE, "mqa_attention_bwd: G > 65535");
+    const size_t need = diqt_mqa_attention_bwd_workspace_bytes(G, n, h, d, n_extra, n_self, rel ? 1 : 0);
+    DIQT_REQUIRE(workspace_bytes >= need, DIQT_E_WORKSPACE, "mqa_attention_bwd: workspace %zu < %zu", workspace_bytes, need);
+    const int TBL = rel ? (2 * n_self - 1) * h : 0;
+    DIQT_REQUIRE((size_t)4 * TBL * sizeof(float) <= 24 * 1024, DIQT_E_UNSUPPORTED,
+                 "mqa_attention_bwd: relative-bias table of %d entries per wave does not fit the LDS budget", TBL);
+    hipStream_t s = (hipStream_t)stream;
+    const int R = n * h, M = n_extra + n_self;
+    const int gx = (R + AQ - 1) / AQ, gy = G < 256 ? G : 256, rows = gy * gx * 4;
+    float* delta = static_cast<float*>(workspace);
+    float* tbl_part = delta + (size_t)G * R;
+    float* dnull_part = tbl_part + (size_t)rows * TBL;
+    {
+        const dim3 grid(gx, gy);
+        const size_t lds = (size_t)4 * TBL * sizeof(float);
+        if (d == 64)
+            hipLaunchKernelGGL(mqa_flash_bwd_dq_kernel<2>, grid, dim3(256), lds, s, q, kv, rel, null_bias, out, dout, lse, dq, delta, tbl_part,
+                               null_bias ? dnull_part : (float*)nullptr, G, n, h, n_extra, n_self, causal, scale);
+        else
+            hipLaunchKernelGGL(mqa_flash_bwd_dq_kernel<1>, grid, dim3(256), lds, s, q, kv, rel, null_bias, out, dout, lse, dq, delta, tbl_part,
+                               null_bias ? dnull_part : (float*)nullptr, G, n, h, n_extra, n_self, causal, scale);
+        int rc = check_launch("mqa_attention_bwd(dq)");
+        if (rc) return rc;
+    }
+    if (rel || null_bias) {
+        const int ntb = rel ? (TBL + 63) / 64 : 0;
+        const size_t lds_r = (size_t)(256 * h > 256 ? 256 * h : 256) * sizeof(float);
+        hipLaunchKernelGGL(attn_bias_reduce_kernel, dim3((unsigned)(ntb + (null_bias ? 1 : 0))), dim3(256), lds_r, s, tbl_part, dnull_part,
+                           rel ? drel : (float*)nullptr, null_bias ? dnull : (float*)nullptr, rows, TBL, gx, h, R, ntb);
+        int rc = check_launch("mqa_attention_bwd(bias reduce)");
+        if (rc) return rc;
+    }
+    {
+        const int Mt = M - (n_extra == 1 ? 1 : 0);              // keys that go through the MFMA tiles (a lone null key is VALU work)
+        // key tiles per workgroup; the other 4 / KW waves split the query tiles.  Few batch entries (the joint 2048-token attentions:
+        // G = 8) need the finer split to fill 256 CUs: every workgroup walks ALL query rows of its batch entry.
+        int KW = Mt <= 32 ? 1 : (Mt <= 64 ? 2 : 4);
+        while (KW > 1 && (long long)((Mt + 32 * KW - 1) / (32 * KW)) * G < 512) KW >>= 1;
+        const int nkt = Mt > 0 ? (Mt + 32 * KW - 1) / (32 * KW) : 1;
+        const dim3 grid((unsigned)nkt, G);
+        const int ROW = d + 4;
+        size_t lds = (size_t)4 * (2 * 32 * ROW + 128) * sizeof(float);
+        const size_t red = (size_t)(4 - KW) * (2 * (d / 32) * 16 * 64 + 128) * sizeof(float);
+        if (red > lds) lds = red;
+        auto kern = d == 64 ? mqa_flash_bwd_dkv_kernel<2> : mqa_flash_bwd_dkv_kernel<1>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "mqa_attention_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, kv, rel, null_bias, dout, lse, delta, dkv, n, h, n_extra, n_self, causal, scale, KW);
+        return check_launch("mqa_attention_bwd(dkv)");
+    }
 }

@@ -11,6 +11,8 @@ share K/V, so QK^T is ONE GEMM with M = tokens x heads).
 import math
 from functools import partial
 
+import os
+
 import torch
 from torch import nn
 
@@ -154,6 +156,9 @@ class DynamicPositionBias(nn.Module):
         return pos
 
 
+_UNFUSED_ATTN = os.environ.get("DIQT_UNFUSED_ATTN") == "1"     # A/B switch: training attention through GEMM -> soft-max -> GEMM
+
+
 class Attention(nn.Module):
     """Multi-query attention with a learned null key/value, optional conditioning tokens as extra keys, optional
     relative position bias + causal mask (imagen_video.py:410-525).  x: [G, n, dim]."""
@@ -201,6 +206,10 @@ class Attention(nn.Module):
             out = ops.mqa_attention_nograd(q.contiguous(), kv_ext.reshape(G, M, 2 * d).contiguous(),
                                            rel.contiguous() if exists(rel) else None,
                                            null_bias.contiguous() if exists(null_bias) else None, n, h, d, E, n, self.causal, self.scale)
+            return self.to_out(out)
+        if not _UNFUSED_ATTN and ops.mqa_attention_fused_ok(G, n, h, d, n, exists(rel)):
+            # training path: the same fused kernel family with autograd (flash-style backward, no materialised scores)
+            out = ops.mqa_attention(q, kv_ext.reshape(G, M, 2 * d), rel, null_bias, n, h, d, E, n, self.causal, self.scale)
             return self.to_out(out)
         sim = ops.bmm_strided(q, kv_ext, (G, n * h, M, d, False, True, n * h * d, d, M * 2 * d, 2 * d, n * h * M, M,
                                           self.scale, (G, n, h, M), 0, 0))

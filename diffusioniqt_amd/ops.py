@@ -1039,6 +1039,49 @@ def mqa_attention_nograd(q, kv_ext, rel, null_bias, n, h, d, n_extra, n_self, ca
     return out
 
 
+class _MqaAttentionFn(Function):
+    """Fused multi-query attention with autograd (training path): scores and probabilities never reach HBM, the backward
+    recomputes them from the row log-sum-exp (diqt_mqa_attention_fwd_lse / diqt_mqa_attention_bwd)."""
+    @staticmethod
+    def forward(ctx, q, kv_ext, rel, null_bias, n, h, d, n_extra, n_self, causal, scale):
+        _chk(q, kv_ext, rel, null_bias)
+        G = q.shape[0]
+        out = torch.empty((G, n, h * d), dtype=torch.float32, device=q.device)
+        lse = torch.empty((G, n * h), dtype=torch.float32, device=q.device)
+        _lib.call("diqt_mqa_attention_fwd_lse", q, kv_ext, rel, null_bias, out, lse, G, n, h, d, n_extra, n_self, int(causal),
+                  float(scale), _stream())
+        ctx.save_for_backward(q, kv_ext, rel, null_bias, out, lse)
+        ctx.cfg = (G, n, h, d, n_extra, n_self, int(causal), float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv_ext, rel, null_bias, out, lse = ctx.saved_tensors
+        G, n, h, d, n_extra, n_self, causal, scale = ctx.cfg
+        dout = dout.contiguous()
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv_ext)
+        drel = torch.empty_like(rel) if rel is not None else None
+        dnull = torch.empty_like(null_bias) if null_bias is not None else None
+        nws = _lib.query("diqt_mqa_attention_bwd_workspace_bytes", G, n, h, d, n_extra, n_self, int(rel is not None))
+        ws = _workspace(nws, q.device)
+        _lib.call("diqt_mqa_attention_bwd", q, kv_ext, rel, null_bias, out, dout, lse, dq, dkv, drel, dnull, ws, nws, G, n, h, d,
+                  n_extra, n_self, causal, scale, _stream())
+        return dq, dkv, drel, dnull, None, None, None, None, None, None, None
+
+
+def mqa_attention(q, kv_ext, rel, null_bias, n, h, d, n_extra, n_self, causal, scale):
+    """Fused multi-query attention WITH autograd.  q: [G, n, h*d]; kv_ext: [G, n_extra + n_self, 2d]; rel: [2n-1, h] or None."""
+    return _MqaAttentionFn.apply(q.contiguous(), kv_ext.contiguous(), rel.contiguous() if rel is not None else None,
+                                 null_bias.contiguous() if null_bias is not None else None, n, h, d, n_extra, n_self, bool(causal),
+                                 float(scale))
+
+
+def mqa_attention_fused_ok(G, n, h, d, n_self, has_rel):
+    """Shapes the fused training kernels take (otherwise: GEMM -> attn_softmax -> GEMM)."""
+    return d in (32, 64) and G <= 65535 and (not has_rel or 4 * (2 * n_self - 1) * h * 4 <= 24 * 1024)
+
+
 def attn_softmax(sim, rel, null_bias, n, h, n_extra, n_self, causal):
     """softmax over keys of sim[G, n, h, n_extra + n_self] with T5-style relative bias table rel[2n-1, h] on the self
     keys, null_bias[h] on the null key (last extra key) and an optional causal mask (imagen_video.py:490-518)."""

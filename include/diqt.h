@@ -401,6 +401,19 @@ int diqt_attn_softmax_bwd_ws(const float* p, const float* dp, float* dsim, float
  * out[G][n][h*d] = softmax(scale q.k + bias) v.  The [G, n*h, keys] score tensor is never materialised.  d = 32 or 64. */
 int diqt_mqa_attention_fwd(const float* q, const float* kv, const float* rel, const float* null_bias, float* out, int G,
                            int n, int h, int d, int n_extra, int n_self, int causal, float scale, void* stream);
+/* Training path of the same Attention.forward (imagen_video.py:483-520 `sim = einsum(...)`, `sim.softmax`, `einsum(attn, v)` and
+ * their autograd backward): the forward additionally writes lse[G][n*h] (row log-sum-exp), and the backward recomputes the
+ * probabilities from it instead of reading a stored [G, n*h, keys] tensor:
+ *   dq[G][n*h][d], dkv[G][n_extra + n_self][2d] (every row written: the extra rows carry the gradient of the null / context
+ *   keys), drel[2 n_self - 1][h] and dnull[h] (required iff rel / null_bias are given).
+ * Deterministic (no atomics; bias tables are summed per wave, then in a fixed order).  workspace: ..._bwd_workspace_bytes. */
+int diqt_mqa_attention_fwd_lse(const float* q, const float* kv, const float* rel, const float* null_bias, float* out, float* lse,
+                               int G, int n, int h, int d, int n_extra, int n_self, int causal, float scale, void* stream);
+size_t diqt_mqa_attention_bwd_workspace_bytes(int G, int n, int h, int d, int n_extra, int n_self, int has_rel);
+int diqt_mqa_attention_bwd(const float* q, const float* kv, const float* rel, const float* null_bias, const float* out,
+                           const float* dout, const float* lse, float* dq, float* dkv, float* drel, float* dnull,
+                           void* workspace, size_t workspace_bytes, int G, int n, int h, int d, int n_extra, int n_self,
+                           int causal, float scale, void* stream);
 
 /* Mixed-precision variant for torch.autocast (the reference's `einsum('b h i d, b j d -> b h i j')` and `einsum(attn, v)` run in
  * fp16 / bf16 there, its soft-max in fp32; imagen_video.py:483-520): q k^T and p v on v_mfma_f32_32x32x16_{f16,bf16} with fp32

@@ -506,6 +506,64 @@ def test_fused_mqa_attention_forward(ops, G, n, h, d, E, use_rel, causal):
     close(got, ref, tol=3e-5, what="fused MQA attention")
 
 
+def _mqa_ref(q, kv, rel, nb, n, h, d, E, causal, scale):
+    """float64 restatement of Attention.forward's products (imagen_video.py:483-520) on leaf tensors that require grad"""
+    G = q.shape[0]
+    qd = q.reshape(G, n, h, d)
+    k, v = kv[..., :d], kv[..., d:]
+    sim = torch.einsum('gihd,gjd->gihj', qd, k) * scale
+    if rel is not None:
+        i = torch.arange(n)[:, None]; j = torch.arange(n)[None, :]
+        bias = rel[(i - j + n - 1)].permute(0, 2, 1)[None]                                  # [1, n, h, n] indexed (i, hh, j)
+        sim = torch.cat((sim[..., :E - 1], sim[..., E - 1:E] + nb[None, None, :, None], sim[..., E:] + bias), dim=-1)
+    if causal:
+        i = torch.arange(n)[:, None]; j = torch.arange(n)[None, :]
+        mask = torch.cat((torch.zeros(n, E, dtype=torch.bool), j > i), dim=1)[None, :, None, :]
+        sim = sim.masked_fill(mask, float('-inf'))
+    return torch.einsum('gihj,gjd->gihd', sim.softmax(dim=-1), v).reshape(G, n, h * d)
+
+
+@pytest.mark.parametrize("G,n,h,d,E,use_rel,causal", [
+    (3, 32, 8, 64, 1, True, True),       # temporal attention of Unet3D: 32 frames + null key, causal, relative bias: key tile + VALU null key
+    (2, 64, 8, 64, 1, False, False),     # 8x8 spatial attention: 2 key tiles, the query tiles split over wave pairs
+    (2, 40, 4, 64, 1, False, False),     # ragged key / query tiles
+    (2, 33, 3, 32, 1, True, False),      # dim_head 32, heads that do not divide the wave, relative bias without mask
+    (1, 150, 2, 32, 3, False, False),    # context tokens in front of the null key (E = 3): all keys through the tile loop; > 128 keys
+    (2, 16, 8, 64, 2, True, True),       # E = 2 with bias and mask
+    (300, 8, 2, 32, 1, True, True),      # more batch entries than resident workgroups: the persistent walk of the dQ kernel
+    (1, 1, 8, 64, 1, True, True)])
+def test_fused_mqa_attention_backward(ops, G, n, h, d, E, use_rel, causal):
+    """diqt_mqa_attention_fwd_lse / diqt_mqa_attention_bwd (flash-style: no stored scores) against float64 autograd of the
+    reference formula: out, dq, dkv (incl. the null / context key rows), d rel-bias table, d null bias; run twice: bit-identical."""
+    gen = torch.Generator().manual_seed(G * 131 + n)
+    q = torch.randn(G, n, h * d, generator=gen)
+    kv = torch.randn(G, E + n, 2 * d, generator=gen)
+    rel = torch.randn(2 * n - 1, h, generator=gen) if use_rel else None
+    nb = torch.randn(h, generator=gen) if use_rel else None
+    up = torch.randn(G, n, h * d, generator=gen)
+    scale = d ** -0.5
+    leaf = lambda t: t.double().requires_grad_() if t is not None else None
+    qr, kvr, relr, nbr = leaf(q), leaf(kv), leaf(rel), leaf(nb)
+    ref = _mqa_ref(qr, kvr, relr, nbr, n, h, d, E, causal, scale)
+    ref.backward(up.double())
+    runs = []
+    for _ in range(2):
+        dl = lambda t: t.to(DEV).requires_grad_() if t is not None else None
+        qd, kvd, reld, nbd = dl(q), dl(kv), dl(rel), dl(nb)
+        out = ops.mqa_attention(qd, kvd, reld, nbd, n, h, d, E, n, causal, scale)
+        out.backward(up.to(DEV))
+        runs.append((out, qd.grad, kvd.grad, reld.grad if use_rel else None, nbd.grad if use_rel else None))
+    out, dq, dkv, drel, dnb = runs[0]
+    close(out, ref, tol=3e-5, what="fused MQA attention (training forward)")
+    close(dq, qr.grad, tol=1e-4, what="dq")
+    close(dkv, kvr.grad, tol=1e-4, what="dkv")
+    if use_rel:
+        close(drel, relr.grad, tol=1e-4, what="d rel-bias table")
+        close(dnb, nbr.grad, tol=1e-4, what="d null bias")
+    for a, b in zip(runs[0], runs[1]):
+        assert a is None or torch.equal(a, b), "fused attention backward is not run-to-run deterministic"
+
+
 def test_multi_accumulate_matches_per_tensor_adds(ops):
     """Gradient accumulation into the flat arena: one launch == the per-parameter `grad += new` adds (bit-exact)."""
     g = torch.Generator().manual_seed(11)

@@ -1,5 +1,5 @@
 """Per-shape time of the conv launches in one C2 sampler step and one training micro-step (HIP-event timed).
-   python tools/shape_profile.py [sample|train]"""
+   python tools/shape_profile.py [sample|train] [a|b]      (b: Family B Unet3D dim 64)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,23 +8,38 @@ from diffusioniqt_amd import ops, _lib
 from diffusioniqt_amd.imagen_pytorch3D import SRUnet256
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "sample"
+fam = sys.argv[2] if len(sys.argv) > 2 else "a"
 _lib.load()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 B, S = 8, 32
-unet = SRUnet256(**unet_kwargs(S)).to(dev)
+if fam == "b":
+    from bench import unet3d_kwargs
+    from diffusioniqt_amd.imagen_video import Unet3D
+    unet = Unet3D(**unet3d_kwargs()).to(dev)
+else:
+    unet = SRUnet256(**unet_kwargs(S)).to(dev)
 x = torch.randn(B, 1, S, S, S, device=dev)
 lr = torch.randn(B, 1, S, S, S, device=dev)
 t = torch.rand(B, device=dev)
 
 
+lt = torch.full((B,), 0.2, device=dev)
+
+
+def fwd():
+    if fam == "b":
+        return unet(x, t * 0.5, lowres_cond_img=lr, lowres_noise_times=lt)
+    return unet(x, None, t, lowres_cond_img=lr)
+
+
 def step():
     if mode == "sample":
         with torch.no_grad():
-            unet(x, None, t, lowres_cond_img=lr)
+            fwd()
     else:
         unet.zero_grad(set_to_none=True)
-        unet(x, None, t, lowres_cond_img=lr).square().mean().backward()
+        fwd().square().mean().backward()
 
 
 unet.train(mode == "train")

@@ -286,11 +286,12 @@ def bench_c5(args, torch, ops, device, world, timed, instrumented, roofline_of):
             last["out"] = elu.sample(batch_size=B, video_frames=64, use_tqdm=False)
 
     def short():                               # warm-up / instrumented pass: 2 Heun steps per stage (3 evals each)
-        elu.num_sample_steps = (2, 2)
+        keep = list(elu.hparams)
+        elu.hparams = [hp._replace(num_sample_steps=2) for hp in keep]
         try:
             cascade()
         finally:
-            elu.num_sample_steps = (n_steps, n_steps)
+            elu.hparams = keep
     short()
     dt = timed(cascade, W, K)
     assert tuple(last["out"].shape) == (B, 1, 64, 64, 64) and torch.isfinite(last["out"]).all()

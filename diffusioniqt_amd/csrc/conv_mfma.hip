@@ -49,9 +49,27 @@ struct ConvGeom {
     int chunksPerSplit;         // forward split-K over input-channel chunks (grid.y slices; == nChunks when unsplit)
     unsigned long long slabStride;   // floats between the split-K output slabs
     unsigned long long* dbg;    // diagnostic cycle stamps (NULL in production)
+    int subF;                   // > 0: the batch is a cube of subF^3 sub-volumes and halo voxels are read from the NEIGHBOUR sub-volume
 };
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Source voxel (index into x[B][D][H][W]) of input coordinate (iz, iy, ix) of batch entry b, or -1 for zero padding.
+// Neighbour mode (g.subF = f > 0; `boundary=True` of the reference, imagen_pytorch3D.py:37-46 boundary_pad): the batch holds the
+// f^3 sub-volumes of one merged (fA)^3 volume, entry n = b2 + f b3 + f^2 b4 with axis D <-> b2, H <-> b3, W <-> b4
+// (utils_mine.py:25-67); a coordinate one voxel outside a sub-volume is the edge voxel of its neighbour, and only the faces of the
+// merged volume are zero padded -- the conv reads what merge -> zero-pad -> overlapping split would have copied, without the copies.
+__device__ __forceinline__ int conv_src_voxel(const ConvGeom& g, int b, int iz, int iy, int ix) {
+    if (g.subF > 0) {
+        const int f = g.subF, A = g.D, S = f * A;
+        const int gz = (b % f) * A + iz, gy = ((b / f) % f) * A + iy, gx = (b / (f * f)) * A + ix;
+        if ((unsigned)gz >= (unsigned)S || (unsigned)gy >= (unsigned)S || (unsigned)gx >= (unsigned)S) return -1;
+        const int nb = gz / A + f * (gy / A) + f * f * (gx / A);
+        return ((nb * A + gz % A) * A + gy % A) * A + gx % A;
+    }
+    if (iz < 0 || iz >= g.D || iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) return -1;
+    return ((b * g.D + iz) * g.H + iy) * g.W + ix;
+}
 
 // ---------------------------------------------------------------------------------------------
 // weight packing: packed[((chunk*T + tap)*CoutPad + co)*32 + k]
@@ -154,11 +172,8 @@ __global__ __launch_bounds__(256, CKT == 16 ? 3 : 2) void conv_fwd_kernel(const 
     for (int hv = tid; hv < HV; hv += 256) {
         const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
         const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
-        int src = BUF ? (int)BUF_OOB : -1;
-        if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
-            src = ((b * g.D + iz) * g.H + iy) * g.W + ix;
-            if (BUF) src *= g.Cin * 4;           // byte offset of the input voxel's channel row
-        }
+        int src = conv_src_voxel(g, b, iz, iy, ix);
+        if (BUF) src = src < 0 ? (int)BUF_OOB : src * g.Cin * 4;           // byte offset of the input voxel's channel row
         halo_src[hv] = src;
     }
     // buffer descriptors (wave-uniform inputs only); the slab base of a split-K launch is folded into the y descriptor below
@@ -435,9 +450,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
         for (int hv = tid; hv < HV; hv += 512) {
             const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
             const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
-            int src = (int)BUF_OOB;
-            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) src = (((b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin * 4;
-            halo_src[slot * HV + hv] = src;
+            const int sv = conv_src_voxel(g, b, iz, iy, ix);
+            halo_src[slot * HV + hv] = sv < 0 ? (int)BUF_OOB : sv * g.Cin * 4;
         }
     };
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
@@ -799,10 +813,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_smallcin_kernel(const float* 
         const int hv = e / CINP, ci = e % CINP;
         const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
         const int iz = d0 + hz - g.pd, iy = h0 + hy - g.ph, ix = w0 + hx - g.pw;
-        float v = 0.f;
-        if (ci < g.Cin && iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-            v = x[(size_t)(((b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin + ci];
-        halo[e] = v;
+        const int sv = ci < g.Cin ? conv_src_voxel(g, b, iz, iy, ix) : -1;
+        halo[e] = sv >= 0 ? x[(size_t)sv * g.Cin + ci] : 0.f;
     }
     // the voxel this thread gathers for the im2col tile (rows 0..127, two 16-wide k halves)
     const int gv = tid & (MTILE - 1), ghalf = tid >> 7;
@@ -1495,6 +1507,7 @@ static int make_geom(ConvGeom& g, int B, int D, int H, int W, int Cin, int Cout,
         B = 1; D = 1; H = 1; W = (int)rows;
     }
     g.dbg = nullptr;
+    g.subF = 0;
     g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
     g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw;
     g.Do = D + 2 * pd + epd - kd + 1; g.Ho = H + 2 * ph + eph - kh + 1; g.Wo = W + 2 * pw + epw - kw + 1;
@@ -1705,6 +1718,28 @@ extern "C" int diqt_conv3d_fwd_ex(const float* x, const float* packed, const flo
                            epd, eph, epw, stream, stats);
 }
 
+static int conv3d_fwd_one(const float* x, const float* packed, const float* bias, const float* residual,
+                          float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                          int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats,
+                          int subF = 0);
+
+// 'same' convolution (odd cubic filter k, padding k / 2) over the f^3 sub-volume batch x[f^3][A][A][A][Cin] of ONE merged volume, the
+// halo of a sub-volume read in place from its neighbours (conv_src_voxel): what the reference computes as
+// boundary_pad(x) -> unpadded Conv3d (imagen_pytorch3D.py:37-46, 550-566 with boundary=True).  Same kernels, same bits per output
+// element as running the padded copies; workspace / stats as diqt_conv3d_fwd_ex for (B = f^3, D = H = W = A, pad = k / 2).
+extern "C" int diqt_conv3d_fwd_neighbours(const float* x, const float* packed, const float* bias, const float* residual, float* y,
+                                          float* stats, void* workspace, size_t workspace_bytes, int f, int A, int Cin, int Cout,
+                                          int k, void* stream) {
+    DIQT_REQUIRE(f >= 1 && A >= 1 && k >= 1 && (k & 1) && k / 2 <= A, DIQT_E_SHAPE, "conv3d_fwd_neighbours: bad shape (f %d, A %d, k %d)", f, A, k);
+    const int B = f * f * f, p = k / 2;
+    DIQT_REQUIRE((unsigned long long)B * A * A * A * (unsigned long long)(Cin > Cout ? Cin : Cout) * 4ull < (1ull << 30), DIQT_E_UNSUPPORTED,
+                 "conv3d_fwd_neighbours: the sub-volume batch must stay below 1 GiB (it cannot be cut into independent launches)");
+    DIQT_REQUIRE(!stats || diqt_conv3d_fwd_stats_blocks(B, A, A, A, Cin, Cout, k, k, k, p, p, p, 0, 0, 0) > 0, DIQT_E_UNSUPPORTED,
+                 "conv3d_fwd_neighbours: this shape does not produce output statistics");
+    return conv3d_fwd_one(x, packed, bias, residual, y, workspace, workspace_bytes, B, A, A, A, Cin, Cout, k, k, k, p, p, p, 0, 0, 0, stream,
+                          stats, f);
+}
+
 extern "C" int diqt_conv3d_fwd_ws(const float* x, const float* packed, const float* bias, const float* residual,
                                   float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin,
                                   int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw,
@@ -1713,9 +1748,6 @@ extern "C" int diqt_conv3d_fwd_ws(const float* x, const float* packed, const flo
                            pw, epd, eph, epw, stream, nullptr);
 }
 
-static int conv3d_fwd_one(const float* x, const float* packed, const float* bias, const float* residual,
-                          float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                          int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats);
 
 // The fast kernels address x and y through 32-bit buffer descriptors (tensors < 1 GiB).  Larger launches -- big patch batches are the
 // natural way to use 288 GB of HBM -- are cut into independent sub-launches below that size: row ranges for the flattened 1x1x1 /
@@ -1761,11 +1793,13 @@ static int conv3d_fwd_impl(const float* x, const float* packed, const float* bia
 
 static int conv3d_fwd_one(const float* x, const float* packed, const float* bias, const float* residual,
                           float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                          int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats) {
+                          int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats,
+                          int subF) {
     DIQT_REQUIRE(x && packed && y, DIQT_E_ALIGN, "conv3d_fwd: null pointer");
     ConvGeom g;
     int rc = make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw);
     if (rc) return rc;
+    g.subF = subF;
     g.chunksPerSplit = g.nChunks;
     g.slabStride = 0;
     DIQT_REQUIRE(aligned16(packed), DIQT_E_ALIGN, "conv3d_fwd: packed weights must be 16-byte aligned");

@@ -317,6 +317,11 @@ class Block(nn.Module):
             assert scale_shift is None
             x = self.activation(x)
         if self.boundary:
+            if not torch.is_grad_enabled():
+                # sampling: the conv reads each sub-volume's halo straight from its neighbours (no merged / re-split copies)
+                y = ops.conv3d_neighbours(x, self.project.weight, self.project.bias, self.factor, residual, emit_stats)
+                if y is not None:
+                    return y
             x = boundary_pad(x, self.factor)
         return self.project(x, residual=residual, want_stats=emit_stats)
 
@@ -905,9 +910,13 @@ class Unet(nn.Module):
             assert cond_images.shape[1] == self.cond_images_channels
             x = ops.concat_channels(to_channels_last(cond_images.float()), x)
 
-        if self.boundary:
-            x = boundary_pad(x)
-        x = self.init_conv(x)
+        if self.boundary and not torch.is_grad_enabled() and isinstance(self.init_conv, Conv3d) and \
+                (y0 := ops.conv3d_neighbours(x, self.init_conv.weight, self.init_conv.bias, self.batch_sample_factor)) is not None:
+            x = y0
+        else:
+            if self.boundary:
+                x = boundary_pad(x)
+            x = self.init_conv(x)
 
         t = TimeCond(self.to_time_cond(self.to_time_hiddens(time.float().contiguous())))
 

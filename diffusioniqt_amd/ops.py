@@ -311,6 +311,32 @@ def conv3d(x, weight, bias=None, padding=(0, 0, 0), residual=None, extra_pad=(0,
     return y
 
 
+def conv3d_neighbours(x, weight, bias, f, residual=None, want_stats=False):
+    """Inference-only 'same' conv over the f^3 sub-volume batch x[f^3, A, A, A, Cin] of one merged volume whose halo voxels come
+    from the NEIGHBOUR sub-volumes (zero only outside the merged volume) -- the reference's ``boundary_pad`` + unpadded Conv3d
+    (imagen_pytorch3D.py:37-46, 550-566) without the merge / pad / split copies.  No autograd: training keeps the copy path."""
+    _chk(x, weight, bias, residual)
+    assert not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad), 'conv3d_neighbours is the sampling path'
+    B, A, A2, A3, Cin = x.shape
+    Cout, Cin2, k, k2, k3 = weight.shape
+    assert B == f ** 3 and A == A2 == A3 and Cin == Cin2 and k == k2 == k3 and k % 2 == 1, (tuple(x.shape), tuple(weight.shape), f)
+    if lp_mode() is not None:          # mixed precision: the 16-bit kernel has no neighbour tables -- materialise the copies
+        return None
+    p = k // 2
+    geo = (B, A, A, A, Cin, Cout, k, k, k, p, p, p, 0, 0, 0)
+    y = torch.empty((B, A, A, A, Cout), dtype=torch.float32, device=x.device)
+    n = _lib.query("diqt_conv3d_fwd_workspace_bytes", *geo)
+    ws = _workspace(n, x.device) if n else None
+    stats = None
+    if want_stats:
+        nblk = _lib.query("diqt_conv3d_fwd_stats_blocks", *geo)
+        if nblk > 0:
+            stats = torch.empty((B, nblk, 2, Cout), dtype=torch.float32, device=x.device)
+            y._diqt_stats = ColStats(stats, nblk, A * A * A)
+    _lib.call("diqt_conv3d_fwd_neighbours", x, _packed(weight, 0), bias, residual, y, stats, ws, n, f, A, Cin, Cout, k, _stream())
+    return y
+
+
 class _LinearSmallFn(Function):
     """nn.Linear over <= 64 rows (time-conditioning MLPs): one wave per output column, no MFMA pipeline fill."""
     @staticmethod

@@ -108,6 +108,15 @@ int diqt_groupnorm_stats_from_partials(const float* partials, float* mean, float
                                        int C, int G, float eps, void* stream);
 int diqt_channel_mean_from_partials(const float* partials, float* pooled, int B, int nblk, int rows_per_batch, int C, void* stream);
 
+/* 'same' convolution (odd cubic filter k, padding k/2) over the f^3 sub-volume batch x[f^3][A][A][A][Cin] of ONE merged (fA)^3
+ * volume (entry n = b2 + f b3 + f^2 b4, utils_mine.py:25-67), each sub-volume's halo read IN PLACE from its neighbours and zero
+ * only outside the merged volume: the reference's boundary_pad (merge_sub_volumes -> F.pad -> overlapping unfold,
+ * imagen_pytorch3D.py:37-46) followed by the unpadded Conv3d of Block.forward (:550-566, boundary=True), without the merged and
+ * re-split copies.  Bit-identical to running those copies through diqt_conv3d_fwd_ex.  stats / workspace as diqt_conv3d_fwd_ex
+ * for (B = f^3, D = H = W = A, pad = k/2).  The batch must stay below 1 GiB. */
+int diqt_conv3d_fwd_neighbours(const float* x, const float* packed, const float* bias, const float* residual, float* y, float* stats,
+                               void* workspace, size_t workspace_bytes, int f, int A, int Cin, int Cout, int k, void* stream);
+
 /* Same operator with a caller-owned workspace: launches too small to fill the chip (8^3 / 16^3 levels) slice the
  * input-channel chunks over grid.y into output slabs and a second kernel sums them (+ bias + residual) in a fixed
  * order.  diqt_conv3d_fwd_workspace_bytes() returns 0 when the shape is not split.                              */

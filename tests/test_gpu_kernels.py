@@ -564,6 +564,40 @@ def test_fused_mqa_attention_backward(ops, G, n, h, d, E, use_rel, causal):
         assert a is None or torch.equal(a, b), "fused attention backward is not run-to-run deterministic"
 
 
+@pytest.mark.parametrize("f,A,Cin,Cout,k", [(3, 4, 16, 16, 3),      # 27 x 4^3 (the reference fixture's size): 4-wave kernel, split-K levels
+                                            (3, 8, 64, 64, 3),      # 27 x 8^3
+                                            (3, 16, 2, 16, 3),      # init conv: 2 input channels (tap-packed kernel)
+                                            (2, 16, 20, 24, 3),     # ragged channels, factor 2
+                                            (3, 32, 64, 64, 3),     # 27 x 32^3 (one 96^3 block of eval_config.yaml): 8-wave kernel, persistent walk
+                                            (3, 8, 32, 32, 5)])     # 5^3 filter: a 2-voxel halo from the neighbours
+def test_conv3d_neighbour_halo_equals_boundary_pad_copies(ops, f, A, Cin, Cout, k):
+    """diqt_conv3d_fwd_neighbours (halo voxels read in place from the neighbouring sub-volumes) is bit-identical to
+    the reference's formulation -- merge_sub_volumes -> zero pad -> overlapping split (boundary_pad, imagen_pytorch3D.py:37-46) ->
+    unpadded conv -- incl. bias, residual epilogue and the per-tile output statistics."""
+    gen = torch.Generator().manual_seed(f * 1000 + A)
+    B, p = f ** 3, k // 2
+    x = torch.randn(B, A, A, A, Cin, generator=gen).to(DEV)
+    w = (torch.randn(Cout, Cin, k, k, k, generator=gen) / math.sqrt(Cin * k ** 3)).to(DEV)
+    b = torch.randn(Cout, generator=gen).to(DEV)
+    r = torch.randn(B, A, A, A, Cout, generator=gen).to(DEV)
+    with torch.no_grad():
+        padded = ops.split_volume(ops.merge_volume(x, f), f, A, halo=p)                 # [f^3, A + 2p, ...]: the copies
+        ref = ops.conv3d(padded, w, b, (0, 0, 0), residual=r)
+        got = ops.conv3d_neighbours(x, w, b, f, residual=r)
+        assert torch.equal(got, ref), f"max diff {(got - ref).abs().max().item():.3e}"
+        got2 = ops.conv3d_neighbours(x, w, b, f, want_stats=True)
+        assert torch.equal(got2, ops.conv3d(padded, w, b, (0, 0, 0)))
+        st = getattr(got2, "_diqt_stats", None)
+        if st is not None:                                                                # the consumer's GroupNorm statistics ride along
+            sums = st.partials[:, :, 0, :].double().sum(1)
+            close(sums, got2.double().sum(dim=(1, 2, 3)), tol=1e-5, what="per-tile column sums")
+    # against a float64 conv of the merged, zero-padded volume
+    vol = ops.merge_volume(x, f)[0].permute(3, 0, 1, 2).double().cpu()[None]
+    full = F.conv3d(vol, w.double().cpu(), b.double().cpu(), padding=p)
+    want = ops.split_volume(full[0].permute(1, 2, 3, 0)[None].float().contiguous().to(DEV), f, A, 0)
+    close(ops.conv3d_neighbours(x, w, b, f), want, what="neighbour conv vs float64 conv of the merged volume")
+
+
 def test_multi_accumulate_matches_per_tensor_adds(ops):
     """Gradient accumulation into the flat arena: one launch == the per-parameter `grad += new` adds (bit-exact)."""
     g = torch.Generator().manual_seed(11)

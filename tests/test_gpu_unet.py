@@ -95,6 +95,9 @@ def test_unet_boundary_merged_volume_attention_factor3_matches_reference_golden(
     y = unet(T(g['x']).to(DEV), T(g['times']).to(DEV), T(g['log_snr']).to(DEV), lowres_cond_img=T(g['lowres']).to(DEV))
     rel = close(y, T(g['y']), 5e-4, f"boundary + merged attention ({kind}) fwd")
     assert rel <= 5e-5, rel
+    with torch.no_grad():      # sampling path: convs read the neighbours' voxels in place (no merge / pad / split copies): same bits
+        y_ng = unet(T(g['x']).to(DEV), T(g['times']).to(DEV), T(g['log_snr']).to(DEV), lowres_cond_img=T(g['lowres']).to(DEV))
+    assert torch.equal(y_ng, y.detach()), "neighbour-halo convs differ from the boundary_pad copies"
     (y ** 2).mean().backward()
     named = dict(unet.named_parameters())
     n = 0

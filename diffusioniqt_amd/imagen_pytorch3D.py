@@ -340,16 +340,45 @@ class SE3D(nn.Module):
 
 class TimeCond:
     """The time embedding handed to every ResnetBlock of one U-Net evaluation.  Each block's time_mlp starts with the
-    same Mish(t) (imagen_pytorch3D.py:575-578), so it is evaluated once here and shared."""
-    __slots__ = ("t", "_act")
+    same Mish(t) (imagen_pytorch3D.py:575-578), so it is evaluated once here and shared; on the sampling path the Linear
+    layers of ALL blocks then run as one launch over their concatenated weights (``batched``: id(linear) -> SSView)."""
+    __slots__ = ("t", "_act", "batched")
 
     def __init__(self, t):
-        self.t, self._act = t, None
+        self.t, self._act, self.batched = t, None, None
 
     def mish(self):
         if self._act is None:
             self._act = ops.mish(self.t)
         return self._act
+
+
+class BatchedTimeMLPs:
+    """Concatenation of the time-MLP Linear layers of a U-Net's ResnetBlocks (reference: one ``time_mlp`` call per block,
+    imagen_pytorch3D.py:586-589 -- ~20 launches of a [B, 256] x [256, 2C] product per eval): weights / biases are packed into one
+    [sum 2C_i, 256] matrix, rebuilt whenever a parameter changed, and applied with one skinny-linear launch."""
+
+    def __init__(self, linears):
+        self.linears = list(linears)
+        self.key, self.w, self.b, self.offs = None, None, None, None
+
+    def __call__(self, tc):
+        if not self.linears or tc.t.shape[0] > 64:
+            return None
+        key = tuple((l.weight.data_ptr(), l.weight._version, l.bias._version if l.bias is not None else -1) for l in self.linears) \
+            + (ops._WEIGHT_EPOCH,)
+        if key != self.key:
+            with torch.no_grad():
+                self.w = torch.cat([l.weight for l in self.linears], dim=0).contiguous()
+                self.b = torch.cat([l.bias if l.bias is not None else torch.zeros(l.weight.shape[0], device=l.weight.device)
+                                    for l in self.linears]).contiguous()
+            self.offs, off = {}, 0
+            for l in self.linears:
+                self.offs[id(l)] = (off, l.weight.shape[0])
+                off += l.weight.shape[0]
+            self.key = key
+        out = ops.linear(tc.mish(), self.w, self.b)                                   # ONE launch: [B, sum 2C_i]
+        return {k: ops.SSView(out, off, n) for k, (off, n) in self.offs.items()}
 
 
 class ResnetBlock(nn.Module):
@@ -368,7 +397,11 @@ class ResnetBlock(nn.Module):
     def forward(self, x, time_emb=None):
         scale_shift = None
         if exists(self.time_mlp) and exists(time_emb):      # [B, 2C]: scale | shift
-            scale_shift = self.time_mlp[1](time_emb.mish()) if isinstance(time_emb, TimeCond) else self.time_mlp(time_emb)
+            if isinstance(time_emb, TimeCond):
+                pre = time_emb.batched.get(id(self.time_mlp[1])) if time_emb.batched is not None else None
+                scale_shift = pre if pre is not None else self.time_mlp[1](time_emb.mish())
+            else:
+                scale_shift = self.time_mlp(time_emb)
         h = self.block1(x, emit_stats=True)                  # block2's GroupNorm statistics come from this conv's epilogue
         res = self.res_conv(x)
         if isinstance(self.se, SE3D):
@@ -919,6 +952,10 @@ class Unet(nn.Module):
             x = self.init_conv(x)
 
         t = TimeCond(self.to_time_cond(self.to_time_hiddens(time.float().contiguous())))
+        if not torch.is_grad_enabled():
+            if getattr(self, '_time_mlps', None) is None:
+                self._time_mlps = BatchedTimeMLPs(m.time_mlp[1] for m in self.modules() if isinstance(m, ResnetBlock) and m.time_mlp is not None)
+            t.batched = self._time_mlps(t)
 
         hiddens = []
         last = len(self.downs)

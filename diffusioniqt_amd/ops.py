@@ -419,10 +419,19 @@ def conv3d_direct(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), gro
 # --------------------------------------------------------------------------------------------
 # GroupNorm + scale/shift + activation
 # --------------------------------------------------------------------------------------------
+class SSView:
+    """Columns [off, off + width) of a batched time-MLP output ``base`` [B, sum of widths]: the (scale | shift) embedding of one
+    ResnetBlock when all blocks' time MLPs ran as ONE launch (sampling path)."""
+    __slots__ = ("base", "off", "width")
+
+    def __init__(self, base, off, width):
+        self.base, self.off, self.width = base, off, width
+
+
 class _GnActFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, ss, groups, act, eps, pre=None):
-        _chk(x, gamma, beta, ss)
+        _chk(x, gamma, beta, ss.base if isinstance(ss, SSView) else ss)
         B, C = x.shape[0], x.shape[-1]
         rows = x.numel() // (B * C)
         mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
@@ -437,6 +446,13 @@ class _GnActFn(Function):
         y = torch.empty_like(x)
         scale = shift = None
         cs = 0
+        if isinstance(ss, SSView):
+            # one row block of a batched time-MLP output [B, sum 2C_i] (sampling path, no autograd): columns off .. off + 2C
+            assert ss.width == 2 * C and ss.base.shape[0] == B and not torch.is_grad_enabled()
+            scale, cs = ss.base.data_ptr() + 4 * ss.off, ss.base.shape[1]
+            shift = scale + 4 * C
+            _lib.call("diqt_gn_act_fwd", x, mean, rstd, gamma, beta, scale, shift, cs, y, B, rows, C, groups, act, s)
+            return y
         if ss is not None:
             assert ss.shape == (B, 2 * C), f"scale/shift embedding must be [B, 2C], got {tuple(ss.shape)}"
             scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, 2 * C

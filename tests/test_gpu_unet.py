@@ -181,6 +181,26 @@ def test_unet_config2_shape_vs_oracle_fresh_inputs():
     assert rel <= 2e-5, rel
 
 
+def test_batched_time_mlps_equal_the_per_block_launches():
+    """K5: on the sampling path the ~20 per-block time MLPs (imagen_pytorch3D.py:586-589) run as ONE launch over concatenated
+    weights; the U-Net output is bit-identical to the per-block path (taken when autograd records), also after a weight update."""
+    g = load_golden('unetA_tiny')
+    unet, sd, cfg = build(g, 0)
+    unet.eval()
+    args = (T(g['x']).to(DEV), T(g['times']).to(DEV), T(g['log_snr']).to(DEV))
+    lr = T(g['lowres']).to(DEV)
+    for rnd in range(2):
+        with torch.no_grad():
+            y_b = unet(*args, lowres_cond_img=lr)
+        assert unet._time_mlps.w is not None and unet._time_mlps.w.shape[1] == 64      # time_cond_dim = 4 * dim
+        y_p = unet(*args, lowres_cond_img=lr).detach()
+        assert torch.equal(y_b, y_p), f"round {rnd}"
+        with torch.no_grad():                      # an in-place weight change must invalidate the packed copy
+            for m in unet.modules():
+                if hasattr(m, 'time_mlp') and m.time_mlp is not None:
+                    m.time_mlp[1].weight.mul_(1.5)
+
+
 @pytest.mark.parametrize("B", [2, 4])
 def test_unet_config2_at_32cubed_routes_through_conv_fwd8_vs_oracle(B):
     """The exact BASELINE config-2 network at its real 32^3 patch size: B=2 fills exactly one round of 256 workgroups of the

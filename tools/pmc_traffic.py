@@ -28,7 +28,7 @@ def collect(root, counter):
     return tot, cnt
 
 
-def main(fetch_dir, write_dir, out):
+def main(fetch_dir, write_dir, out, cmd=None):
     ft, fc = collect(fetch_dir, "FETCH_SIZE")
     wt, wc = collect(write_dir, "WRITE_SIZE")
     kernels = {}
@@ -37,8 +37,8 @@ def main(fetch_dir, write_dir, out):
         fkb, wkb = ft[name] / n, wt.get(name, 0.0) / max(wc.get(name, 0), 1)
         kernels[name] = dict(launches=n, fetch_size_raw_kb_per_launch=round(fkb, 2), write_size_kb_per_launch=round(wkb, 2),
                              hbm_bytes_per_launch=int(round((2.0 * fkb + wkb) * 1024)))
-    doc = dict(command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (two separate passes) -- python3 bench.py --mode sample --steps 4 --warmup 1 "
-                       "--no-cpu-baseline --no-extras --no-kernel-timer",
+    doc = dict(command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (two separate passes) -- " +
+                       (cmd or "python3 bench.py --mode sample --steps 4 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-timer"),
                units="FETCH_SIZE / WRITE_SIZE are KB per dispatch (rocprofv3 derived metrics); FETCH_SIZE is doubled for gfx950 "
                      "(16-byte-per-lane reads are tallied at half, MI355X_MICROARCH.md §HBM)",
                kernels=dict(list(kernels.items())[:24]))
@@ -49,4 +49,4 @@ def main(fetch_dir, write_dir, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

@@ -391,7 +391,7 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
         state["img"] = torch.randn(B, 1, S, S, S, device=device)
         n_i = min(K, 8)
         summ = instrumented(sample_step, n_i)
-        roof = roofline_of(summ, PEAK_F32_MFMA_TFLOPS, prefer="conv_fwd8_kernel", step_ms=result["sample"]["ms_per_step"], n_steps=n_i)
+        roof = roofline_of(summ, PEAK_F32_MFMA_TFLOPS, step_ms=result["sample"]["ms_per_step"], n_steps=n_i)
         if roof is not None:
             roof["traffic"] = pmc_traffic(roof["kernel"], B, S)
             roof["traffic_note"] = "HBM bytes per average launch from the committed rocprofv3 --pmc passes of this command (profiles/), not re-measured in this run"

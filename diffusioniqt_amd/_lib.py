@@ -86,6 +86,7 @@ PROTOTYPES = {
     "diqt_conv3d_fwd_kernel_id": (I, [I] * 15),
     "diqt_conv3d_bwd_weight_kernel_id": (I, [I] * 15),
     "diqt_conv3d_fwd_ex": (I, [P, P, P, P, P, P, P, Z] + [I] * 15 + [P]),
+    "diqt_conv3d_fwd_neighbours_stats_blocks": (I, [I, I, I, I, I]),
     "diqt_conv3d_fwd_neighbours": (I, [P, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_groupnorm_stats_from_partials": (I, [P, P, P, I, I, I, I, I, F, P]),
     "diqt_channel_mean_from_partials": (I, [P, P, I, I, I, I, P]),

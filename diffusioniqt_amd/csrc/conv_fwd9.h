@@ -1,0 +1,20 @@
+// Internal interface of the version-9 forward conv (conv_fwd9.hip), called from conv3d_fwd_one (conv_mfma.hip).
+#pragma once
+#include <stddef.h>
+
+namespace diqt {
+
+struct F9Geom {
+    int B, D, H, W, Cin, Cout, Do, Ho, Wo, pd, ph, pw;
+    int tilesD, tilesH, tilesW, MT, nNt, CoutPad;
+    unsigned xBytes, yBytes, wBytes;
+    float* stats;                // optional per-tile column sums of the output: [B][tiles per batch][2][Cout]
+};
+
+// Does conv_fwd9_kernel take this launch (3x3x3, Cin % 16 == 0, whole rounds of 512-voxel tiles, tensors < 1 GiB)?
+bool fwd9_plan(F9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
+               int ph, int pw, int epd, int eph, int epw, size_t packedElems);
+int fwd9_launch(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
+                unsigned grid, void* stream);
+
+}  // namespace diqt

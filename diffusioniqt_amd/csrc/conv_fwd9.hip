@@ -1,0 +1,290 @@
+// Forward / backward-data 3x3x3 convolution for the LARGE launches of the U-Nets (the 32^3 level of C2: >= 512 tiles of 512 voxels),
+// version 9: the structure that took the weight gradient from 0.63 to 0.83 of the f32 MFMA peak (conv_wgrad.hip), applied to the
+// forward implicit GEMM  M = voxels, N = co, K = taps x ci  on v_mfma_f32_32x32x2_f32 (exact fp32; same fragment order and k order
+// per output element as conv_fwd_kernel / conv_fwd8_kernel, hence the same bits).
+//   * ONE wave per SIMD (256 threads, one workgroup per CU) with EIGHT accumulator tiles per wave: a workgroup owns an 8x8x8 block of
+//     512 output voxels x 64 co, a wave two 8x8 planes (128 voxels) x 64 co.  Twice the voxels per weight byte of the 256-voxel tile:
+//     every KiB landing in the CU costs ~100 cycles of matrix-pipe issue (profiles/r02_wgrad_ablation.md), and at 256 voxels the
+//     weight stream alone is 6 % of the MFMA time.
+//   * K is walked in 16-channel chunks so that TWO halo images (10^3 voxels x 64 B) fit the LDS beside a 3-slot ring of 2-tap weight
+//     groups (152 KB): the next chunk's halo and the weight group two steps ahead arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`)
+//     while the current step computes -- no register staging, no tables, no full stop at a chunk boundary; a step ends with
+//     `s_waitcnt vmcnt(0)` + ONE barrier per 128 MFMAs of a wave.  Zero padding / ragged tiles = out-of-range buffer offsets
+//     (the DMA writes zeros), per lane from packed tile-independent coordinates (sign-bit test, no branches).
+//   * the 27 taps of a chunk are unrolled: every LDS offset of the 1728 MFMAs' operands is an immediate; fragments of tap t+1 are
+//     read (ds_read_b128) between the MFMAs of tap t, also across step and chunk boundaries.
+//   * persistent tile walk: the first chunk of the next tile is prefetched during the last chunk of the current one, the weight
+//     ring runs on; a tile boundary is the epilogue (bias, residual, per-tile column sums for the consumer's GroupNorm / SE pool).
+// Reference call sites: Block.project of every ResnetBlock at the full-resolution level (/root/reference/imagen_pytorch3D.py:535-566).
+#include "common.h"
+#include "conv_fwd9.h"
+#include <stdlib.h>
+
+namespace diqt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void9;
+
+namespace f9 {
+constexpr unsigned OOB = 0x80000000u;
+constexpr int TD = 8, TH = 8, TW = 8, K = 3, T = 27;
+constexpr int HD = TD + K - 1, HH = TH + K - 1, HWd = TW + K - 1, HV = HD * HH * HWd;     // 10 x 10 x 10 = 1000 halo voxels
+constexpr int CH = 16, ROWB = CH * 4;                    // channels per chunk, bytes per halo voxel row / weight row
+constexpr int HB = 65536;                                // halo image: 1000 rows of 64 B in 64 one-KiB DMA instructions
+constexpr int NPH = HB / 1024 / 4;                       // halo DMA pieces per wave and chunk (16)
+constexpr int WTAP = 64 * ROWB;                          // one tap's weight panel: 64 co x 16 ci (4 KiB = one piece per wave)
+constexpr int TG = 2, NSTEP = (T + TG - 1) / TG;         // taps per step, steps per chunk (14)
+constexpr int WSLOT = TG * WTAP, NWS = 3;                // weight ring: 3 step slots
+constexpr int LDS_BYTES = 2 * HB + NWS * WSLOT;          // 155 648
+static_assert(HV * ROWB <= HB && (HV - 1) * ROWB + ROWB <= 65536, "halo image");
+__host__ __device__ constexpr int tapoff(int t) { return ((t / 9) * HH + (t / 3) % 3) * HWd + t % 3; }
+// halo row (at tap 0) of voxel block vb (0..3) of a wave, relative to the lane's own row: planes 2w + (vb >> 1), rows 4 (vb & 1) + l31 / 8
+__host__ __device__ constexpr int vbrow(int vb) { return (vb >> 1) * HH * HWd + (vb & 1) * 4 * HWd; }
+}  // namespace f9
+
+__device__ __forceinline__ void f9_dma(__amdgpu_buffer_rsrc_t rs, unsigned lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void9*)(size_t)lds, 16, voff, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                           const float* __restrict__ bias, const float* __restrict__ residual,
+                                                           float* __restrict__ y, F9Geom g) {
+    using namespace f9;
+    extern __shared__ __attribute__((aligned(1024))) char smem9[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hf = lane >> 5;
+    const unsigned Gn = gridDim.x;
+    const unsigned total = (unsigned)g.MT * g.nNt;
+    unsigned L = xcd_remap(blockIdx.x, Gn);
+    if (L >= total) return;
+    const int nMine = (int)((total - 1 - L) / Gn) + 1;
+    const int n0 = (int)(L % g.nNt) * 64;
+    const int nC = g.Cin / CH;
+
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, (int)g.wBytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
+    const unsigned ldsBase = (unsigned)(size_t)(lds_void9*)smem9;
+    const unsigned wringBase = ldsBase + 2 * HB;
+
+    // ---- tile-independent description of this lane's halo DMA pieces (16 per chunk; registers for the whole kernel) ----
+    unsigned posH[NPH], relH[NPH];
+#pragma unroll
+    for (int r = 0; r < NPH; ++r) {
+        const int p = (wave + 4 * r) * 64 + lane;                  // 16-byte piece of the image: row p / 4, channel quad p % 4
+        const int row = p >> 2;
+        const int hx = row % HWd, hy = (row / HWd) % HH, hz = row / (HWd * HH);
+        posH[r] = (unsigned)hz | ((unsigned)hy << 8) | ((unsigned)hx << 16) | (row < HV ? 0u : 1u << 24);
+        relH[r] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin) * 4u + (unsigned)(p & 3) * 16u;
+    }
+    // this lane's weight piece of a tap panel: co row 16 w + lane / 4, channel quad lane % 4 of the 16-channel sub-chunk
+    const unsigned relW = (unsigned)((n0 + 16 * wave + (lane >> 2)) * 128 + (lane & 3) * 16);
+    const unsigned tapStrideW = (unsigned)g.CoutPad * 128u;          // bytes between the panels of consecutive taps (32-wide packed rows)
+    auto dma_w = [&](int c16, int tap, unsigned ldsSlot, int tapInStep) __attribute__((always_inline)) {
+        const unsigned voff = ((unsigned)(c16 >> 1) * T + (unsigned)tap) * tapStrideW + (unsigned)(c16 & 1) * 64u + relW;
+        f9_dma(rs_w, ldsSlot + (unsigned)tapInStep * WTAP + (unsigned)wave * 1024u, voff);
+    };
+
+    // ---- tile coordinates (wave-uniform) ----
+    const int Dm1 = g.D - 1, Hm1 = g.H - 1, Wm1 = g.W - 1;
+    int tb, d0, h0, w0;                                    // tile being computed
+    int bz, by, bxx;                                       // tile whose halo is being fetched (origin minus padding) ...
+    unsigned baseX = 0, deadX = OOB;                       // ... its byte base, and 0x80000000 when there is none
+    auto tile_of = [&](unsigned Lt, int& b_, int& d_, int& h_, int& w_) __attribute__((always_inline)) {
+        int mt = (int)(Lt / g.nNt);
+        const int tx = mt % g.tilesW; mt /= g.tilesW;
+        const int ty = mt % g.tilesH; mt /= g.tilesH;
+        const int tz = mt % g.tilesD;
+        b_ = mt / g.tilesD; d_ = tz * TD; h_ = ty * TH; w_ = tx * TW;
+    };
+    auto set_fetch = [&](unsigned Lt, bool live) __attribute__((always_inline)) {
+        int b_, d_, h_, w_;
+        tile_of(live ? Lt : L, b_, d_, h_, w_);
+        bz = d_ - g.pd; by = h_ - g.ph; bxx = w_ - g.pw;
+        baseX = (unsigned)((((b_ * g.D + bz) * g.H + by) * g.W + bxx) * g.Cin) * 4u;
+        deadX = live ? 0u : OOB;
+    };
+    auto dma_h = [&](int r, unsigned hbuf, int c16) __attribute__((always_inline)) {     // r static
+        const unsigned p = posH[r];
+        const int iz = bz + (int)(p & 255u), iy = by + (int)((p >> 8) & 255u), ix = bxx + (int)((p >> 16) & 255u);
+        const unsigned m = (unsigned)(iz | iy | ix) | (unsigned)((Dm1 - iz) | (Hm1 - iy) | (Wm1 - ix)) | (p << 7) | deadX;
+        const unsigned voff = (baseX + relH[r] + (unsigned)c16 * ROWB) | (m & OOB);
+        f9_dma(rs_x, hbuf + (unsigned)(wave + 4 * r) * 1024u, voff);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int vb = 0; vb < 4; ++vb)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[vb][ch][i] = 0.f;
+
+    const int co0 = n0 + l31, co1 = n0 + 32 + l31;
+    const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
+    const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+    const unsigned c0o = co0 < g.Cout ? (unsigned)co0 * 4u : 0x40000000u, c1o = co1 < g.Cout ? (unsigned)co1 * 4u : 0x40000000u;
+
+    // per-lane operand bases: A = halo row of the lane's voxel (planes 2w.., row l31 / 8, column l31 % 8) + its 16-byte half of a k-group
+    const unsigned aLane = (unsigned)(((2 * wave) * HH + (l31 >> 3)) * HWd + (l31 & 7)) * ROWB + (unsigned)hf * 16u;
+    const unsigned bLane = (unsigned)l31 * ROWB + (unsigned)hf * 16u;
+
+    // ---- prologue: halo chunk 0 of the first tile -> image 0, weight groups of steps 0 and 1 -> ring slots 0 and 1 ----
+    tile_of(L, tb, d0, h0, w0);
+    set_fetch(L, true);
+#pragma unroll
+    for (int r = 0; r < NPH; ++r) dma_h(r, ldsBase, 0);
+    dma_w(0, 0, wringBase, 0); dma_w(0, 1, wringBase, 1);
+    dma_w(0, 2, wringBase + WSLOT, 0); dma_w(0, 3, wringBase + WSLOT, 1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0)
+    __syncthreads();
+
+    int wcur = 0, hcur = 0;
+    for (int it = 0; it < nMine; ++it) {
+        const bool lastTile = it + 1 == nMine;
+        for (int c = 0; c < nC; ++c) {
+            // which (tile, chunk) the halo pieces issued during this chunk belong to, and the chunk the wrapped weight steps belong to
+            const bool wrap = c + 1 == nC;
+            const int cNext = wrap ? 0 : c + 1;
+            if (wrap) set_fetch(L + Gn, !lastTile);        // from here on the fetches are the next tile's first chunk (or dead)
+            const unsigned hbufN = ldsBase + (unsigned)(hcur ^ 1) * HB;
+            const char* hb = smem9 + hcur * HB + aLane;
+            f32x4v A0[4][2], A1[4][2], B0[2][2], B1[2][2];   // ping-pong fragments: [voxel block | co half][k-group]
+#define F9_RD(Av, Bv, TAP, WS, TIS)                                                                                  \
+    do {                                                                                                             \
+        const char* wb_ = smem9 + 2 * HB + (WS) * WSLOT + (TIS) * WTAP + bLane;                                      \
+        _Pragma("unroll") for (int vb = 0; vb < 4; ++vb)                                                             \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
+                Av[vb][q] = *reinterpret_cast<const f32x4v*>(hb + (vbrow(vb) + tapoff(TAP)) * ROWB + q * 32);        \
+        _Pragma("unroll") for (int ch = 0; ch < 2; ++ch)                                                             \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
+                Bv[ch][q] = *reinterpret_cast<const f32x4v*>(wb_ + ch * 32 * ROWB + q * 32);                         \
+    } while (0)
+#define F9_MM(Av, Bv)                                                                                                \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                            \
+                _Pragma("unroll") for (int vb = 0; vb < 4; ++vb)                                                     \
+                    _Pragma("unroll") for (int ch = 0; ch < 2; ++ch)                                                 \
+                        acc[vb][ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(Av[vb][q][e], Bv[ch][q][e], acc[vb][ch], 0, 0, 0);   \
+        /* the 12 fragment reads of the next tap (issued above in program order) go between this tap's 64 MFMAs */  \
+        _Pragma("unroll") for (int u = 0; u < 12; ++u) {                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                       \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                           \
+    } while (0)
+            F9_RD(A0, B0, 0, wcur, 0);                     // cold read of the chunk's first tap (prefetched across chunks would be the next step)
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int wnext = wcur == NWS - 1 ? 0 : wcur + 1;
+                const int wnn = wnext == NWS - 1 ? 0 : wnext + 1;
+                // ---- this step's DMA: the weight group two steps ahead, two halo pieces of the next chunk (steps 0..7) ----
+                {
+                    const int s2 = s + 2 < NSTEP ? s + 2 : s + 2 - NSTEP;
+                    const int c2 = s + 2 < NSTEP ? c : cNext;
+                    const unsigned slot = wringBase + (unsigned)wnn * WSLOT;
+                    dma_w(c2, 2 * s2, slot, 0);
+                    if (2 * s2 + 1 < T) dma_w(c2, 2 * s2 + 1, slot, 1);
+                    if (2 * s < NPH) { dma_h(2 * s, hbufN, cNext); dma_h(2 * s + 1, hbufN, cNext); }
+                }
+                // ---- taps 2s, 2s + 1 ----
+                if (2 * s + 1 < T) {
+                    F9_RD(A1, B1, 2 * s + 1, wcur, 1);
+                    F9_MM(A0, B0);
+                    if (s + 1 < NSTEP) F9_RD(A0, B0, 2 * s + 2, wnext, 0);
+                    F9_MM(A1, B1);
+                } else {
+                    F9_MM(A0, B0);
+                }
+                __builtin_amdgcn_s_waitcnt(0x0f70);        // this step's pieces (issued a whole step ago) have landed ...
+                __syncthreads();                           // ... everybody's have, and everybody is done with this step's weight slot
+                wcur = wnext;
+            }
+#undef F9_RD
+#undef F9_MM
+            hcur ^= 1;
+        }
+        // ---- epilogue of the tile: D[row = voxel][col = co]; voxel of (vb, register i, lane half): plane 2w + (vb >> 1),
+        //      row 4 (vb & 1) + (i >> 2), column (i & 3) + 4 hf ----
+        {
+            float cs0 = 0.f, cq0 = 0.f, cs1 = 0.f, cq1 = 0.f;
+#pragma unroll
+            for (int vb = 0; vb < 4; ++vb) {
+                const int od = d0 + 2 * wave + (vb >> 1);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int oh = h0 + 4 * (vb & 1) + (i >> 2), ow = w0 + (i & 3) + 4 * hf;
+                    const bool ok = od < g.Do && oh < g.Ho && ow < g.Wo;
+                    const unsigned off = ok ? (unsigned)((((tb * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout) * 4u : OOB;
+                    float v0 = acc[vb][0][i] + bias0, v1 = acc[vb][1][i] + bias1;
+                    if (residual) {        // kernel-uniform
+                        v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0o, 0, 0));
+                        v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1o, 0, 0));
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1o, 0, 0);
+                    if (g.stats && ok) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
+                    acc[vb][0][i] = 0.f; acc[vb][1][i] = 0.f;
+                }
+            }
+            if (g.stats) {         // kernel-uniform: fixed-order combine of the lane halves, then of the 4 waves through LDS
+                cs0 += __shfl_xor(cs0, 32, 64); cq0 += __shfl_xor(cq0, 32, 64);
+                cs1 += __shfl_xor(cs1, 32, 64); cq1 += __shfl_xor(cq1, 32, 64);
+                // scratch: the halo image that is NOT being filled (the next tile's first chunk lands in image hcur)
+                float* red = reinterpret_cast<float*>(smem9 + (hcur ^ 1) * HB);
+                if (hf == 0) {
+                    red[(wave * 4 + 0) * 32 + l31] = cs0; red[(wave * 4 + 1) * 32 + l31] = cq0;
+                    red[(wave * 4 + 2) * 32 + l31] = cs1; red[(wave * 4 + 3) * 32 + l31] = cq1;
+                }
+                __syncthreads();
+                if (tid < 128) {   // q = tid >> 5: 0 sum(co0) 1 sumsq(co0) 2 sum(co1) 3 sumsq(co1)
+                    const int q = tid >> 5, l = tid & 31;
+                    const float v = ((red[q * 32 + l] + red[(4 + q) * 32 + l]) + red[(8 + q) * 32 + l]) + red[(12 + q) * 32 + l];
+                    const int co = n0 + (q >> 1) * 32 + l;
+                    const int tpb = g.tilesD * g.tilesH * g.tilesW, mtile = (int)(L / g.nNt);
+                    if (co < g.Cout) g.stats[(((size_t)(mtile / tpb) * tpb + mtile % tpb) * 2 + (q & 1)) * g.Cout + co] = v;
+                }
+                __syncthreads();   // the scratch is free again before the next chunk's pieces may land in it
+            }
+        }
+        L += Gn;
+        if (!lastTile) tile_of(L, tb, d0, h0, w0);
+    }
+}
+
+bool fwd9_plan(F9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
+               int ph, int pw, int epd, int eph, int epw, size_t packedElems) {
+    static const int mode = [] { const char* e = getenv("DIQT_CONV_F9"); return e ? atoi(e) : 1; }();      // 0: never, 2: any tile count
+    if (!mode || kd != 3 || kh != 3 || kw != 3 || Cin % f9::CH != 0 || Cin < f9::CH || Cout < 1) return false;
+    if (D > 255 || H > 255 || W > 255) return false;                   // packed 8-bit halo coordinates
+    g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.pd = pd; g.ph = ph; g.pw = pw;
+    g.Do = D + 2 * pd + epd - 2; g.Ho = H + 2 * ph + eph - 2; g.Wo = W + 2 * pw + epw - 2;
+    if (g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return false;
+    g.tilesD = (g.Do + 7) / 8; g.tilesH = (g.Ho + 7) / 8; g.tilesW = (g.Wo + 7) / 8;
+    g.nNt = (Cout + 63) / 64; g.CoutPad = g.nNt * 64;
+    const long long mt = (long long)B * g.tilesD * g.tilesH * g.tilesW;
+    const unsigned long long xb = (unsigned long long)B * D * H * W * Cin * 4ull, yb = (unsigned long long)B * g.Do * g.Ho * g.Wo * Cout * 4ull;
+    const unsigned long long wb = (unsigned long long)packedElems * 4ull;
+    if (mt >= (1ll << 30) || xb >= (1ull << 30) || yb >= (1ull << 30) || wb >= (1ull << 30)) return false;
+    g.MT = (int)mt; g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.wBytes = (unsigned)wb; g.stats = nullptr;
+    // efficiency of the 8^3 tile on ragged extents, and whole rounds of one workgroup per CU
+    const double useful = (double)g.Do * g.Ho * g.Wo / ((double)g.tilesD * g.tilesH * g.tilesW * 512.0);
+    const long long nwg = mt * g.nNt;
+    if (mode != 2 && (useful < 0.9 || nwg < 256 || (double)nwg / (double)((nwg + 255) / 256 * 256) < 0.94)) return false;
+    grid = (nwg > 256 && 256 % g.nNt == 0) ? 256u : (unsigned)nwg;     // persistent walk: a workgroup keeps its 64-channel block
+    lds = f9::LDS_BYTES;
+    return true;
+}
+
+int fwd9_launch(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
+                unsigned grid, void* stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd9_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd(v9): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(conv_fwd9_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
+    return check_launch("conv3d_fwd(v9)");
+}
+
+}  // namespace diqt

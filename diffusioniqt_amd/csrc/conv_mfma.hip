@@ -22,6 +22,7 @@
 //   layout and are reduced in a fixed order (deterministic) by conv_reduce_dw_kernel.
 #include "common.h"
 #include "conv_wgrad.h"
+#include "conv_fwd9.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -1671,8 +1672,19 @@ static bool fwd8_plan(const ConvGeom& g, ConvGeom& g8, size_t& lds) {
 
 // per-tile output statistics are produced by the buffer-path kernel of an unsplit launch; returns the number of tiles per batch
 // entry (the `nblk` of the [B][nblk][2][Cout] partial layout) or 0 when this shape would take another path
+static int fwd_stats_blocks_impl(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd,
+                                 int eph, int epw, bool neighbours);
 extern "C" int diqt_conv3d_fwd_stats_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
                                             int pw, int epd, int eph, int epw) {
+    return fwd_stats_blocks_impl(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, false);
+}
+// the same for diqt_conv3d_fwd_neighbours (which never takes conv_fwd9_kernel: that kernel has no neighbour addressing)
+extern "C" int diqt_conv3d_fwd_neighbours_stats_blocks(int f, int A, int Cin, int Cout, int k) {
+    if (f < 1 || A < 1 || k < 1 || !(k & 1)) return 0;
+    return fwd_stats_blocks_impl(f * f * f, A, A, A, Cin, Cout, k, k, k, k / 2, k / 2, k / 2, 0, 0, 0, true);
+}
+static int fwd_stats_blocks_impl(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd,
+                                 int eph, int epw, bool neighbours) {
     static const bool off = [] { const char* e = getenv("DIQT_CONV_NOSTATS"); return e && e[0] == '1'; }();
     static const bool nobuf = [] { const char* e = getenv("DIQT_CONV_NOBUF"); return e && e[0] == '1'; }();
     ConvGeom g;
@@ -1686,12 +1698,20 @@ extern "C" int diqt_conv3d_fwd_stats_blocks(int B, int D, int H, int W, int Cin,
     if (lds > 160 * 1024) return 0;
     ConvGeom g8;
     size_t lds8;
+    {
+        F9Geom g9;
+        size_t l9;
+        unsigned gr9;
+        if (!neighbours && Cin % 4 == 0 && fwd_ksplit(g) <= 1 && !smallcin_pad(Cin, kd * kh * kw) &&
+            fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw)))
+            return g9.tilesD * g9.tilesH * g9.tilesW;                          // conv_fwd9_kernel: one row per 512-voxel tile
+    }
     if (fwd8_plan(g, g8, lds8)) return g8.tilesD * g8.tilesH * g8.tilesW;      // the 8-wave kernel writes one row per 256-voxel tile
     return g.tilesD * g.tilesH * g.tilesW;
 }
 
 // which kernel diqt_conv3d_fwd* dispatches this shape to (for profilers / bench.py, so that per-kernel numbers carry the names
-// rocprofv3 reports): 0 conv_fwd_kernel, 1 conv_fwd_smallcin_kernel, 2 conv1x1_fwd_kernel, 3 conv_fwd8_kernel, -1 bad shape
+// rocprofv3 reports): 0 conv_fwd_kernel, 1 conv_fwd_smallcin_kernel, 2 conv1x1_fwd_kernel, 3 conv_fwd8_kernel, 4 conv_fwd9_kernel, -1 bad shape
 extern "C" int diqt_conv3d_fwd_kernel_id(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                                          int epd, int eph, int epw) {
     ConvGeom g;
@@ -1702,6 +1722,13 @@ extern "C" int diqt_conv3d_fwd_kernel_id(int B, int D, int H, int W, int Cin, in
     const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
     const bool buf = Cin % 4 == 0 && xb < (1ull << 30) && yb < (1ull << 30);
     if (!buf || fwd_ksplit(g) > 1) return 0;
+    {
+        F9Geom g9;
+        size_t l9;
+        unsigned gr9;
+        if (fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw)))
+            return 4;
+    }
     ConvGeom g8;
     size_t lds8;
     if (fwd8_plan(g, g8, lds8)) return 3;
@@ -1734,8 +1761,8 @@ extern "C" int diqt_conv3d_fwd_neighbours(const float* x, const float* packed, c
     const int B = f * f * f, p = k / 2;
     DIQT_REQUIRE((unsigned long long)B * A * A * A * (unsigned long long)(Cin > Cout ? Cin : Cout) * 4ull < (1ull << 30), DIQT_E_UNSUPPORTED,
                  "conv3d_fwd_neighbours: the sub-volume batch must stay below 1 GiB (it cannot be cut into independent launches)");
-    DIQT_REQUIRE(!stats || diqt_conv3d_fwd_stats_blocks(B, A, A, A, Cin, Cout, k, k, k, p, p, p, 0, 0, 0) > 0, DIQT_E_UNSUPPORTED,
-                 "conv3d_fwd_neighbours: this shape does not produce output statistics");
+    DIQT_REQUIRE(!stats || diqt_conv3d_fwd_neighbours_stats_blocks(f, A, Cin, Cout, k) > 0, DIQT_E_UNSUPPORTED,
+                 "conv3d_fwd_neighbours: this shape does not produce output statistics (diqt_conv3d_fwd_neighbours_stats_blocks == 0)");
     return conv3d_fwd_one(x, packed, bias, residual, y, workspace, workspace_bytes, B, A, A, A, Cin, Cout, k, k, k, p, p, p, 0, 0, 0, stream,
                           stats, f);
 }
@@ -1877,6 +1904,16 @@ static int conv3d_fwd_one(const float* x, const float* packed, const float* bias
     if (buf && !ck16) {
         ConvGeom g8;
         size_t lds8;
+        {
+            F9Geom g9;
+            size_t l9;
+            unsigned gr9;
+            if (g.subF == 0 && fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw,
+                                         diqt_conv_packed_elems(Cout, Cin, kd, kh, kw))) {
+                g9.stats = stats;
+                return fwd9_launch(x, packed, bias, residual, y, g9, l9, gr9, stream);
+            }
+        }
         if (fwd8_plan(g, g8, lds8)) {
             g8.stats = stats;
             g8.dbg = nullptr;

@@ -229,7 +229,7 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0), stat
         # the tag names the kernel the C side dispatches to, so that bench.py's per-kernel numbers line up with rocprofv3's
         taps = kd * kh * kw
         kid = _lib.query("diqt_conv3d_fwd_kernel_id", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
-        tag = ("conv_fwd_kernel", "conv_fwd_smallcin_kernel", "conv1x1_fwd_kernel", "conv_fwd8_kernel")[kid if kid > 0 and n == 0 else 0]
+        tag = ("conv_fwd_kernel", "conv_fwd_smallcin_kernel", "conv1x1_fwd_kernel", "conv_fwd8_kernel", "conv_fwd9_kernel")[kid if kid > 0 and n == 0 else 0]
         TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * taps, tag, (B, D, H, W, Cin, Cout, kd, kh, kw)))
     return y
 
@@ -329,7 +329,7 @@ def conv3d_neighbours(x, weight, bias, f, residual=None, want_stats=False):
     ws = _workspace(n, x.device) if n else None
     stats = None
     if want_stats:
-        nblk = _lib.query("diqt_conv3d_fwd_stats_blocks", *geo)
+        nblk = _lib.query("diqt_conv3d_fwd_neighbours_stats_blocks", f, A, Cin, Cout, k)
         if nblk > 0:
             stats = torch.empty((B, nblk, 2, Cout), dtype=torch.float32, device=x.device)
             y._diqt_stats = ColStats(stats, nblk, A * A * A)

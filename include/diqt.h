@@ -112,8 +112,10 @@ int diqt_channel_mean_from_partials(const float* partials, float* pooled, int B,
  * volume (entry n = b2 + f b3 + f^2 b4, utils_mine.py:25-67), each sub-volume's halo read IN PLACE from its neighbours and zero
  * only outside the merged volume: the reference's boundary_pad (merge_sub_volumes -> F.pad -> overlapping unfold,
  * imagen_pytorch3D.py:37-46) followed by the unpadded Conv3d of Block.forward (:550-566, boundary=True), without the merged and
- * re-split copies.  Bit-identical to running those copies through diqt_conv3d_fwd_ex.  stats / workspace as diqt_conv3d_fwd_ex
- * for (B = f^3, D = H = W = A, pad = k/2).  The batch must stay below 1 GiB. */
+ * re-split copies.  Same kernels (conv_fwd8 / conv_fwd / small-Cin) and bits as running those copies through them.  stats:
+ * [f^3][diqt_conv3d_fwd_neighbours_stats_blocks][2][Cout]; workspace as diqt_conv3d_fwd_ex for (B = f^3, D = H = W = A, pad = k/2).
+ * The batch must stay below 1 GiB. */
+int diqt_conv3d_fwd_neighbours_stats_blocks(int f, int A, int Cin, int Cout, int k);   /* rows per batch entry of `stats` (0: none) */
 int diqt_conv3d_fwd_neighbours(const float* x, const float* packed, const float* bias, const float* residual, float* y, float* stats,
                                void* workspace, size_t workspace_bytes, int f, int A, int Cin, int Cout, int k, void* stream);
 

@@ -201,16 +201,17 @@ def test_batched_time_mlps_equal_the_per_block_launches():
                     m.time_mlp[1].weight.mul_(1.5)
 
 
-@pytest.mark.parametrize("B", [2, 4])
-def test_unet_config2_at_32cubed_routes_through_conv_fwd8_vs_oracle(B):
-    """The exact BASELINE config-2 network at its real 32^3 patch size: B=2 fills exactly one round of 256 workgroups of the
-    8-wave ``conv_fwd8_kernel`` (the headline's dominant kernel), B=4 takes its persistent tile walk.  Whole-U-Net composition
-    on the GPU vs ``oracle.unet_forward`` on the host, same tolerances as the 16^3 case."""
+@pytest.mark.parametrize("B,kid", [(2, 3), (4, 4)])
+def test_unet_config2_at_32cubed_routes_through_conv_fwd8_vs_oracle(B, kid):
+    """The exact BASELINE config-2 network at its real 32^3 patch size, whole-U-Net composition on the GPU vs ``oracle.unet_forward``
+    on the host (same tolerances as the 16^3 case): B=2 fills exactly one round of 256 workgroups of the 8-wave ``conv_fwd8_kernel``,
+    B=4 one round of the one-wave-per-SIMD ``conv_fwd9_kernel`` (512-voxel tiles) that carries the headline's 32^3-level convs; their
+    persistent tile walks are covered at the kernel level (tests/test_gpu_kernels.py)."""
     from bench import unet_kwargs
     from diffusioniqt_amd import _lib
     from diffusioniqt_amd.imagen_pytorch3D import SRUnet256
-    assert _lib.query("diqt_conv3d_fwd_kernel_id", B, 32, 32, 32, 64, 64, 3, 3, 3, 1, 1, 1, 0, 0, 0) == 3, \
-        "the 64->64 3x3x3 conv at 32^3 no longer dispatches to conv_fwd8_kernel: this test would not cover it"
+    assert _lib.query("diqt_conv3d_fwd_kernel_id", B, 32, 32, 32, 64, 64, 3, 3, 3, 1, 1, 1, 0, 0, 0) == kid, \
+        "the 64->64 3x3x3 conv at 32^3 no longer dispatches to the kernel this case is meant to cover"
     kw = unet_kwargs(32)
     unet = SRUnet256(**kw)
     sd = O.hash_fill_state_dict(unet.state_dict(), 7)

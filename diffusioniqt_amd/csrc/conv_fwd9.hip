@@ -26,31 +26,41 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void9;
 
-namespace f9 {
-constexpr unsigned OOB = 0x80000000u;
-constexpr int TD = 8, TH = 8, TW = 8, K = 3, T = 27;
-constexpr int HD = TD + K - 1, HH = TH + K - 1, HWd = TW + K - 1, HV = HD * HH * HWd;     // 10 x 10 x 10 = 1000 halo voxels
-constexpr int CH = 16, ROWB = CH * 4;                    // channels per chunk, bytes per halo voxel row / weight row
-constexpr int HB = 65536;                                // halo image: 1000 rows of 64 B in 64 one-KiB DMA instructions
-constexpr int NPH = HB / 1024 / 4;                       // halo DMA pieces per wave and chunk (16)
-constexpr int WTAP = 64 * ROWB;                          // one tap's weight panel: 64 co x 16 ci (4 KiB = one piece per wave)
-constexpr int TG = 2, NSTEP = (T + TG - 1) / TG;         // taps per step, steps per chunk (14)
-constexpr int WSLOT = TG * WTAP, NWS = 3;                // weight ring: 3 step slots
-constexpr int LDS_BYTES = 2 * HB + NWS * WSLOT;          // 155 648
-static_assert(HV * ROWB <= HB && (HV - 1) * ROWB + ROWB <= 65536, "halo image");
-__host__ __device__ constexpr int tapoff(int t) { return ((t / 9) * HH + (t / 3) % 3) * HWd + t % 3; }
-// halo row (at tap 0) of voxel block vb (0..3) of a wave, relative to the lane's own row: planes 2w + (vb >> 1), rows 4 (vb & 1) + l31 / 8
-__host__ __device__ constexpr int vbrow(int vb) { return (vb >> 1) * HH * HWd + (vb & 1) * 4 * HWd; }
-}  // namespace f9
+constexpr unsigned F9_OOB = 0x80000000u;
+constexpr int F9_CH = 16, F9_ROWB = F9_CH * 4;           // channels per chunk, bytes per halo voxel row / weight row
+constexpr int F9_WTAP = 64 * F9_ROWB;                    // one tap's weight panel: 64 co x 16 ci (4 KiB = one DMA piece per wave)
+constexpr int F9_TG = 2, F9_NWS = 3;                     // taps per step, slots of the weight ring
+constexpr int F9_WSLOT = F9_TG * F9_WTAP;
+
+// Filter (KD, KH, KW), tile (TD, TH, TW) and voxel blocks per wave NVB (4: 512-voxel tile, 2: 256).  A voxel BLOCK is 4 rows x 8
+// columns of one plane = the 32 rows of an accumulator tile; block id = (plane * TH/4 + row group) * TW/8 + column group, wave = id / NVB.
+template <int KD_, int KH_, int KW_, int TD_, int TH_, int TW_, int NVB_>
+struct F9Cfg {
+    static constexpr int KD = KD_, KH = KH_, KW = KW_, TD = TD_, TH = TH_, TW = TW_, NVB = NVB_;
+    static constexpr int T = KD * KH * KW, NSTEP = (T + F9_TG - 1) / F9_TG;
+    static constexpr int HD = TD + KD - 1, HH = TH + KH - 1, HWd = TW + KW - 1, HV = HD * HH * HWd;
+    static constexpr int HB = (HV * F9_ROWB + 4095) / 4096 * 4096;      // halo image in whole 1-KiB DMA instructions, the same count per wave
+    static constexpr int NPH = HB / 4096;                              // halo DMA pieces per wave and chunk
+    static constexpr int NBH = TH / 4, NBW = TW / 8;
+    static constexpr int LDS_BYTES = 2 * HB + F9_NWS * F9_WSLOT;
+    static_assert(TD * TH * TW == 128 * NVB && TH % 4 == 0 && TW % 8 == 0, "tile = 4 waves x NVB blocks of 4 x 8 voxels");
+    static_assert(HV * F9_ROWB <= 65536 && LDS_BYTES <= 160 * 1024, "halo image: 16-bit LDS immediates, two images + weight ring in LDS");
+    static_assert(NPH <= 16, "halo piece descriptors live in registers");
+    __host__ __device__ static constexpr int tapoff(int t) { return ((t / (KW * KH)) * HH + (t / KW) % KH) * HWd + t % KW; }
+    __host__ __device__ static constexpr int blockrow(int id) { return ((id / (NBH * NBW)) * HH + ((id / NBW) % NBH) * 4) * HWd + (id % NBW) * 8; }
+};
 
 __device__ __forceinline__ void f9_dma(__amdgpu_buffer_rsrc_t rs, unsigned lds, unsigned voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void9*)(size_t)lds, 16, voff, 0, 0, 0);
 }
 
+template <class C>
 __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias, const float* __restrict__ residual,
                                                            float* __restrict__ y, F9Geom g) {
-    using namespace f9;
+    constexpr int T = C::T, NSTEP = C::NSTEP, HB = C::HB, NPH = C::NPH, NVB = C::NVB, HH = C::HH, HWd = C::HWd, HV = C::HV;
+    constexpr int CH = F9_CH, ROWB = F9_ROWB, WTAP = F9_WTAP, WSLOT = F9_WSLOT, NWS = F9_NWS;
+    constexpr unsigned OOB = F9_OOB;
     extern __shared__ __attribute__((aligned(1024))) char smem9[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hf = lane >> 5;
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
         const int tx = mt % g.tilesW; mt /= g.tilesW;
         const int ty = mt % g.tilesH; mt /= g.tilesH;
         const int tz = mt % g.tilesD;
-        b_ = mt / g.tilesD; d_ = tz * TD; h_ = ty * TH; w_ = tx * TW;
+        b_ = mt / g.tilesD; d_ = tz * C::TD; h_ = ty * C::TH; w_ = tx * C::TW;
     };
     auto set_fetch = [&](unsigned Lt, bool live) __attribute__((always_inline)) {
         int b_, d_, h_, w_;
@@ -114,9 +124,9 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
         f9_dma(rs_x, hbuf + (unsigned)(wave + 4 * r) * 1024u, voff);
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[NVB][2];
 #pragma unroll
-    for (int vb = 0; vb < 4; ++vb)
+    for (int vb = 0; vb < NVB; ++vb)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
@@ -127,9 +137,17 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
     const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
     const unsigned c0o = co0 < g.Cout ? (unsigned)co0 * 4u : 0x40000000u, c1o = co1 < g.Cout ? (unsigned)co1 * 4u : 0x40000000u;
 
-    // per-lane operand bases: A = halo row of the lane's voxel (planes 2w.., row l31 / 8, column l31 % 8) + its 16-byte half of a k-group
-    const unsigned aLane = (unsigned)(((2 * wave) * HH + (l31 >> 3)) * HWd + (l31 & 7)) * ROWB + (unsigned)hf * 16u;
+    // per-lane operand bases: A = halo row of the lane's voxel inside its block (row l31 / 8, column l31 % 8) + its 16-byte half of a
+    // k-group; the blocks of this wave start at rows blockrow(wave * NVB + vb) (wave-uniform), taps add compile-time row offsets
+    const unsigned aLane = (unsigned)((l31 >> 3) * HWd + (l31 & 7)) * ROWB + (unsigned)hf * 16u;
     const unsigned bLane = (unsigned)l31 * ROWB + (unsigned)hf * 16u;
+    int brow[NVB], bd[NVB], bh4[NVB], bw8[NVB];            // halo row / plane / first row / first column of the wave's blocks
+#pragma unroll
+    for (int vb = 0; vb < NVB; ++vb) {
+        const int id = wave * NVB + vb;
+        bd[vb] = id / (C::NBH * C::NBW); bh4[vb] = ((id / C::NBW) % C::NBH) * 4; bw8[vb] = (id % C::NBW) * 8;
+        brow[vb] = (bd[vb] * HH + bh4[vb]) * HWd + bw8[vb];
+    }
 
     // ---- prologue: halo chunk 0 of the first tile -> image 0, weight groups of steps 0 and 1 -> ring slots 0 and 1 ----
     tile_of(L, tb, d0, h0, w0);
@@ -150,14 +168,16 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
             const int cNext = wrap ? 0 : c + 1;
             if (wrap) set_fetch(L + Gn, !lastTile);        // from here on the fetches are the next tile's first chunk (or dead)
             const unsigned hbufN = ldsBase + (unsigned)(hcur ^ 1) * HB;
-            const char* hb = smem9 + hcur * HB + aLane;
-            f32x4v A0[4][2], A1[4][2], B0[2][2], B1[2][2];   // ping-pong fragments: [voxel block | co half][k-group]
+            const char* hb[NVB];
+#pragma unroll
+            for (int vb = 0; vb < NVB; ++vb) hb[vb] = smem9 + hcur * HB + aLane + brow[vb] * ROWB;
+            f32x4v A0[NVB][2], A1[NVB][2], B0[2][2], B1[2][2];   // ping-pong fragments: [voxel block | co half][k-group]
 #define F9_RD(Av, Bv, TAP, WS, TIS)                                                                                  \
     do {                                                                                                             \
         const char* wb_ = smem9 + 2 * HB + (WS) * WSLOT + (TIS) * WTAP + bLane;                                      \
-        _Pragma("unroll") for (int vb = 0; vb < 4; ++vb)                                                             \
+        _Pragma("unroll") for (int vb = 0; vb < NVB; ++vb)                                                           \
             _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
-                Av[vb][q] = *reinterpret_cast<const f32x4v*>(hb + (vbrow(vb) + tapoff(TAP)) * ROWB + q * 32);        \
+                Av[vb][q] = *reinterpret_cast<const f32x4v*>(hb[vb] + C::tapoff(TAP) * ROWB + q * 32);               \
         _Pragma("unroll") for (int ch = 0; ch < 2; ++ch)                                                             \
             _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
                 Bv[ch][q] = *reinterpret_cast<const f32x4v*>(wb_ + ch * 32 * ROWB + q * 32);                         \
@@ -166,15 +186,15 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
     do {                                                                                                             \
         _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                \
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                            \
-                _Pragma("unroll") for (int vb = 0; vb < 4; ++vb)                                                     \
+                _Pragma("unroll") for (int vb = 0; vb < NVB; ++vb)                                                   \
                     _Pragma("unroll") for (int ch = 0; ch < 2; ++ch)                                                 \
                         acc[vb][ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(Av[vb][q][e], Bv[ch][q][e], acc[vb][ch], 0, 0, 0);   \
-        /* the 12 fragment reads of the next tap (issued above in program order) go between this tap's 64 MFMAs */  \
-        _Pragma("unroll") for (int u = 0; u < 12; ++u) {                                                             \
-            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);                                                       \
+        /* the 2 NVB + 4 fragment reads of the next tap (issued above in program order) go between this tap's 16 NVB MFMAs */  \
+        _Pragma("unroll") for (int u = 0; u < 2 * NVB + 4; ++u) {                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, NVB == 4 ? 5 : 3, 0);                                        \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                       \
         }                                                                                                            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 * NVB - (2 * NVB + 4) * (NVB == 4 ? 5 : 3), 0);              \
     } while (0)
             F9_RD(A0, B0, 0, wcur, 0);                     // cold read of the chunk's first tap (prefetched across chunks would be the next step)
 #pragma unroll
@@ -188,7 +208,9 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
                     const unsigned slot = wringBase + (unsigned)wnn * WSLOT;
                     dma_w(c2, 2 * s2, slot, 0);
                     if (2 * s2 + 1 < T) dma_w(c2, 2 * s2 + 1, slot, 1);
-                    if (2 * s < NPH) { dma_h(2 * s, hbufN, cNext); dma_h(2 * s + 1, hbufN, cNext); }
+#pragma unroll
+                    for (int r = 0; r < NPH; ++r)
+                        if (r * NSTEP / NPH == s) dma_h(r, hbufN, cNext);           // the next chunk's pieces, spread over the steps
                 }
                 // ---- taps 2s, 2s + 1 ----
                 if (2 * s + 1 < T) {
@@ -207,26 +229,35 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
 #undef F9_MM
             hcur ^= 1;
         }
-        // ---- epilogue of the tile: D[row = voxel][col = co]; voxel of (vb, register i, lane half): plane 2w + (vb >> 1),
-        //      row 4 (vb & 1) + (i >> 2), column (i & 3) + 4 hf ----
+        // ---- epilogue of the tile: D[row = voxel][col = co]; voxel of (block vb, register i, lane half): plane bd, row bh4 + (i >> 2),
+        //      column bw8 + (i & 3) + 4 hf ----
         {
             float cs0 = 0.f, cq0 = 0.f, cs1 = 0.f, cq1 = 0.f;
 #pragma unroll
-            for (int vb = 0; vb < 4; ++vb) {
-                const int od = d0 + 2 * wave + (vb >> 1);
+            for (int vb = 0; vb < NVB; ++vb) {
+                const int od = d0 + bd[vb];
+                unsigned offs[16];
+                float r0[16], r1[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int oh = h0 + 4 * (vb & 1) + (i >> 2), ow = w0 + (i & 3) + 4 * hf;
+                    const int oh = h0 + bh4[vb] + (i >> 2), ow = w0 + bw8[vb] + (i & 3) + 4 * hf;
                     const bool ok = od < g.Do && oh < g.Ho && ow < g.Wo;
-                    const unsigned off = ok ? (unsigned)((((tb * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout) * 4u : OOB;
-                    float v0 = acc[vb][0][i] + bias0, v1 = acc[vb][1][i] + bias1;
-                    if (residual) {        // kernel-uniform
-                        v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0o, 0, 0));
-                        v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1o, 0, 0));
+                    offs[i] = ok ? (unsigned)((((tb * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout) * 4u : OOB;
+                }
+                if (residual) {            // kernel-uniform; all 32 loads of the block in flight before the first add
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        r0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, offs[i] + c0o, 0, 0));
+                        r1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, offs[i] + c1o, 0, 0));
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0o, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1o, 0, 0);
-                    if (g.stats && ok) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v0 = acc[vb][0][i] + bias0, v1 = acc[vb][1][i] + bias1;
+                    if (residual) { v0 += r0[i]; v1 += r1[i]; }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, offs[i] + c0o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, offs[i] + c1o, 0, 0);
+                    if (g.stats && offs[i] != OOB) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
                     acc[vb][0][i] = 0.f; acc[vb][1][i] = 0.f;
                 }
             }
@@ -255,36 +286,71 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
     }
 }
 
-bool fwd9_plan(F9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
-               int ph, int pw, int epd, int eph, int epw, size_t packedElems) {
-    static const int mode = [] { const char* e = getenv("DIQT_CONV_F9"); return e ? atoi(e) : 1; }();      // 0: never, 2: any tile count
-    if (!mode || kd != 3 || kh != 3 || kw != 3 || Cin % f9::CH != 0 || Cin < f9::CH || Cout < 1) return false;
-    if (D > 255 || H > 255 || W > 255) return false;                   // packed 8-bit halo coordinates
-    g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.pd = pd; g.ph = ph; g.pw = pw;
-    g.Do = D + 2 * pd + epd - 2; g.Ho = H + 2 * ph + eph - 2; g.Wo = W + 2 * pw + epw - 2;
-    if (g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return false;
-    g.tilesD = (g.Do + 7) / 8; g.tilesH = (g.Ho + 7) / 8; g.tilesW = (g.Wo + 7) / 8;
-    g.nNt = (Cout + 63) / 64; g.CoutPad = g.nNt * 64;
-    const long long mt = (long long)B * g.tilesD * g.tilesH * g.tilesW;
-    const unsigned long long xb = (unsigned long long)B * D * H * W * Cin * 4ull, yb = (unsigned long long)B * g.Do * g.Ho * g.Wo * Cout * 4ull;
-    const unsigned long long wb = (unsigned long long)packedElems * 4ull;
-    if (mt >= (1ll << 30) || xb >= (1ull << 30) || yb >= (1ull << 30) || wb >= (1ull << 30)) return false;
-    g.MT = (int)mt; g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.wBytes = (unsigned)wb; g.stats = nullptr;
-    // efficiency of the 8^3 tile on ragged extents, and whole rounds of one workgroup per CU
-    const double useful = (double)g.Do * g.Ho * g.Wo / ((double)g.tilesD * g.tilesH * g.tilesW * 512.0);
+using F9_333_512 = F9Cfg<3, 3, 3, 8, 8, 8, 4>;
+using F9_333_256 = F9Cfg<3, 3, 3, 4, 8, 8, 2>;
+using F9_133_A = F9Cfg<1, 3, 3, 1, 16, 32, 4>;       // a 32-wide frame row pair per block row
+using F9_133_B = F9Cfg<1, 3, 3, 2, 16, 16, 4>;
+using F9_133_C = F9Cfg<1, 3, 3, 4, 8, 8, 2>;         // 8x8 frames: 256-voxel tiles
+
+template <class C> static bool f9_try(F9Geom& g, size_t& lds, unsigned& grid, int mode) {
+    g.tilesD = (g.Do + C::TD - 1) / C::TD; g.tilesH = (g.Ho + C::TH - 1) / C::TH; g.tilesW = (g.Wo + C::TW - 1) / C::TW;
+    const long long mt = (long long)g.B * g.tilesD * g.tilesH * g.tilesW;
+    if (mt >= (1ll << 30)) return false;
+    g.MT = (int)mt;
+    // efficiency of the tile on ragged extents, and whole rounds of one workgroup per CU
+    const double useful = (double)g.Do * g.Ho * g.Wo / ((double)g.tilesD * g.tilesH * g.tilesW * (double)(C::TD * C::TH * C::TW));
     const long long nwg = mt * g.nNt;
     if (mode != 2 && (useful < 0.9 || nwg < 256 || (double)nwg / (double)((nwg + 255) / 256 * 256) < 0.94)) return false;
     grid = (nwg > 256 && 256 % g.nNt == 0) ? 256u : (unsigned)nwg;     // persistent walk: a workgroup keeps its 64-channel block
-    lds = f9::LDS_BYTES;
+    lds = C::LDS_BYTES;
     return true;
+}
+
+bool fwd9_plan(F9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
+               int ph, int pw, int epd, int eph, int epw, size_t packedElems) {
+    static const int mode = [] { const char* e = getenv("DIQT_CONV_F9"); return e ? atoi(e) : 1; }();      // 0: never, 2: any tile count
+    const bool k333 = kd == 3 && kh == 3 && kw == 3, k133 = kd == 1 && kh == 3 && kw == 3;
+    if (!mode || !(k333 || k133) || Cin % F9_CH != 0 || Cin < F9_CH || Cout < 1) return false;
+    if (D > 255 || H > 255 || W > 255) return false;                   // packed 8-bit halo coordinates
+    g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.pd = pd; g.ph = ph; g.pw = pw;
+    g.Do = D + 2 * pd + epd - kd + 1; g.Ho = H + 2 * ph + eph - kh + 1; g.Wo = W + 2 * pw + epw - kw + 1;
+    if (g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return false;
+    g.nNt = (Cout + 63) / 64; g.CoutPad = g.nNt * 64;
+    const unsigned long long xb = (unsigned long long)B * D * H * W * Cin * 4ull, yb = (unsigned long long)B * g.Do * g.Ho * g.Wo * Cout * 4ull;
+    const unsigned long long wb = (unsigned long long)packedElems * 4ull;
+    if (xb >= (1ull << 30) || yb >= (1ull << 30) || wb >= (1ull << 30)) return false;
+    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.wBytes = (unsigned)wb; g.stats = nullptr;
+    if (k333) {
+        if (f9_try<F9_333_512>(g, lds, grid, mode)) { g.variant = 0; return true; }
+        if (f9_try<F9_333_256>(g, lds, grid, mode)) { g.variant = 1; return true; }
+        return false;
+    }
+    if (f9_try<F9_133_A>(g, lds, grid, mode)) { g.variant = 2; return true; }
+    if (f9_try<F9_133_B>(g, lds, grid, mode)) { g.variant = 3; return true; }
+    if (f9_try<F9_133_C>(g, lds, grid, mode)) { g.variant = 4; return true; }
+    return false;
+}
+
+template <class C> static int f9_launch(const float* x, const float* packed, const float* bias, const float* residual, float* y,
+                                        const F9Geom& g, size_t lds, unsigned grid, void* stream) {
+    auto kern = conv_fwd9_kernel<C>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd(v9): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
+    return check_launch("conv3d_fwd(v9)");
 }
 
 int fwd9_launch(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
                 unsigned grid, void* stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd9_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd(v9): hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(conv_fwd9_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
-    return check_launch("conv3d_fwd(v9)");
+    switch (g.variant) {
+        case 0: return f9_launch<F9_333_512>(x, packed, bias, residual, y, g, lds, grid, stream);
+        case 1: return f9_launch<F9_333_256>(x, packed, bias, residual, y, g, lds, grid, stream);
+        case 2: return f9_launch<F9_133_A>(x, packed, bias, residual, y, g, lds, grid, stream);
+        case 3: return f9_launch<F9_133_B>(x, packed, bias, residual, y, g, lds, grid, stream);
+        case 4: return f9_launch<F9_133_C>(x, packed, bias, residual, y, g, lds, grid, stream);
+    }
+    set_error("conv3d_fwd(v9): no variant");
+    return DIQT_E_UNSUPPORTED;
 }
 
 }  // namespace diqt

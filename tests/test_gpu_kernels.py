@@ -608,31 +608,39 @@ def test_conv3d_neighbour_halo_equals_boundary_pad_copies(ops, f, A, Cin, Cout, 
     close(ops.conv3d_neighbours(x, w, b, f), want, what="neighbour conv vs float64 conv of the merged volume")
 
 
-@pytest.mark.parametrize("B,sp,Cin,Cout,pad,res", [
-    (4, (32, 32, 32), 64, 64, 1, False),      # exactly one round of 256 workgroups (no tile walk)
-    (8, (32, 32, 32), 64, 64, 1, True),       # the headline's dominant launch: persistent walk, 2 tiles per workgroup, 4 chunks; residual
-    (8, (32, 32, 30), 32, 128, 1, False),     # ragged W tiles, two 64-channel blocks (the workgroup keeps its block over the walk)
-    (8, (34, 34, 34), 16, 48, 0, True),       # un-padded ('boundary' copies): no halo outside the volume; one chunk; ragged Cout
-    (12, (31, 32, 32), 48, 64, 1, False)])    # 3 chunks, ragged D, 3 tiles per workgroup
-def test_conv3d_on_the_one_wave_per_simd_kernel(ops, B, sp, Cin, Cout, pad, res):
-    """conv_fwd9_kernel (512-voxel tiles, LDS-DMA double-buffered 16-channel halo chunks, weight ring) against a float64 conv:
-    output, residual epilogue, per-tile column sums, and the backward-data pass that runs on the same kernel."""
+@pytest.mark.parametrize("B,sp,Cin,Cout,k,pad,res", [
+    (4, (32, 32, 32), 64, 64, (3, 3, 3), 1, False),      # exactly one round of 256 workgroups (no tile walk)
+    (8, (32, 32, 32), 64, 64, (3, 3, 3), 1, True),       # the headline's dominant launch: persistent walk, 2 tiles per workgroup, 4 chunks; residual
+    (8, (32, 32, 30), 32, 128, (3, 3, 3), 1, False),     # ragged W tiles, two 64-channel blocks (the workgroup keeps its block over the walk)
+    (8, (34, 34, 34), 16, 48, (3, 3, 3), 0, True),       # un-padded ('boundary' copies): no halo outside the volume; one chunk; ragged Cout
+    (12, (31, 32, 32), 48, 64, (3, 3, 3), 1, False),     # 3 chunks, ragged D, 3 tiles per workgroup
+    (8, (16, 16, 16), 128, 128, (3, 3, 3), 1, True),     # the 16^3 level: 256-voxel tiles (4 x 8 x 8), one round
+    (16, (15, 16, 16), 32, 128, (3, 3, 3), 1, False),    # 256-voxel tiles: ragged D, walk of 2 tiles
+    (8, (32, 32, 32), 64, 64, (1, 3, 3), 1, True),       # Family B full resolution: (1,3,3) filter, 1 x 16 x 32 tiles, walk of 2
+    (8, (32, 30, 32), 32, 64, (1, 3, 3), 1, False),      # ... ragged H
+    (8, (32, 34, 34), 16, 48, (1, 3, 3), 0, False),      # ... un-padded, ragged Cout
+    (8, (32, 16, 16), 128, 128, (1, 3, 3), 1, True),     # Family B second level: 2 x 16 x 16 tiles
+    (8, (32, 8, 8), 256, 256, (1, 3, 3), 1, False)])     # Family B third level: 4 x 8 x 8 tiles of 256 voxels, four 64-channel blocks
+def test_conv3d_on_the_one_wave_per_simd_kernel(ops, B, sp, Cin, Cout, k, pad, res):
+    """conv_fwd9_kernel (512- / 256-voxel tiles, LDS-DMA double-buffered 16-channel halo chunks, weight ring) against a float64 conv:
+    output, residual epilogue, per-tile column sums, run-to-run determinism."""
     from diffusioniqt_amd import _lib
     D, H, W = sp
-    assert _lib.query("diqt_conv3d_fwd_kernel_id", B, D, H, W, Cin, Cout, 3, 3, 3, pad, pad, pad, 0, 0, 0) == 4, "not routed to conv_fwd9_kernel"
+    pads = tuple(pad * (kk // 2) for kk in k)
+    assert _lib.query("diqt_conv3d_fwd_kernel_id", B, D, H, W, Cin, Cout, *k, *pads, 0, 0, 0) == 4, "not routed to conv_fwd9_kernel"
     g = torch.Generator().manual_seed(B * 1000 + Cin)
     x = torch.randn(B, Cin, D, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(Cin * 27)
+    w = torch.randn(Cout, Cin, *k, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
     b = torch.randn(Cout, generator=g) * 0.1
-    Do, Ho, Wo = D + 2 * pad - 2, H + 2 * pad - 2, W + 2 * pad - 2
+    Do, Ho, Wo = (n + 2 * p - kk + 1 for n, p, kk in zip(sp, pads, k))
     r = torch.randn(B, Cout, Do, Ho, Wo, generator=g) if res else None
     xd, wd, bd = cl(x), w.to(DEV), b.to(DEV)
     with torch.no_grad():
-        y = ops.conv3d(xd, wd, bd, (pad,) * 3, residual=cl(r) if res else None, want_stats=True)
+        y = ops.conv3d(xd, wd, bd, pads, residual=cl(r) if res else None, want_stats=True)
     # float64 reference on the host for the first / last batch entry and the first / last 8 output channels (the full conv in
     # float64 would take the CPU minutes); the column sums below tie the rest of the tensor to these
     bs, cs = [0, B - 1], list(range(8)) + list(range(Cout - 8, Cout))
-    ref = F.conv3d(x[bs].double(), w[cs].double(), b[cs].double(), padding=pad)
+    ref = F.conv3d(x[bs].double(), w[cs].double(), b[cs].double(), padding=pads)
     if res:
         ref = ref + r[bs][:, cs].double()
     close(cf(y)[bs][:, cs], ref, what="conv_fwd9 output")
@@ -641,8 +649,18 @@ def test_conv3d_on_the_one_wave_per_simd_kernel(ops, B, sp, Cin, Cout, pad, res)
     close(st.partials[:, :, 0, :].double().sum(1), y.double().sum(dim=(1, 2, 3)), tol=1e-5, what="per-tile column sums")
     close(st.partials[:, :, 1, :].double().sum(1), (y.double() ** 2).sum(dim=(1, 2, 3)), tol=1e-5, what="per-tile sums of squares")
     with torch.no_grad():
-        y2 = ops.conv3d(xd, wd, bd, (pad,) * 3, residual=cl(r) if res else None)
+        y2 = ops.conv3d(xd, wd, bd, pads, residual=cl(r) if res else None)
     assert torch.equal(y, y2), "conv_fwd9 is not run-to-run deterministic"
+    # the middle batch entries and channels: a batch-rotated input must give the batch-rotated output, bit for bit (tiles of different
+    # workgroups / walk positions compute the same voxels), which ties every batch entry to the two checked in float64 ...
+    with torch.no_grad():
+        yr = ops.conv3d(torch.roll(xd, 1, 0).contiguous(), wd, bd, pads, residual=torch.roll(cl(r), 1, 0).contiguous() if res else None)
+    assert torch.equal(torch.roll(y, 1, 0), yr), "conv_fwd9: a tile's result depends on which workgroup computed it"
+    # ... and an output-channel rotation of the filter ties every channel to the 16 checked
+    with torch.no_grad():
+        yc = ops.conv3d(xd, torch.roll(wd, 8, 0).contiguous(), torch.roll(bd, 8, 0).contiguous(), pads,
+                        residual=torch.roll(cl(r), 8, -1).contiguous() if res else None)
+    assert torch.equal(torch.roll(y, 8, -1), yc), "conv_fwd9: a channel's result depends on its position in the 64-channel block"
 
 
 def test_multi_accumulate_matches_per_tensor_adds(ops):

@@ -12,13 +12,14 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 B, S, Cin, Cout = (int(v) for v in sys.argv[3:7]) if len(sys.argv) > 6 else (8, 32, 64, 64)
 _lib.load()
 dev = "cuda"
-x = torch.randn(B, S, S, S, Cin, device=dev)
+SP = tuple(int(v) for v in os.environ["SHAPE"].split(",")) if "SHAPE" in os.environ else (S, S, S)    # non-cubic volumes (Family B: frames x H x W)
+x = torch.randn(B, *SP, Cin, device=dev)
 KS = tuple(int(v) for v in os.environ.get("KSHAPE", "3,3,3").split(","))      # filter extents (padding = k // 2)
 PADS = tuple(k // 2 for k in KS)
 w = (torch.randn(Cout, Cin, *KS, device=dev) * 0.02).requires_grad_()
 bias = torch.zeros(Cout, device=dev, requires_grad=True)
-dy = torch.randn(B, S, S, S, Cout, device=dev)
-flops = 2.0 * B * S ** 3 * Cin * Cout * KS[0] * KS[1] * KS[2]
+dy = torch.randn(B, *SP, Cout, device=dev)
+flops = 2.0 * B * SP[0] * SP[1] * SP[2] * Cin * Cout * KS[0] * KS[1] * KS[2]
 
 
 def timeit(fn, n):
@@ -37,7 +38,7 @@ def timeit(fn, n):
 if mode in ("fwd", "both"):
     with torch.no_grad():
         ms = timeit(lambda: ops.conv3d(x, w, bias, PADS), iters)
-    print(f"conv fwd  B={B} {S}^3 {Cin}->{Cout}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
+    print(f"conv fwd  B={B} {SP} k={KS} {Cin}->{Cout}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
 if mode in ("fwdh",):           # fp16 / bf16 operand kernel (LP=fp16|bf16)
     with torch.no_grad(), ops.low_precision(os.environ.get("LP", "fp16")):
         ms = timeit(lambda: ops.conv3d(x, w, bias, PADS), iters)

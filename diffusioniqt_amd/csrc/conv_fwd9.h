@@ -7,13 +7,17 @@ namespace diqt {
 struct F9Geom {
     int B, D, H, W, Cin, Cout, Do, Ho, Wo, pd, ph, pw;
     int tilesD, tilesH, tilesW, MT, nNt, CoutPad, variant;
+    int ksplit, chunksPerSplit;  // split-K launches: gridDim.y slabs of slabElems floats, chunksPerSplit 16-channel chunks each
+    unsigned slabElems;
     unsigned xBytes, yBytes, wBytes;
     float* stats;                // optional per-tile column sums of the output: [B][tiles per batch][2][Cout]
 };
 
+// maySplit: the caller has a workspace for split-K slabs (g.ksplit * output elements floats when g.ksplit > 1; the kernel then gets
+// the slab base as y and no bias / residual / statistics).
 // Does conv_fwd9_kernel take this launch (3x3x3 or (1,3,3), Cin % 16 == 0, whole rounds of 512- / 256-voxel tiles, tensors < 1 GiB)?
 bool fwd9_plan(F9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
-               int ph, int pw, int epd, int eph, int epw, size_t packedElems);
+               int ph, int pw, int epd, int eph, int epw, size_t packedElems, bool maySplit);
 int fwd9_launch(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
                 unsigned grid, void* stream);
 

@@ -70,11 +70,14 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
     if (L >= total) return;
     const int nMine = (int)((total - 1 - L) / Gn) + 1;
     const int n0 = (int)(L % g.nNt) * 64;
-    const int nC = g.Cin / CH;
+    // split-K launches (gridDim.y > 1; small volumes: the 8^3 level of C2): this workgroup walks chunksPerSplit of the 16-channel
+    // chunks and writes its partial sums into slab blockIdx.y (bias / residual / statistics come with conv_fwd_reduce_kernel)
+    const int cBeg = (int)blockIdx.y * g.chunksPerSplit;
+    const int cEnd = min(g.Cin / CH, cBeg + g.chunksPerSplit);
 
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, (int)g.wBytes, 0x00020000);
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)blockIdx.y * g.slabElems, 0, (int)g.yBytes, 0x00020000);
     const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
     const unsigned ldsBase = (unsigned)(size_t)(lds_void9*)smem9;
     const unsigned wringBase = ldsBase + 2 * HB;
@@ -153,19 +156,19 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
     tile_of(L, tb, d0, h0, w0);
     set_fetch(L, true);
 #pragma unroll
-    for (int r = 0; r < NPH; ++r) dma_h(r, ldsBase, 0);
-    dma_w(0, 0, wringBase, 0); dma_w(0, 1, wringBase, 1);
-    dma_w(0, 2, wringBase + WSLOT, 0); dma_w(0, 3, wringBase + WSLOT, 1);
+    for (int r = 0; r < NPH; ++r) dma_h(r, ldsBase, cBeg);
+    dma_w(cBeg, 0, wringBase, 0); dma_w(cBeg, 1, wringBase, 1);
+    dma_w(cBeg, 2, wringBase + WSLOT, 0); dma_w(cBeg, 3, wringBase + WSLOT, 1);
     __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0)
     __syncthreads();
 
     int wcur = 0, hcur = 0;
     for (int it = 0; it < nMine; ++it) {
         const bool lastTile = it + 1 == nMine;
-        for (int c = 0; c < nC; ++c) {
+        for (int c = cBeg; c < cEnd; ++c) {
             // which (tile, chunk) the halo pieces issued during this chunk belong to, and the chunk the wrapped weight steps belong to
-            const bool wrap = c + 1 == nC;
-            const int cNext = wrap ? 0 : c + 1;
+            const bool wrap = c + 1 == cEnd;
+            const int cNext = wrap ? cBeg : c + 1;
             if (wrap) set_fetch(L + Gn, !lastTile);        // from here on the fetches are the next tile's first chunk (or dead)
             const unsigned hbufN = ldsBase + (unsigned)(hcur ^ 1) * HB;
             const char* hb[NVB];
@@ -292,22 +295,33 @@ using F9_133_A = F9Cfg<1, 3, 3, 1, 16, 32, 4>;       // a 32-wide frame row pair
 using F9_133_B = F9Cfg<1, 3, 3, 2, 16, 16, 4>;
 using F9_133_C = F9Cfg<1, 3, 3, 4, 8, 8, 2>;         // 8x8 frames: 256-voxel tiles
 
-template <class C> static bool f9_try(F9Geom& g, size_t& lds, unsigned& grid, int mode) {
+template <class C> static bool f9_try(F9Geom& g, size_t& lds, unsigned& grid, int mode, bool maySplit) {
     g.tilesD = (g.Do + C::TD - 1) / C::TD; g.tilesH = (g.Ho + C::TH - 1) / C::TH; g.tilesW = (g.Wo + C::TW - 1) / C::TW;
     const long long mt = (long long)g.B * g.tilesD * g.tilesH * g.tilesW;
     if (mt >= (1ll << 30)) return false;
     g.MT = (int)mt;
     // efficiency of the tile on ragged extents, and whole rounds of one workgroup per CU
     const double useful = (double)g.Do * g.Ho * g.Wo / ((double)g.tilesD * g.tilesH * g.tilesW * (double)(C::TD * C::TH * C::TW));
-    const long long nwg = mt * g.nNt;
-    if (mode != 2 && (useful < 0.9 || nwg < 256 || (double)nwg / (double)((nwg + 255) / 256 * 256) < 0.94)) return false;
-    grid = (nwg > 256 && 256 % g.nNt == 0) ? 256u : (unsigned)nwg;     // persistent walk: a workgroup keeps its 64-channel block
+    long long nwg = mt * g.nNt;
+    const int nC = g.Cin / F9_CH;
+    g.ksplit = 1; g.chunksPerSplit = nC; g.slabElems = 0;
+    if (nwg < 241 && maySplit && nC >= 2) {
+        // too few tiles for one round of 256 workgroups: split K over the 16-channel chunks in equal shares, partial sums to slabs
+        int ks = (int)(256 / nwg);
+        if (ks > 16) ks = 16;
+        while (ks > 1 && nC % ks != 0) --ks;
+        if (ks > 1) { g.ksplit = ks; g.chunksPerSplit = nC / ks; g.slabElems = g.yBytes / 4u; nwg *= ks; }
+    }
+    if (mode != 2 && (useful < 0.9 || nwg < 241 || (double)nwg / (double)((nwg + 255) / 256 * 256) < 0.94)) return false;
+    if (g.ksplit > 1 && (unsigned long long)g.yBytes * g.ksplit >= (1ull << 32)) return false;
+    // persistent walk: a workgroup keeps its 64-channel block
+    grid = (g.ksplit == 1 && nwg > 256 && 256 % g.nNt == 0) ? 256u : (unsigned)(nwg / g.ksplit);
     lds = C::LDS_BYTES;
     return true;
 }
 
 bool fwd9_plan(F9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
-               int ph, int pw, int epd, int eph, int epw, size_t packedElems) {
+               int ph, int pw, int epd, int eph, int epw, size_t packedElems, bool maySplit) {
     static const int mode = [] { const char* e = getenv("DIQT_CONV_F9"); return e ? atoi(e) : 1; }();      // 0: never, 2: any tile count
     const bool k333 = kd == 3 && kh == 3 && kw == 3, k133 = kd == 1 && kh == 3 && kw == 3;
     if (!mode || !(k333 || k133) || Cin % F9_CH != 0 || Cin < F9_CH || Cout < 1) return false;
@@ -320,14 +334,25 @@ bool fwd9_plan(F9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int 
     const unsigned long long wb = (unsigned long long)packedElems * 4ull;
     if (xb >= (1ull << 30) || yb >= (1ull << 30) || wb >= (1ull << 30)) return false;
     g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.wBytes = (unsigned)wb; g.stats = nullptr;
+    // un-split launches first (the statistics query of the consumer's GroupNorm plans with maySplit = false and must see the same tiles)
     if (k333) {
-        if (f9_try<F9_333_512>(g, lds, grid, mode)) { g.variant = 0; return true; }
-        if (f9_try<F9_333_256>(g, lds, grid, mode)) { g.variant = 1; return true; }
-        return false;
+        if (f9_try<F9_333_512>(g, lds, grid, mode, false)) { g.variant = 0; return true; }
+        if (f9_try<F9_333_256>(g, lds, grid, mode, false)) { g.variant = 1; return true; }
+    } else {
+        if (f9_try<F9_133_A>(g, lds, grid, mode, false)) { g.variant = 2; return true; }
+        if (f9_try<F9_133_B>(g, lds, grid, mode, false)) { g.variant = 3; return true; }
+        if (f9_try<F9_133_C>(g, lds, grid, mode, false)) { g.variant = 4; return true; }
     }
-    if (f9_try<F9_133_A>(g, lds, grid, mode)) { g.variant = 2; return true; }
-    if (f9_try<F9_133_B>(g, lds, grid, mode)) { g.variant = 3; return true; }
-    if (f9_try<F9_133_C>(g, lds, grid, mode)) { g.variant = 4; return true; }
+    if (!maySplit) return false;
+    // split-K: the small tiles first (fewer slabs for the same number of workgroups)
+    if (k333) {
+        if (f9_try<F9_333_256>(g, lds, grid, mode, true)) { g.variant = 1; return true; }
+        if (f9_try<F9_333_512>(g, lds, grid, mode, true)) { g.variant = 0; return true; }
+    } else {
+        if (f9_try<F9_133_C>(g, lds, grid, mode, true)) { g.variant = 4; return true; }
+        if (f9_try<F9_133_B>(g, lds, grid, mode, true)) { g.variant = 3; return true; }
+        if (f9_try<F9_133_A>(g, lds, grid, mode, true)) { g.variant = 2; return true; }
+    }
     return false;
 }
 
@@ -336,7 +361,7 @@ template <class C> static int f9_launch(const float* x, const float* packed, con
     auto kern = conv_fwd9_kernel<C>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd(v9): hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
+    hipLaunchKernelGGL(kern, dim3(grid, g.ksplit), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
     return check_launch("conv3d_fwd(v9)");
 }
 

@@ -1621,7 +1621,19 @@ extern "C" size_t diqt_conv3d_fwd_workspace_bytes(int B, int D, int H, int W, in
     ConvGeom g;
     if (make_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return 0;
     const int ks = fwd_ksplit(g);
-    return ks > 1 ? (size_t)ks * g.B * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float) : 0;
+    size_t need = ks > 1 ? (size_t)ks * g.B * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float) : 0;
+    {
+        F9Geom g9;
+        size_t l9;
+        unsigned gr9;
+        if (Cin % 4 == 0 && !smallcin_pad(Cin, kd * kh * kw) &&
+            fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw), true) &&
+            g9.ksplit > 1) {
+            const size_t n9 = (size_t)g9.ksplit * g.B * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float);
+            if (n9 > need) need = n9;
+        }
+    }
+    return need;
 }
 
 static int conv3d_fwd_impl(const float* x, const float* packed, const float* bias, const float* residual,
@@ -1703,8 +1715,8 @@ static int fwd_stats_blocks_impl(int B, int D, int H, int W, int Cin, int Cout, 
         size_t l9;
         unsigned gr9;
         if (!neighbours && Cin % 4 == 0 && fwd_ksplit(g) <= 1 && !smallcin_pad(Cin, kd * kh * kw) &&
-            fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw)))
-            return g9.tilesD * g9.tilesH * g9.tilesW;                          // conv_fwd9_kernel: one row per 512-voxel tile
+            fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw), false))
+            return g9.tilesD * g9.tilesH * g9.tilesW;                          // conv_fwd9_kernel: one row per 512- / 256-voxel tile
     }
     if (fwd8_plan(g, g8, lds8)) return g8.tilesD * g8.tilesH * g8.tilesW;      // the 8-wave kernel writes one row per 256-voxel tile
     return g.tilesD * g.tilesH * g.tilesW;
@@ -1721,14 +1733,15 @@ extern "C" int diqt_conv3d_fwd_kernel_id(int B, int D, int H, int W, int Cin, in
     const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
     const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
     const bool buf = Cin % 4 == 0 && xb < (1ull << 30) && yb < (1ull << 30);
-    if (!buf || fwd_ksplit(g) > 1) return 0;
+    if (!buf) return 0;
     {
         F9Geom g9;
         size_t l9;
         unsigned gr9;
-        if (fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw)))
-            return 4;
+        if (fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw), true))
+            return 4;                // incl. its split-K form (callers that pass the workspace diqt_conv3d_fwd_workspace_bytes asks for)
     }
+    if (fwd_ksplit(g) > 1) return 0;
     ConvGeom g8;
     size_t lds8;
     if (fwd8_plan(g, g8, lds8)) return 3;
@@ -1879,6 +1892,30 @@ static int conv3d_fwd_one(const float* x, const float* packed, const float* bias
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
+    if (buf && !ck16 && g.subF == 0) {
+        // conv_fwd9_kernel first: whole rounds of 512- / 256-voxel tiles, or (small volumes) split-K slabs in the caller's workspace
+        F9Geom g9;
+        size_t l9;
+        unsigned gr9;
+        const bool maySplit = workspace && aligned16(workspace);
+        if (fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw),
+                      maySplit)) {
+            if (g9.ksplit == 1) {
+                g9.stats = stats;
+                return fwd9_launch(x, packed, bias, residual, y, g9, l9, gr9, stream);
+            }
+            const size_t n = (size_t)g.B * g.Do * g.Ho * g.Wo * g.Cout;
+            if (!stats && workspace_bytes >= (size_t)g9.ksplit * n * sizeof(float)) {
+                float* slabs = static_cast<float*>(workspace);
+                g9.stats = nullptr;
+                rc = fwd9_launch(x, packed, nullptr, nullptr, slabs, g9, l9, gr9, stream);
+                if (rc) return rc;
+                hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, slabs, bias,
+                                   residual, y, n, g.Cout, g9.ksplit);
+                return check_launch("conv3d_fwd(v9 split-K reduce)");
+            }
+        }
+    }
     const int ks = workspace ? fwd_ksplit(g) : 1;
     static const int tpw_env = [] { const char* e = getenv("DIQT_CONV_TPW"); return e ? atoi(e) : 0; }();
     int tpw = tpw_env > 0 ? tpw_env : 1;      // measured: 2 or 4 tiles per workgroup change nothing (457 / 464 / 459 us), see profiles/r01_conv_ablation.md
@@ -1904,16 +1941,6 @@ static int conv3d_fwd_one(const float* x, const float* packed, const float* bias
     if (buf && !ck16) {
         ConvGeom g8;
         size_t lds8;
-        {
-            F9Geom g9;
-            size_t l9;
-            unsigned gr9;
-            if (g.subF == 0 && fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw,
-                                         diqt_conv_packed_elems(Cout, Cin, kd, kh, kw))) {
-                g9.stats = stats;
-                return fwd9_launch(x, packed, bias, residual, y, g9, l9, gr9, stream);
-            }
-        }
         if (fwd8_plan(g, g8, lds8)) {
             g8.stats = stats;
             g8.dbg = nullptr;

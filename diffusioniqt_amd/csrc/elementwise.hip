@@ -4,10 +4,11 @@
 // All activations are fp32 channels-last rows x[row][C]; every streaming access is 16 B per lane when
 // C % 4 == 0 and the pointers are 16-byte aligned (the scalar variants cover the rest).
 #include "common.h"
+#include <stdlib.h>
 
 namespace diqt {
 
-constexpr int RED_NBLK = 64;   // row slices per batch element in the column reductions
+constexpr int RED_NBLK = 256;  // row slices per batch element in the column reductions (8 x 256 workgroups: 64 slices left the loads of a 32^3 x 64 pass at 4 TB/s)
 
 // ---------------------------------------------------------------------------------------------
 // generic per-(b,c) column reduction: partial[b][blk][NV][C] = sum over the block's rows of f(...)
@@ -86,8 +87,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, float* __restrict__
 }
 
 static inline int red_nblk(int rows) {
+    static const int cap = [] { const char* e = getenv("DIQT_RED_NBLK"); const int v = e ? atoi(e) : RED_NBLK; return v < 1 || v > RED_NBLK ? RED_NBLK : v; }();
     int n = rows / 64;
-    if (n > RED_NBLK) n = RED_NBLK;
+    if (n > cap) n = cap;
     if (n < 1) n = 1;
     return n;
 }

@@ -138,9 +138,12 @@ class BucketedGradReducer:
     skips communication like DDP's ``no_sync``.
     """
 
-    def __init__(self, arena: FlatArena, bucket_cap_mb=25.0, first_bucket_mb=1.0, process_group=None):
+    def __init__(self, arena: FlatArena, bucket_cap_mb=25.0, first_bucket_mb=1.0, process_group=None, force=False):
         self.arena, self.pg = arena, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force: run the collectives on a one-rank group too (bring-up of the RCCL path on a one-GPU box, tests/test_gpu_rccl.py);
+        # a single-rank mean is the identity, so the gradients must come out unchanged
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.sync = True
         self.used = None                    # learned set of parameter indices that receive gradients
         self._seen, self._pending, self._handles = set(), {}, []
@@ -161,7 +164,7 @@ class BucketedGradReducer:
 
     def _make_hook(self, i):
         def hook(_param):
-            if self.world == 1 or not self.sync:
+            if not self.active or not self.sync:
                 return
             self._seen.add(i)
             if self.used is None:
@@ -196,7 +199,7 @@ class BucketedGradReducer:
 
     def finalize_backward(self):
         """Call after ``loss.backward()`` of a synchronised micro-step: launches whatever is left and waits."""
-        if self.world == 1 or not self.sync:
+        if not self.active or not self.sync:
             return
         for b in range(len(self.buckets)):
             if b not in self._launched:

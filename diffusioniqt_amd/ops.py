@@ -229,7 +229,8 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0), stat
         # the tag names the kernel the C side dispatches to, so that bench.py's per-kernel numbers line up with rocprofv3's
         taps = kd * kh * kw
         kid = _lib.query("diqt_conv3d_fwd_kernel_id", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
-        tag = ("conv_fwd_kernel", "conv_fwd_smallcin_kernel", "conv1x1_fwd_kernel", "conv_fwd8_kernel", "conv_fwd9_kernel")[kid if kid > 0 and n == 0 else 0]
+        # (a split-K launch -- n > 0 -- is conv_fwd9_kernel or conv_fwd_kernel writing slabs; its interval includes the slab sum)
+        tag = ("conv_fwd_kernel", "conv_fwd_smallcin_kernel", "conv1x1_fwd_kernel", "conv_fwd8_kernel", "conv_fwd9_kernel")[kid if kid > 0 and (n == 0 or kid == 4) else 0]
         TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * taps, tag, (B, D, H, W, Cin, Cout, kd, kh, kw)))
     return y
 

@@ -620,7 +620,11 @@ def test_conv3d_neighbour_halo_equals_boundary_pad_copies(ops, f, A, Cin, Cout, 
     (8, (32, 30, 32), 32, 64, (1, 3, 3), 1, False),      # ... ragged H
     (8, (32, 34, 34), 16, 48, (1, 3, 3), 0, False),      # ... un-padded, ragged Cout
     (8, (32, 16, 16), 128, 128, (1, 3, 3), 1, True),     # Family B second level: 2 x 16 x 16 tiles
-    (8, (32, 8, 8), 256, 256, (1, 3, 3), 1, False)])     # Family B third level: 4 x 8 x 8 tiles of 256 voxels, four 64-channel blocks
+    (8, (32, 8, 8), 256, 256, (1, 3, 3), 1, False),      # Family B third level: 4 x 8 x 8 tiles of 256 voxels, four 64-channel blocks
+    (8, (8, 8, 8), 256, 256, (3, 3, 3), 1, True),        # the 8^3 level: 64 tiles x co blocks -> split-K over 4 x 4 chunks, slabs + reduce
+    (8, (8, 8, 8), 384, 256, (3, 3, 3), 1, False),       # ... 24 chunks in 4 shares (the decoder's concatenated input)
+    (2, (16, 16, 16), 64, 128, (3, 3, 3), 1, True),      # ... one chunk per share
+    (4, (16, 8, 8), 256, 224, (1, 3, 3), 1, False)])     # (1,3,3) split-K, ragged Cout
 def test_conv3d_on_the_one_wave_per_simd_kernel(ops, B, sp, Cin, Cout, k, pad, res):
     """conv_fwd9_kernel (512- / 256-voxel tiles, LDS-DMA double-buffered 16-channel halo chunks, weight ring) against a float64 conv:
     output, residual epilogue, per-tile column sums, run-to-run determinism."""
@@ -645,9 +649,12 @@ def test_conv3d_on_the_one_wave_per_simd_kernel(ops, B, sp, Cin, Cout, k, pad, r
         ref = ref + r[bs][:, cs].double()
     close(cf(y)[bs][:, cs], ref, what="conv_fwd9 output")
     st = getattr(y, "_diqt_stats", None)
-    assert st is not None and st.rows == y.shape[1] * y.shape[2] * y.shape[3]
-    close(st.partials[:, :, 0, :].double().sum(1), y.double().sum(dim=(1, 2, 3)), tol=1e-5, what="per-tile column sums")
-    close(st.partials[:, :, 1, :].double().sum(1), (y.double() ** 2).sum(dim=(1, 2, 3)), tol=1e-5, what="per-tile sums of squares")
+    split = _lib.query("diqt_conv3d_fwd_workspace_bytes", B, D, H, W, Cin, Cout, *k, *pads, 0, 0, 0) > 0
+    assert (st is None) == split, "statistics come from un-split launches only"
+    if st is not None:
+        assert st.rows == y.shape[1] * y.shape[2] * y.shape[3]
+        close(st.partials[:, :, 0, :].double().sum(1), y.double().sum(dim=(1, 2, 3)), tol=1e-5, what="per-tile column sums")
+        close(st.partials[:, :, 1, :].double().sum(1), (y.double() ** 2).sum(dim=(1, 2, 3)), tol=1e-5, what="per-tile sums of squares")
     with torch.no_grad():
         y2 = ops.conv3d(xd, wd, bd, pads, residual=cl(r) if res else None)
     assert torch.equal(y, y2), "conv_fwd9 is not run-to-run deterministic"

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Re-collects the judged profiles of a round on the GPU box (one gpurun call):  bash tools/collect_profiles.sh <tag>
+# Outputs under gpurun_out/prof_<tag>/ ; copy the summaries into profiles/ afterwards (gpurun only merges gpurun_out/ back).
+set -e
+TAG=${1:-r02b}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="--no-cpu-baseline --no-extras --no-kernel-timer"
+stats() {  # name, command...
+  local n=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$n -o $n -- "$@" > $OUT/$n.log 2>&1
+  cp $(find /tmp/p_$n -name "*kernel_stats.csv" | head -1) $OUT/${n}_kernel_stats.csv
+  echo "done $n"
+}
+stats sample python3 $R/bench.py --mode sample --steps 20 --warmup 3 $B
+stats train python3 $R/bench.py --mode train --steps 12 --warmup 4 $B
+stats unet3d_eval python3 $R/tools/unet3d_bench.py 64 32 8
+stats unet3d_train python3 $R/tools/unet3d_train_bench.py 64 32 8
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $R/bench.py --mode both --steps 4 --warmup 4 $B > $OUT/pmc_fetch.log 2>&1
+echo "done fetch"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $R/bench.py --mode both --steps 4 --warmup 4 $B > $OUT/pmc_write.log 2>&1
+echo "done write"
+python3 $R/tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write $OUT/pmc_hbm_traffic.json "bench.py --mode both --steps 4 --warmup 4 $B"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/pmc_sq -- python3 $R/tools/conv_bench.py both 10 > $OUT/pmc_sq.log 2>&1
+cp $(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1) $OUT/pmc_sq_counter_collection.csv
+echo "done sq"

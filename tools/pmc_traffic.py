@@ -22,7 +22,9 @@ def collect(root, counter):
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] != counter:
                     continue
-                name = r["Kernel_Name"].split("(")[0]
+                # base name: template arguments dropped, so that the variants of one kernel (conv_fwd9_kernel<F9Cfg<...>>) are averaged
+                # together, the way bench.py's per-kernel timer tags them
+                name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
                 tot[name] += float(r["Counter_Value"])
                 cnt[name] += 1
     return tot, cnt

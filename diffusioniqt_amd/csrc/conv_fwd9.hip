@@ -1,21 +1,28 @@
-// Forward / backward-data 3x3x3 convolution for the LARGE launches of the U-Nets (the 32^3 level of C2: >= 512 tiles of 512 voxels),
-// version 9: the structure that took the weight gradient from 0.63 to 0.83 of the f32 MFMA peak (conv_wgrad.hip), applied to the
-// forward implicit GEMM  M = voxels, N = co, K = taps x ci  on v_mfma_f32_32x32x2_f32 (exact fp32; same fragment order and k order
-// per output element as conv_fwd_kernel / conv_fwd8_kernel, hence the same bits).
-//   * ONE wave per SIMD (256 threads, one workgroup per CU) with EIGHT accumulator tiles per wave: a workgroup owns an 8x8x8 block of
-//     512 output voxels x 64 co, a wave two 8x8 planes (128 voxels) x 64 co.  Twice the voxels per weight byte of the 256-voxel tile:
-//     every KiB landing in the CU costs ~100 cycles of matrix-pipe issue (profiles/r02_wgrad_ablation.md), and at 256 voxels the
-//     weight stream alone is 6 % of the MFMA time.
+// Forward / backward-data convolution of the 3x3x3 and (1,3,3) filters of the U-Nets, version 9: the structure that took the weight
+// gradient from 0.63 to 0.83 of the f32 MFMA peak (conv_wgrad.hip), applied to the forward implicit GEMM  M = voxels, N = co,
+// K = taps x ci  on v_mfma_f32_32x32x2_f32 (exact fp32 products and sums; K is walked chunk-major -- 16 channels x all taps -- where
+// conv_fwd_kernel / conv_fwd8_kernel walk 32-channel chunks, so results agree with theirs to rounding, not bit for bit).
+//   * ONE wave per SIMD (256 threads, one workgroup per CU) with EIGHT accumulator tiles per wave: a workgroup owns 512 output voxels
+//     x 64 co, a wave 128 voxels (4 blocks of 4 x 8) x 64 co.  Twice the voxels per weight byte of the 256-voxel tile: every KiB
+//     landing in the CU costs ~100 cycles of matrix-pipe issue (profiles/r02_wgrad_ablation.md), and at 256 voxels the weight stream
+//     alone is 6 % of the MFMA time.  Filter, tile extents and blocks per wave are template parameters (F9Cfg): 8x8x8 and 4x8x8
+//     (256 voxels, 4 accumulator tiles: the 16^3 level) for 3x3x3, 1x16x32 / 2x16x16 / 4x8x8 for the per-frame (1,3,3) convs of the
+//     pseudo-3D U-Net; the host picks the first variant whose tiles fill whole rounds of 256 workgroups.
 //   * K is walked in 16-channel chunks so that TWO halo images (10^3 voxels x 64 B) fit the LDS beside a 3-slot ring of 2-tap weight
 //     groups (152 KB): the next chunk's halo and the weight group two steps ahead arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`)
 //     while the current step computes -- no register staging, no tables, no full stop at a chunk boundary; a step ends with
 //     `s_waitcnt vmcnt(0)` + ONE barrier per 128 MFMAs of a wave.  Zero padding / ragged tiles = out-of-range buffer offsets
 //     (the DMA writes zeros), per lane from packed tile-independent coordinates (sign-bit test, no branches).
-//   * the 27 taps of a chunk are unrolled: every LDS offset of the 1728 MFMAs' operands is an immediate; fragments of tap t+1 are
-//     read (ds_read_b128) between the MFMAs of tap t, also across step and chunk boundaries.
+//   * the taps of a chunk are unrolled: every LDS offset of the 1728 MFMAs' operands is an immediate; fragments of tap t+1 are
+//     read (ds_read_b128) between the MFMAs of tap t, also across step boundaries.
 //   * persistent tile walk: the first chunk of the next tile is prefetched during the last chunk of the current one, the weight
 //     ring runs on; a tile boundary is the epilogue (bias, residual, per-tile column sums for the consumer's GroupNorm / SE pool).
-// Reference call sites: Block.project of every ResnetBlock at the full-resolution level (/root/reference/imagen_pytorch3D.py:535-566).
+//   * small volumes (the 8^3 level: fewer tiles than CUs): gridDim.y splits the chunks into equal shares that write slabs, summed in
+//     a fixed order (with bias / residual) by conv_fwd_reduce_kernel.
+// Measured (MI355X, 64->64 3x3x3 @ 8x32^3): 411 us = 141 TFLOP/s = 0.90 of the f32 MFMA peak (conv_fwd8_kernel: 444 us); MFMA pipe
+// busy 0.92 of the kernel's cycles, 6 % of wave cycles waiting (profiles/r02_pmc_sq_conv.json).
+// Reference call sites: Block.project of every ResnetBlock (/root/reference/imagen_pytorch3D.py:535-566) and the per-frame Conv2d of
+// the pseudo-3D blocks (/root/reference/imagen_video.py:352-381 Conv3d.spatial_conv, 671-697 Block).
 #include "common.h"
 #include "conv_fwd9.h"
 #include <stdlib.h>

@@ -95,7 +95,9 @@ int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const float* bias, c
  * (sum, sum of squares) over the valid voxels of each output tile, nblk = diqt_conv3d_fwd_stats_blocks(...) (0: this shape
  * takes a path without statistics and `stats` must be NULL).  Saves one full read of the tensor per consumer.            */
 /* Diagnostic: the kernel diqt_conv3d_fwd* runs for this shape -- 0 conv_fwd_kernel, 1 conv_fwd_smallcin_kernel, 2 conv1x1_fwd_kernel,
- * 3 conv_fwd8_kernel (-1: bad shape) -- so that per-kernel timings taken around the call carry the names rocprofv3 reports.       */
+ * 3 conv_fwd8_kernel, 4 conv_fwd9_kernel (incl. its split-K form, taken when the caller passes the workspace that
+ * diqt_conv3d_fwd_workspace_bytes asks for) (-1: bad shape) -- so that per-kernel timings taken around the call carry the names
+ * rocprofv3 reports.                                                                                                               */
 int diqt_conv3d_fwd_kernel_id(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                               int epd, int eph, int epw);
 int diqt_conv3d_fwd_stats_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,

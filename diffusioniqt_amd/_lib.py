@@ -43,6 +43,7 @@ PROTOTYPES = {
     "diqt_gn_act_fwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "diqt_gn_act_bwd": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_chan_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "diqt_chan_layernorm_fwd_res": (I, [P, P, P, P, P, P, P, I, I, F, P]),
     "diqt_chan_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, P]),
     "diqt_act_fwd": (I, [P, P, Z, I, P]),
     "diqt_act_bwd": (I, [P, P, P, Z, I, P]),

@@ -750,6 +750,8 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
 
     const int nqt = (R + 31) / 32;
     const bool active = kbase + kt * 32 < M || doNull;     // wave-uniform
+    const bool plain = !rel && !null_bias && !causal;      // kernel-uniform
+    const int hs = (h & (h - 1)) == 0 ? __builtin_ctz(h) : -1;
     typedef float f32x4v __attribute__((ext_vector_type(4)));      // plain vector registers (HIP's float4 class kept these arrays in scratch)
     f32x4v pq[NPQ], pdo[NPQ];
     float pl = 0.f, pdl = 0.f;
@@ -838,16 +840,28 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
         }
         // ---- P = exp(S + bias - L[row]), dS = P (dP - delta[row]) ----
         f32x16 ds;
+        if (plain) {
+            // no bias, no mask (the joint space-time attentions: 2048 tokens x 8 heads per batch entry): only ragged keys / rows die
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = acc_row(i, hf), rr = r0 + row;
-            const int rcl = min(rr, R - 1);
-            const int qi = rcl / h, qh = rcl % h;
-            const float nbv = null_bias ? null_bias[qh] : 0.f;
-            const float sv = attn_bias_mask(s[i], j, M, E, ns, h, qi, qh, causal, rel, nbv);
-            const float p = (sv == -INFINITY || rr >= R) ? 0.f : __expf(sv - Ls[row]);
-            s[i] = p;
-            ds[i] = p * (dp[i] - Dls[row]);
+            for (int i = 0; i < 16; ++i) {
+                const int row = acc_row(i, hf), rr = r0 + row;
+                const float p = (!jvalid || rr >= R) ? 0.f : __expf(s[i] - Ls[row]);
+                s[i] = p;
+                ds[i] = p * (dp[i] - Dls[row]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = acc_row(i, hf), rr = r0 + row;
+                const int rcl = min(rr, R - 1);
+                int qi, qh;                                    // token, head of the row: shifts when h is a power of two (an integer
+                if (hs >= 0) { qi = rcl >> hs; qh = rcl & (h - 1); } else { qi = rcl / h; qh = rcl - qi * h; }      // division costs ~2 MFMAs)
+                const float nbv = null_bias ? null_bias[qh] : 0.f;
+                const float sv = attn_bias_mask(s[i], j, M, E, ns, h, qi, qh, causal, rel, nbv);
+                const float p = (sv == -INFINITY || rr >= R) ? 0.f : __expf(sv - Ls[row]);
+                s[i] = p;
+                ds[i] = p * (dp[i] - Dls[row]);
+            }
         }
         // ---- dV^T += dO^T P, dK^T += Q^T dS : step i contracts the query pair held in register i of the two lane halves ----
 #pragma unroll

@@ -354,9 +354,9 @@ __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // one wave per row; C <= 64*16
 __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                          const float* __restrict__ bb, float* __restrict__ y,
-                                                          float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                          int C, float eps) {
+                                                          const float* __restrict__ bb, const float* __restrict__ res,
+                                                          float* __restrict__ y, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb) {
@@ -367,7 +367,11 @@ __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const float* __restric
         float v = 0.f;
         for (int c = lane; c < C; c += 64) { const float d = xr[c] - m; v += d * d; }
         const float rs = rsqrtf(wave_sum(v) / C + eps);
-        for (int c = lane; c < C; c += 64) y[(size_t)r * C + c] = (xr[c] - m) * rs * g[c] + (bb ? bb[c] : 0.f);
+        for (int c = lane; c < C; c += 64) {
+            float v = (xr[c] - m) * rs * g[c] + (bb ? bb[c] : 0.f);
+            if (res) v += res[(size_t)r * C + c];          // the caller's `LN(x) + residual` (attention blocks) in the same pass
+            y[(size_t)r * C + c] = v;
+        }
         if (lane == 0) { if (mean) mean[r] = m; if (rstd) rstd[r] = rs; }
     }
 }
@@ -1517,13 +1521,17 @@ extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mea
     return check_launch("gn_act_bwd/dx");
 }
 
-extern "C" int diqt_chan_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean,
-                                       float* rstd, int rows, int C, float eps, void* stream) {
+extern "C" int diqt_chan_layernorm_fwd_res(const float* x, const float* g, const float* b, const float* residual, float* y,
+                                           float* mean, float* rstd, int rows, int C, float eps, void* stream) {
     DIQT_REQUIRE(x && g && y, DIQT_E_ALIGN, "chan_layernorm_fwd: null pointer");
     DIQT_REQUIRE(rows > 0 && C > 0, DIQT_E_SHAPE, "chan_layernorm_fwd: bad shape");
-    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3(grid_for((size_t)rows, 4, 4096)), dim3(256), 0, STREAM, x, g, b, y, mean, rstd,
-                       rows, C, eps);
+    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3(grid_for((size_t)rows, 4, 4096)), dim3(256), 0, STREAM, x, g, b, residual, y, mean,
+                       rstd, rows, C, eps);
     return check_launch("chan_layernorm_fwd");
+}
+extern "C" int diqt_chan_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean,
+                                       float* rstd, int rows, int C, float eps, void* stream) {
+    return diqt_chan_layernorm_fwd_res(x, g, b, nullptr, y, mean, rstd, rows, C, eps, stream);
 }
 
 extern "C" int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean,

@@ -342,15 +342,17 @@ class TimeCond:
     """The time embedding handed to every ResnetBlock of one U-Net evaluation.  Each block's time_mlp starts with the
     same Mish(t) (imagen_pytorch3D.py:575-578), so it is evaluated once here and shared; on the sampling path the Linear
     layers of ALL blocks then run as one launch over their concatenated weights (``batched``: id(linear) -> SSView)."""
-    __slots__ = ("t", "_act", "batched")
+    __slots__ = ("t", "_act", "batched", "act")
 
-    def __init__(self, t):
-        self.t, self._act, self.batched = t, None, None
+    def __init__(self, t, act=ops.ACT_MISH):
+        self.t, self._act, self.batched, self.act = t, None, None, act      # act: Mish here, SiLU in the pseudo-3D U-Net
 
-    def mish(self):
+    def activated(self):
         if self._act is None:
-            self._act = ops.mish(self.t)
+            self._act = ops.activation(self.t, self.act)
         return self._act
+
+    mish = activated
 
 
 class BatchedTimeMLPs:
@@ -377,7 +379,7 @@ class BatchedTimeMLPs:
                 self.offs[id(l)] = (off, l.weight.shape[0])
                 off += l.weight.shape[0]
             self.key = key
-        out = ops.linear(tc.mish(), self.w, self.b)                                   # ONE launch: [B, sum 2C_i]
+        out = ops.linear(tc.activated(), self.w, self.b)                              # ONE launch: [B, sum 2C_i]
         return {k: ops.SSView(out, off, n) for k, (off, n) in self.offs.items()}
 
 

@@ -19,7 +19,7 @@ from torch import nn
 from . import ops
 from .ops import ACT_SILU, ACT_GELU, ACT_SIGMOID
 from .imagen_pytorch3D import (exists, default, cast_tuple, Conv3d as _Conv3dND, Linear, Act, Identity,
-                               LearnedSinusoidalPosEmb, to_channels_last, to_channels_first, print_once)
+                               LearnedSinusoidalPosEmb, to_channels_last, to_channels_first, print_once, TimeCond, BatchedTimeMLPs)
 
 
 def SiLU():
@@ -41,8 +41,8 @@ class LayerNorm(nn.Module):
         assert not stable
         self.g = nn.Parameter(torch.ones(dim))
 
-    def forward(self, x):
-        return ops.chan_layernorm(x, self.g, 1e-5)
+    def forward(self, x, residual=None):
+        return ops.chan_layernorm(x, self.g, 1e-5, residual=residual)
 
 
 class ChanLayerNorm(nn.Module):
@@ -70,6 +70,8 @@ class Residual(nn.Module):
         self.fn = fn
 
     def forward(self, x, **kwargs):
+        if isinstance(self.fn, Attention):           # its to_out ends in a LayerNorm: `+ x` rides in that kernel
+            return self.fn(x, residual=x, **kwargs)
         return ops.add(self.fn(x, **kwargs), x)
 
 
@@ -94,8 +96,10 @@ class TokensOverSpaceTime(nn.Module):
         super().__init__()
         self.fn = fn
 
-    def forward(self, x, **kwargs):
+    def forward(self, x, residual=None, **kwargs):
         B, F, H, W, C = x.shape
+        if residual is not None:                     # `fn(x) + residual`, added inside fn (Attention)
+            kwargs['residual'] = residual.reshape(B, F * H * W, -1)
         return self.fn(x.reshape(B, F * H * W, C), **kwargs).reshape(B, F, H, W, -1)
 
 
@@ -127,16 +131,21 @@ class Conv3d(nn.Module):
             nn.init.dirac_(self.temporal_conv.weight.data)
             nn.init.zeros_(self.temporal_conv.bias.data)
 
-    def forward(self, x, ignore_time=False):
+    def forward(self, x, ignore_time=False, residual=None, want_stats=False):
+        """``residual`` is added in the epilogue of the LAST conv of the pair (the caller's ``h + res``), whose per-tile column sums
+        (``want_stats``) feed the consumer's GroupNorm."""
         sc = self.spatial_conv
         k = self.kernel_size
-        x = ops.conv3d(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2))
-        if ignore_time or not exists(self.temporal_conv):
+        last = ignore_time or not exists(self.temporal_conv)
+        x = ops.conv3d(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), residual=residual if last else None,
+                       want_stats=want_stats and last)
+        if last:
             return x
         tc = self.temporal_conv
         kt = tc.weight.shape[-1]
         w5 = tc.weight.unsqueeze(-1).unsqueeze(-1)                       # [Co, Co, kt, 1, 1]
-        return ops.conv3d(x, w5, tc.bias, (kt - 1, 0, 0), extra_pad=(-(kt - 1), 0, 0))    # left pad k-1 only (:399-402)
+        return ops.conv3d(x, w5, tc.bias, (kt - 1, 0, 0), residual=residual, extra_pad=(-(kt - 1), 0, 0),    # left pad k-1 only (:399-402)
+                          want_stats=want_stats)
 
 
 class DynamicPositionBias(nn.Module):
@@ -150,9 +159,19 @@ class DynamicPositionBias(nn.Module):
         self.mlp.append(Linear(dim, heads))
 
     def forward(self, n, device):
+        # the table depends on the parameters and n only, not on the input: on the sampling path it is computed once and kept until a
+        # parameter changes (the reference re-runs the MLP in every attention call of every U-Net evaluation: 7 small kernels each)
+        cache = not torch.is_grad_enabled()
+        if cache:
+            key = (n, str(device), ops._WEIGHT_EPOCH) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+            hit = getattr(self, '_table', None)
+            if hit is not None and hit[0] == key:
+                return hit[1]
         pos = torch.arange(-n + 1, n, device=device, dtype=torch.float32).unsqueeze(-1)
         for layer in self.mlp:
             pos = layer(pos)
+        if cache:
+            self._table = (key, pos)
         return pos
 
 
@@ -181,7 +200,10 @@ class Attention(nn.Module):
         if init_zero:
             nn.init.zeros_(self.to_out[-1].g)
 
-    def forward(self, x, context=None, mask=None, attn_bias=None):
+    def _out(self, out, residual):
+        return self.to_out[1](self.to_out[0](out), residual=residual)              # Linear -> LayerNorm (+ residual)
+
+    def forward(self, x, context=None, mask=None, attn_bias=None, residual=None):
         assert mask is None and attn_bias is None
         G, n, _ = x.shape
         h, d = self.heads, self.dim_head
@@ -206,17 +228,17 @@ class Attention(nn.Module):
             out = ops.mqa_attention_nograd(q.contiguous(), kv_ext.reshape(G, M, 2 * d).contiguous(),
                                            rel.contiguous() if exists(rel) else None,
                                            null_bias.contiguous() if exists(null_bias) else None, n, h, d, E, n, self.causal, self.scale)
-            return self.to_out(out)
+            return self._out(out, residual)
         if not _UNFUSED_ATTN and ops.mqa_attention_fused_ok(G, n, h, d, n, exists(rel)):
             # training path: the same fused kernel family with autograd (flash-style backward, no materialised scores)
             out = ops.mqa_attention(q, kv_ext.reshape(G, M, 2 * d), rel, null_bias, n, h, d, E, n, self.causal, self.scale)
-            return self.to_out(out)
+            return self._out(out, residual)
         sim = ops.bmm_strided(q, kv_ext, (G, n * h, M, d, False, True, n * h * d, d, M * 2 * d, 2 * d, n * h * M, M,
                                           self.scale, (G, n, h, M), 0, 0))
         p = ops.attn_softmax(sim, rel, null_bias, n, h, E, n, self.causal)
         out = ops.bmm_strided(p, kv_ext, (G, n * h, d, M, False, False, n * h * M, M, M * 2 * d, 2 * d, n * h * d, d,
                                           1.0, (G, n, h * d), 0, d))
-        return self.to_out(out)
+        return self._out(out, residual)
 
 
 class CrossAttention(nn.Module):
@@ -267,10 +289,10 @@ class Block(nn.Module):
         self.activation = SiLU()
         self.project = Conv3d(dim, dim_out, 3, padding=1)
 
-    def forward(self, x, scale_shift=None, ignore_time=False):
+    def forward(self, x, scale_shift=None, ignore_time=False, residual=None, emit_stats=False):
         gn = self.groupnorm
         x = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_SILU, gn.eps)
-        return self.project(x, ignore_time=ignore_time)
+        return self.project(x, ignore_time=ignore_time, residual=residual, want_stats=emit_stats)
 
 
 class GlobalContext(nn.Module):
@@ -306,16 +328,23 @@ class ResnetBlock(nn.Module):
         self.res_conv = Conv2d(dim, dim_out, 1) if dim != dim_out else Identity()
 
     def forward(self, x, time_emb=None, cond=None, ignore_time=False):
-        scale_shift = self.time_mlp(time_emb) if exists(self.time_mlp) and exists(time_emb) else None
-        h = self.block1(x, ignore_time=ignore_time)
+        scale_shift = None
+        if exists(self.time_mlp) and exists(time_emb):                            # [B, 2C]: scale | shift
+            if isinstance(time_emb, TimeCond):       # SiLU(t) shared by all blocks, the Linears batched on the sampling path
+                pre = time_emb.batched.get(id(self.time_mlp[1])) if time_emb.batched is not None else None
+                scale_shift = pre if pre is not None else self.time_mlp[1](time_emb.activated())
+            else:
+                scale_shift = self.time_mlp(time_emb)
+        # block2's GroupNorm statistics come from the epilogue of block1's last conv (unless cross attention rewrites h in between)
+        h = self.block1(x, ignore_time=ignore_time, emit_stats=not exists(self.cross_attn))
         if exists(self.cross_attn):
             assert exists(cond)
             h = ops.add(self.cross_attn(h, context=cond), h)
-        h = self.block2(h, scale_shift=scale_shift, ignore_time=ignore_time)
         res = self.res_conv(x)
         if exists(self.gca):
+            h = self.block2(h, scale_shift=scale_shift, ignore_time=ignore_time)
             return ops.gate_residual(h, self.gca(h), res)                         # h * gca(h) + res_conv(x)
-        return ops.add(h, res)
+        return self.block2(h, scale_shift=scale_shift, ignore_time=ignore_time, residual=res)      # h + res in the conv epilogue
 
 
 def ChanFeedForward(dim, mult=2):
@@ -338,8 +367,11 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x, context=None):
         for attn, ff in self.layers:
-            x = ops.add(attn(x, context=context), x)
-            x = ops.add(ff(x), x)
+            x = attn(x, context=context, residual=x)                              # attn(x) + x in the attention's last LayerNorm
+            h = x
+            for layer in ff[:-1]:
+                h = layer(h)
+            x = ff[-1](h, residual=x)                                             # ff(x) + x in the last 1x1 conv's epilogue
         return x
 
 
@@ -603,6 +635,13 @@ class Unet3D(nn.Module):
             tok = ops.concat_channels(tok, ltok)                                  # tokens concatenated along the sequence axis
         r = self.num_time_tokens * (2 if self.lowres_cond else 1)
         c = self.norm_cond(tok.reshape(B, r, -1))                                 # conditioning tokens  (:1732-1736)
+        # every ResnetBlock's time_mlp starts with the same SiLU(t) (:716-719): evaluated once; on the sampling path the ~20 Linears run
+        # as one launch over their concatenated weights
+        t = TimeCond(t, ACT_SILU)
+        if not torch.is_grad_enabled():
+            if getattr(self, '_time_mlps', None) is None:
+                self._time_mlps = BatchedTimeMLPs(m.time_mlp[1] for m in self.modules() if isinstance(m, ResnetBlock) and m.time_mlp is not None)
+            t.batched = self._time_mlps(t)
 
         hiddens = []
         for _, init_block, resnet_blocks, attn_block, temporal_peg, temporal_attn, _, post_downsample in self.downs:

@@ -516,16 +516,17 @@ def mish(x):
 
 class _ChanLayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, g, b, eps):
-        _chk(x, g, b)
+    def forward(ctx, x, g, b, eps, res=None):
+        _chk(x, g, b, res)
         C = x.shape[-1]
         rows = x.numel() // C
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        _lib.call("diqt_chan_layernorm_fwd", x, g, b, y, mean, rstd, rows, C, float(eps), _stream())
+        _lib.call("diqt_chan_layernorm_fwd_res", x, g, b, res, y, mean, rstd, rows, C, float(eps), _stream())
         ctx.save_for_backward(x, g, mean, rstd)
         ctx.has_bias = b is not None
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -537,13 +538,18 @@ class _ChanLayerNormFn(Function):
         dg = torch.empty_like(g)
         db = torch.empty_like(g) if ctx.has_bias else None
         ws, n = _reduce_ws(1, C, x.device)
-        _lib.call("diqt_chan_layernorm_bwd", x, dy.contiguous(), g, mean, rstd, dx, dg, db, ws, n, rows, C, _stream())
-        return dx, dg, db, None
+        dy = dy.contiguous()
+        _lib.call("diqt_chan_layernorm_bwd", x, dy, g, mean, rstd, dx, dg, db, ws, n, rows, C, _stream())
+        return dx, dg, db, None, (dy if ctx.has_res else None)
 
 
-def chan_layernorm(x, g, eps=1e-5, bias=None):
-    """LayerNorm over the channel (last) axis; g (and the optional bias) are any tensors with C elements."""
-    y = _ChanLayerNormFn.apply(x.contiguous(), g.reshape(-1), bias.reshape(-1) if bias is not None else None, eps)
+def chan_layernorm(x, g, eps=1e-5, bias=None, residual=None):
+    """LayerNorm over the channel (last) axis; g (and the optional bias) are any tensors with C elements.  ``residual`` (same shape as
+    x) is added to the result in the same pass."""
+    if residual is not None:
+        assert residual.shape == x.shape, (tuple(residual.shape), tuple(x.shape))
+        residual = residual.contiguous()
+    y = _ChanLayerNormFn.apply(x.contiguous(), g.reshape(-1), bias.reshape(-1) if bias is not None else None, eps, residual)
     return y.view(x.shape)
 
 

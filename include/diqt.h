@@ -202,6 +202,10 @@ int diqt_gn_act_bwd(const float* x, const float* dy, const float* mean, const fl
  * nn.LayerNorm at imagen_video.py:444,1306).                                                           */
 int diqt_chan_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,
                             int rows, int C, float eps, void* stream);
+/* The same with `+ residual` in the same pass: Residual(Attention) / TransformerBlock `attn(x) + x`, whose to_out ends in a LayerNorm
+ * (imagen_video.py:217-224, 483-525, 1004-1029); residual may be NULL.                                                          */
+int diqt_chan_layernorm_fwd_res(const float* x, const float* g, const float* b, const float* residual, float* y, float* mean,
+                                float* rstd, int rows, int C, float eps, void* stream);
 /* dg[C], db[C] (db may be NULL) are reduced through `workspace` (diqt_reduce_workspace_bytes(1, C)) */
 int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean,
                             const float* rstd, float* dx, float* dg, float* db, void* workspace,

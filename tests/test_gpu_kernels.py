@@ -624,7 +624,10 @@ def test_conv3d_neighbour_halo_equals_boundary_pad_copies(ops, f, A, Cin, Cout, 
     (8, (8, 8, 8), 256, 256, (3, 3, 3), 1, True),        # the 8^3 level: 64 tiles x co blocks -> split-K over 4 x 4 chunks, slabs + reduce
     (8, (8, 8, 8), 384, 256, (3, 3, 3), 1, False),       # ... 24 chunks in 4 shares (the decoder's concatenated input)
     (2, (16, 16, 16), 64, 128, (3, 3, 3), 1, True),      # ... one chunk per share
-    (4, (16, 8, 8), 256, 224, (1, 3, 3), 1, False)])     # (1,3,3) split-K, ragged Cout
+    (4, (16, 8, 8), 256, 224, (1, 3, 3), 1, False),      # (1,3,3) split-K, ragged Cout
+    (8, (32, 32, 32), 64, 64, (3, 1, 1), 1, True),       # Family B temporal conv: 3 taps = 2 steps per chunk, 8 x 8 x 8 tiles, walk of 2
+    (8, (32, 16, 16), 128, 128, (3, 1, 1), 1, False),    # ... second level, one round
+    (8, (30, 8, 8), 256, 256, (3, 1, 1), 1, False)])     # ... third level: 4 x 8 x 8 tiles, ragged D
 def test_conv3d_on_the_one_wave_per_simd_kernel(ops, B, sp, Cin, Cout, k, pad, res):
     """conv_fwd9_kernel (512- / 256-voxel tiles, LDS-DMA double-buffered 16-channel halo chunks, weight ring) against a float64 conv:
     output, residual epilogue, per-tile column sums, run-to-run determinism."""
@@ -668,6 +671,30 @@ def test_conv3d_on_the_one_wave_per_simd_kernel(ops, B, sp, Cin, Cout, k, pad, r
         yc = ops.conv3d(xd, torch.roll(wd, 8, 0).contiguous(), torch.roll(bd, 8, 0).contiguous(), pads,
                         residual=torch.roll(cl(r), 8, -1).contiguous() if res else None)
     assert torch.equal(torch.roll(y, 8, -1), yc), "conv_fwd9: a channel's result depends on its position in the 64-channel block"
+
+
+@pytest.mark.parametrize("B,sp,C", [(8, (32, 32, 32), 64), (8, (32, 8, 8), 256)])
+def test_causal_temporal_conv_on_the_one_wave_per_simd_kernel(ops, B, sp, C):
+    """The pseudo-3D blocks' temporal conv is CAUSAL: (3,1,1) taps over frames f-2..f (left pad 2, no right pad; imagen_video.py:399-402),
+    expressed as padding 2 with extra_pad -2.  conv_fwd9_kernel's (3,1,1) variants against a float64 conv of the left-padded input,
+    forward and (through autograd: the anti-causal flipped conv on the same kernel) the input gradient."""
+    from diffusioniqt_amd import _lib
+    D, H, W = sp
+    assert _lib.query("diqt_conv3d_fwd_kernel_id", B, D, H, W, C, C, 3, 1, 1, 2, 0, 0, -2, 0, 0) == 4, "not routed to conv_fwd9_kernel"
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, C, D, H, W, generator=g)
+    w = torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)
+    b = torch.randn(C, generator=g) * 0.1
+    dy = torch.randn(B, C, D, H, W, generator=g)
+    bs, cs = [0, B - 1], list(range(8)) + list(range(C - 8, C))
+    xr = x[bs].double().requires_grad_()
+    ref = F.conv3d(F.pad(xr, (0, 0, 0, 0, 2, 0)), w.double(), b.double())
+    ref.backward(dy[bs].double())
+    xd = cl(x).requires_grad_()
+    y = ops.conv3d(xd, w.to(DEV), b.to(DEV), (2, 0, 0), extra_pad=(-2, 0, 0))
+    close(cf(y)[bs], ref, what="causal temporal conv")
+    y.backward(cl(dy))
+    close(cf(xd.grad)[bs], xr.grad, what="causal temporal conv: input gradient")
 
 
 def test_multi_accumulate_matches_per_tensor_adds(ops):

@@ -44,6 +44,9 @@ PROTOTYPES = {
     "diqt_gn_act_bwd": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_chan_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "diqt_chan_layernorm_fwd_res": (I, [P, P, P, P, P, P, P, I, I, F, P]),
+    "diqt_dwconv_temporal_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "diqt_dwconv_temporal_bwd_weight_workspace_bytes": (Z, [I, I, I, I, I]),
+    "diqt_dwconv_temporal_bwd_weight": (I, [P, P, P, P, Z, I, I, I, I, I, I, P]),
     "diqt_chan_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, P]),
     "diqt_act_fwd": (I, [P, P, Z, I, P]),
     "diqt_act_bwd": (I, [P, P, P, Z, I, P]),

@@ -1561,6 +1561,150 @@ extern "C" int diqt_chan_layernorm_bwd(const float* x, const float* dy, const fl
     return check_launch("chan_layernorm_bwd/db-final");
 }
 
+// ---------------------------------------------------------------------------------------------
+// depthwise temporal conv of the pseudo-3D U-Net's TemporalPEG: nn.Conv3d(C, C, (3,1,1), groups=C) after a causal / symmetric frame
+// pad, inside a Residual (/root/reference/imagen_video.py:1340-1362).  An elementwise-class op: x is read once (1.25x with the frame
+// halo of a chunk), y written once; channels-last x[B][F][P = H*W][C], w[C][KT], one thread per (b, 8-frame chunk, pixel, channel quad).
+// ---------------------------------------------------------------------------------------------
+constexpr int DWT_FCH = 8;
+
+template <int KT>
+__global__ __launch_bounds__(256) void dwconv_t_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ res,
+                                                           float* __restrict__ y, int F, int P4, int C4, int left, int flip) {
+    const int e = blockIdx.x * 256 + threadIdx.x;          // float4 index inside a frame: pixel * C4 + channel quad
+    if (e >= P4) return;
+    const int b = blockIdx.z, f0 = blockIdx.y * DWT_FCH, c = (e % C4) * 4;
+    float4 wv[KT];                                         // wv[t] = taps of the 4 channels; flip: the backward-data form
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int tt = flip ? KT - 1 - t : t;
+        wv[t] = make_float4(w[(c + 0) * KT + tt], w[(c + 1) * KT + tt], w[(c + 2) * KT + tt], w[(c + 3) * KT + tt]);
+    }
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* xb = reinterpret_cast<const float4*>(x) + (size_t)b * F * P4 + e;
+    float4 v[DWT_FCH + KT - 1];                            // frames f0 - left .. f0 + 7 - left + KT - 1, all loads in flight together
+#pragma unroll
+    for (int u = 0; u < DWT_FCH + KT - 1; ++u) {
+        const int f = f0 + u - left;
+        v[u] = (f >= 0 && f < F) ? xb[(size_t)f * P4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 rv[DWT_FCH];
+    if (res) {
+        const float4* rb = reinterpret_cast<const float4*>(res) + (size_t)b * F * P4 + e;
+#pragma unroll
+        for (int u = 0; u < DWT_FCH; ++u) rv[u] = f0 + u < F ? rb[(size_t)(f0 + u) * P4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4* yb = reinterpret_cast<float4*>(y) + (size_t)b * F * P4 + e;
+#pragma unroll
+    for (int u = 0; u < DWT_FCH; ++u) {
+        if (f0 + u >= F) break;
+        float4 o = bv;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            o.x = fmaf(wv[t].x, v[u + t].x, o.x); o.y = fmaf(wv[t].y, v[u + t].y, o.y);
+            o.z = fmaf(wv[t].z, v[u + t].z, o.z); o.w = fmaf(wv[t].w, v[u + t].w, o.w);
+        }
+        if (res) { o.x += rv[u].x; o.y += rv[u].y; o.z += rv[u].z; o.w += rv[u].w; }
+        yb[(size_t)(f0 + u) * P4] = o;
+    }
+}
+
+// partial[blk][KT + 1][C]: rows 0..KT-1 = sum dy[f] x[f + t - left], row KT = sum dy (the bias gradient); blk = (b, frame chunk, pixel chunk)
+template <int KT>
+__global__ __launch_bounds__(256) void dwconv_t_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ partial, int F, int P, int C, int left, int pch) {
+    __shared__ float4 sh[KT + 1][256];
+    const int C4 = C >> 2, rpar = 256 / C4;                // C4 divides 256 (host check)
+    const int cq = threadIdx.x % C4, pr = threadIdx.x / C4;
+    const int b = blockIdx.z, f0 = blockIdx.y * DWT_FCH, p0 = blockIdx.x * pch;
+    const int p1 = min(P, p0 + pch);
+    float4 acc[KT + 1];
+#pragma unroll
+    for (int t = 0; t <= KT; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t P4 = (size_t)P * C4;
+    for (int p = p0 + pr; p < p1; p += rpar) {
+        const float4* xb = reinterpret_cast<const float4*>(x) + (size_t)b * F * P4 + (size_t)p * C4 + cq;
+        const float4* db = reinterpret_cast<const float4*>(dy) + (size_t)b * F * P4 + (size_t)p * C4 + cq;
+        float4 v[DWT_FCH + KT - 1], d[DWT_FCH];
+#pragma unroll
+        for (int u = 0; u < DWT_FCH + KT - 1; ++u) {
+            const int f = f0 + u - left;
+            v[u] = (f >= 0 && f < F) ? xb[(size_t)f * P4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < DWT_FCH; ++u) d[u] = f0 + u < F ? db[(size_t)(f0 + u) * P4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < DWT_FCH; ++u) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                acc[t].x = fmaf(d[u].x, v[u + t].x, acc[t].x); acc[t].y = fmaf(d[u].y, v[u + t].y, acc[t].y);
+                acc[t].z = fmaf(d[u].z, v[u + t].z, acc[t].z); acc[t].w = fmaf(d[u].w, v[u + t].w, acc[t].w);
+            }
+            acc[KT].x += d[u].x; acc[KT].y += d[u].y; acc[KT].z += d[u].z; acc[KT].w += d[u].w;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t <= KT; ++t) sh[t][threadIdx.x] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < C4) {                                // fixed order over the parallel pixel rows
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+        for (int t = 0; t <= KT; ++t) {
+            float4 s4 = sh[t][threadIdx.x];
+            for (int k = 1; k < rpar; ++k) {
+                const float4 o = sh[t][k * C4 + threadIdx.x];
+                s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+            }
+            *reinterpret_cast<float4*>(partial + (blk * (KT + 1) + t) * C + threadIdx.x * 4) = s4;
+        }
+    }
+}
+
+static bool dwt_ok(int F, int P, int C, int kt) { return kt == 3 && C % 4 == 0 && 256 % (C / 4) == 0 && F > 0 && P > 0; }
+static int dwt_pch(int B, int F, int P) {                  // pixels per workgroup of the weight-gradient pass: ~2048 workgroups
+    const int fc = (F + DWT_FCH - 1) / DWT_FCH;
+    int pch = (int)(((long long)B * fc * P + 2047) / 2048);
+    if (pch < 4) pch = 4;
+    return pch;
+}
+
+// y = depthwise_conv_t(x) + bias (+ residual); flip = 1 with left = kt - 1 - left_of_forward is the gradient w.r.t. x.
+extern "C" int diqt_dwconv_temporal_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int F,
+                                        int P, int C, int kt, int left, int flip, void* stream) {
+    DIQT_REQUIRE(x && w && y, DIQT_E_ALIGN, "dwconv_temporal_fwd: null pointer");
+    DIQT_REQUIRE(B > 0 && dwt_ok(F, P, C, kt) && left >= 0 && left < kt, DIQT_E_UNSUPPORTED, "dwconv_temporal_fwd: kt = 3, C %% 4 == 0 only");
+    DIQT_REQUIRE(aligned16(x) && aligned16(y) && (!bias || aligned16(bias)) && (!residual || aligned16(residual)), DIQT_E_ALIGN,
+                 "dwconv_temporal_fwd: 16-byte alignment");
+    const int P4 = P * (C / 4);
+    const dim3 grid((P4 + 255) / 256, (F + DWT_FCH - 1) / DWT_FCH, B);
+    hipLaunchKernelGGL(dwconv_t_fwd_kernel<3>, grid, dim3(256), 0, STREAM, x, w, bias, residual, y, F, P4, C / 4, left, flip);
+    return check_launch("dwconv_temporal_fwd");
+}
+extern "C" size_t diqt_dwconv_temporal_bwd_weight_workspace_bytes(int B, int F, int P, int C, int kt) {
+    if (!dwt_ok(F, P, C, kt)) return 0;
+    const int pch = dwt_pch(B, F, P);
+    const size_t nblk = (size_t)B * ((F + DWT_FCH - 1) / DWT_FCH) * ((P + pch - 1) / pch);
+    return nblk * (kt + 1) * C * sizeof(float);
+}
+// dwb[(kt + 1)][C]: rows 0..kt-1 = d w[c][t] (tap-major: the caller transposes the kt x C numbers), row kt = d bias
+extern "C" int diqt_dwconv_temporal_bwd_weight(const float* x, const float* dy, float* dwb, void* workspace, size_t workspace_bytes,
+                                               int B, int F, int P, int C, int kt, int left, void* stream) {
+    DIQT_REQUIRE(x && dy && dwb && workspace, DIQT_E_ALIGN, "dwconv_temporal_bwd_weight: null pointer");
+    DIQT_REQUIRE(B > 0 && dwt_ok(F, P, C, kt) && left >= 0 && left < kt, DIQT_E_UNSUPPORTED, "dwconv_temporal_bwd_weight: kt = 3, C %% 4 == 0 only");
+    DIQT_REQUIRE(workspace_bytes >= diqt_dwconv_temporal_bwd_weight_workspace_bytes(B, F, P, C, kt) && aligned16(workspace) &&
+                     aligned16(x) && aligned16(dy), DIQT_E_WORKSPACE, "dwconv_temporal_bwd_weight: workspace / alignment");
+    const int pch = dwt_pch(B, F, P);
+    const dim3 grid((P + pch - 1) / pch, (F + DWT_FCH - 1) / DWT_FCH, B);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(dwconv_t_wgrad_kernel<3>, grid, dim3(256), 0, STREAM, x, dy, partial, F, P, C, left, pch);
+    int rc = check_launch("dwconv_temporal_bwd_weight");
+    if (rc) return rc;
+    const int nblk = (int)(grid.x * grid.y * grid.z), ncol = (kt + 1) * C;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((ncol + 3) / 4), dim3(256), 0, STREAM, partial, dwb, nblk, ncol, ncol, 1.f);
+    return check_launch("dwconv_temporal_bwd_weight/sum");
+}
+
 extern "C" int diqt_act_fwd(const float* x, float* y, size_t n, int act, void* stream) {
     DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "act_fwd: null pointer");
     if (n == 0) return DIQT_OK;

@@ -72,6 +72,8 @@ class Residual(nn.Module):
     def forward(self, x, **kwargs):
         if isinstance(self.fn, Attention):           # its to_out ends in a LayerNorm: `+ x` rides in that kernel
             return self.fn(x, residual=x, **kwargs)
+        if isinstance(self.fn, nn.Sequential) and len(self.fn) == 2 and isinstance(self.fn[1], TemporalPEGConv):
+            return self.fn[1](self.fn[0](x), residual=x)                          # temporal PEG: conv(pad(x)) + x in one kernel
         return ops.add(self.fn(x, **kwargs), x)
 
 
@@ -440,9 +442,12 @@ class TemporalPEGConv(nn.Conv3d):
         super().__init__(dim, dim, (3, 1, 1), groups=dim)
         self.causal = causal
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        if ops.dwconv_temporal_ok(x, self.weight, self.groups, self.stride):      # elementwise-class kernel, `+ residual` in the same pass
+            return ops.dwconv_temporal(x, self.weight, self.bias, 2 if self.causal else 1, residual)
         pad, extra = ((2, 0, 0), (-2, 0, 0)) if self.causal else ((1, 0, 0), (0, 0, 0))
-        return ops.conv3d_direct(x, self.weight, self.bias, (1, 1, 1), pad, self.groups, extra_pad=extra)
+        y = ops.conv3d_direct(x, self.weight, self.bias, (1, 1, 1), pad, self.groups, extra_pad=extra)
+        return y if residual is None else ops.add(y, residual)
 
 
 class Unet3D(nn.Module):

@@ -417,6 +417,50 @@ def conv3d_direct(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), gro
     return _ConvDirectFn.apply(x, weight, bias, t3(stride), t3(padding), int(groups), t3(extra_pad))
 
 
+class _DwConvTemporalFn(Function):
+    """Depthwise (3,1,1) temporal conv + bias (+ residual) on channels-last x[B,F,H,W,C] (the TemporalPEG of the pseudo-3D U-Net)."""
+    @staticmethod
+    def forward(ctx, x, weight, bias, left, res):
+        _chk(x, weight, bias, res)
+        B, F, H, W, C = x.shape
+        kt = weight.shape[2]
+        w2 = weight.reshape(C, kt).contiguous()
+        y = torch.empty_like(x)
+        _lib.call("diqt_dwconv_temporal_fwd", x, w2, bias, res, y, B, F, H * W, C, kt, int(left), 0, _stream())
+        ctx.save_for_backward(x, w2)
+        ctx.cfg = (B, F, H * W, C, kt, int(left), bias is not None, res is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        B, F, P, C, kt, left, has_bias, has_res, wshape = ctx.cfg
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call("diqt_dwconv_temporal_fwd", dy, w2, None, None, dx, B, F, P, C, kt, kt - 1 - left, 1, _stream())
+        if ctx.needs_input_grad[1]:
+            n = _lib.query("diqt_dwconv_temporal_bwd_weight_workspace_bytes", B, F, P, C, kt)
+            ws = _workspace(n, x.device)
+            dwb = torch.empty((kt + 1, C), dtype=torch.float32, device=x.device)
+            _lib.call("diqt_dwconv_temporal_bwd_weight", x, dy, dwb, ws, n, B, F, P, C, kt, left, _stream())
+            dw = dwb[:kt].t().reshape(wshape)
+            db = dwb[kt].clone() if has_bias else None
+        return dx, dw, db, None, (dy if has_res else None)
+
+
+def dwconv_temporal_ok(x, weight, groups, stride=(1, 1, 1)):
+    C = x.shape[-1]
+    return (x.dim() == 5 and tuple(weight.shape) == (C, 1, 3, 1, 1) and groups == C and tuple(stride) == (1, 1, 1)
+            and C % 4 == 0 and 256 % (C // 4) == 0)
+
+
+def dwconv_temporal(x, weight, bias, left, residual=None):
+    """nn.Conv3d(C, C, (3,1,1), groups=C) on frames padded with ``left`` zero frames in front (2: causal, 1: symmetric), + residual."""
+    return _DwConvTemporalFn.apply(x.contiguous(), weight, bias, int(left), residual.contiguous() if residual is not None else None)
+
+
 # --------------------------------------------------------------------------------------------
 # GroupNorm + scale/shift + activation
 # --------------------------------------------------------------------------------------------

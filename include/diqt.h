@@ -206,6 +206,17 @@ int diqt_chan_layernorm_fwd(const float* x, const float* g, const float* b, floa
  * (imagen_video.py:217-224, 483-525, 1004-1029); residual may be NULL.                                                          */
 int diqt_chan_layernorm_fwd_res(const float* x, const float* g, const float* b, const float* residual, float* y, float* mean,
                                 float* rstd, int rows, int C, float eps, void* stream);
+
+/* Depthwise temporal conv of the pseudo-3D U-Net's TemporalPEG -- nn.Conv3d(C, C, (3,1,1), groups=C) after a causal (2,0) or symmetric
+ * (1,1) frame pad, wrapped in a Residual (/root/reference/imagen_video.py:1340-1362): x[B][F][P][C] channels-last, w[C][kt], kt = 3,
+ * `left` frames of zero padding in front.  y = conv(x) + bias (+ residual).  flip = 1 with left' = kt - 1 - left is the gradient
+ * w.r.t. x.  The weight gradient comes tap-major with the bias gradient as its last row: dwb[kt + 1][C].                          */
+int diqt_dwconv_temporal_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int F, int P,
+                             int C, int kt, int left, int flip, void* stream);
+size_t diqt_dwconv_temporal_bwd_weight_workspace_bytes(int B, int F, int P, int C, int kt);
+int diqt_dwconv_temporal_bwd_weight(const float* x, const float* dy, float* dwb, void* workspace, size_t workspace_bytes, int B, int F,
+                                    int P, int C, int kt, int left, void* stream);
+
 /* dg[C], db[C] (db may be NULL) are reduced through `workspace` (diqt_reduce_workspace_bytes(1, C)) */
 int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean,
                             const float* rstd, float* dx, float* dg, float* db, void* workspace,

@@ -697,6 +697,37 @@ def test_causal_temporal_conv_on_the_one_wave_per_simd_kernel(ops, B, sp, C):
     close(cf(xd.grad)[bs], xr.grad, what="causal temporal conv: input gradient")
 
 
+@pytest.mark.parametrize("B,F_,H,W,C,causal,res", [(2, 32, 8, 8, 64, True, True), (3, 11, 5, 4, 128, False, False), (1, 7, 3, 3, 256, True, True),
+                                                   (2, 16, 6, 6, 32, False, True)])
+def test_depthwise_temporal_conv_matches_grouped_conv3d(ops, B, F_, H, W, C, causal, res):
+    """The TemporalPEG conv -- nn.Conv3d(C, C, (3,1,1), groups=C) after a causal (2,0) / symmetric (1,1) frame pad, + residual
+    (imagen_video.py:1340-1362) -- on the elementwise kernels: forward, and the gradients w.r.t. x, weight, bias and residual."""
+    g = torch.Generator().manual_seed(C + F_)
+    x = torch.randn(B, C, F_, H, W, generator=g)
+    w = torch.randn(C, 1, 3, 1, 1, generator=g) * 0.5
+    b = torch.randn(C, generator=g)
+    r = torch.randn(B, C, F_, H, W, generator=g) if res else None
+    dy = torch.randn(B, C, F_, H, W, generator=g)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    rr = r.double().requires_grad_() if res else None
+    pad = (0, 0, 0, 0, 2, 0) if causal else (0, 0, 0, 0, 1, 1)
+    ref = F.conv3d(F.pad(xr, pad), wr, br, groups=C)
+    if res:
+        ref = ref + rr
+    ref.backward(dy.double())
+    xd, wd, bd = cl(x).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    rd = cl(r).requires_grad_() if res else None
+    assert ops.dwconv_temporal_ok(xd, wd, C)
+    y = ops.dwconv_temporal(xd, wd, bd, 2 if causal else 1, rd)
+    close(cf(y), ref, what="depthwise temporal conv")
+    y.backward(cl(dy))
+    close(cf(xd.grad), xr.grad, what="d x")
+    close(wd.grad, wr.grad, tol=1e-4, what="d weight")
+    close(bd.grad, br.grad, tol=1e-4, what="d bias")
+    if res:
+        close(cf(rd.grad), rr.grad, what="d residual")
+
+
 def test_multi_accumulate_matches_per_tensor_adds(ops):
     """Gradient accumulation into the flat arena: one launch == the per-parameter `grad += new` adds (bit-exact)."""
     g = torch.Generator().manual_seed(11)

@@ -2040,6 +2040,14 @@ static PwPlan pw_plan(int B, int D, int H, int W, int Cin, int Cout, int kd, int
     p.xFirst = Cin >= Cout;                      // the larger channel count takes the 128-row side of the tile
     p.M = p.xFirst ? Cin : Cout; p.N = p.xFirst ? Cout : Cin;
     if (p.M <= 64 || p.V < 4096) { p.ok = false; return p; }      // small problems stay on the conv kernel
+    {
+        // conv_wgrad3_kernel's pointwise variant (LDS-DMA double-buffered 64-row tiles, one wave per SIMD) takes the shapes it can:
+        // the batched GEMM runs these K = all-rows products at ~30 TFLOP/s
+        W3Geom g3;
+        int v3 = 0, ks3 = 0;
+        size_t lds3 = 0;
+        if (wgrad3_plan(g3, v3, ks3, lds3, B, D, H, W, Cin, Cout, 1, 1, 1, 0, 0, 0, 0, 0, 0)) { p.ok = false; return p; }
+    }
     const int tiles = cdiv(p.M, 128) * cdiv(p.N, 64);
     int ks = 1;
     while (ks * 2 * tiles <= 256 && p.V % (ks * 2) == 0 && p.V / (ks * 2) >= 256) ks *= 2;      // one workgroup per CU

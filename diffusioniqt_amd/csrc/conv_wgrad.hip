@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const float* __rest
 using W3_333 = W3Cfg<3, 3, 3, 2, 4, 8, 0>;
 using W3_133 = W3Cfg<1, 3, 3, 1, 8, 8, 1>;
 using W3_311 = W3Cfg<3, 1, 1, 8, 2, 4, 1>;
+using W3_111 = W3Cfg<1, 1, 1, 2, 4, 8, 1>;       // pointwise convs / Linear layers: dW = dY^T X over all rows, taken as 64-row tiles
 
 template <class C> static bool w3_fill(W3Geom& g, int B, int D, int H, int W, int Cin, int Cout, int pd, int ph, int pw, int epd,
                                        int eph, int epw, int& ksplit, size_t& lds, int wgs) {
@@ -378,6 +379,7 @@ static int w3_variant(int kd, int kh, int kw) {
     if (kd == 3 && kh == 3 && kw == 3) return 1;
     if (kd == 1 && kh == 3 && kw == 3) return 2;
     if (kd == 3 && kh == 1 && kw == 1) return 3;
+    if (kd == 1 && kh == 1 && kw == 1) return 4;
     return 0;
 }
 
@@ -387,6 +389,14 @@ bool wgrad3_plan(W3Geom& g, int& variant, int& ksplit, size_t& lds, int B, int D
     static const int wgs = [] { const char* e = getenv("DIQT_BWDW_WGS"); return e ? atoi(e) : 256; }();
     variant = mode ? w3_variant(kd, kh, kw) : 0;
     if (!variant || Cin % 4 != 0 || Cout % 4 != 0 || Cin < 16) return false;
+    if (variant == 4) {
+        // a pointwise filter sees rows, not a volume: any [B, D, H, W] (Linear layers arrive as one long row axis) is re-cut into
+        // V / 64 "batch entries" of one 2 x 4 x 8 tile each
+        static const bool pw3 = [] { const char* e = getenv("DIQT_PW_V3"); return !(e && e[0] == '0'); }();
+        const long long V = (long long)B * D * H * W;
+        if (!pw3 || pd || ph || pw || epd || eph || epw || V % 64 != 0 || V / 64 >= (1ll << 30)) return false;
+        return w3_fill<W3_111>(g, (int)(V / 64), 2, 4, 8, Cin, Cout, 0, 0, 0, 0, 0, 0, ksplit, lds, wgs);
+    }
     if (D > 255 || H > 255 || W > 255) return false;                   // packed 8-bit tile coordinates
     switch (variant) {
         case 1: return w3_fill<W3_333>(g, B, D, H, W, Cin, Cout, pd, ph, pw, epd, eph, epw, ksplit, lds, wgs);
@@ -422,6 +432,7 @@ int wgrad3_launch(const float* x, const float* dy, float* slabs, float* bias_par
         case 1: return w3_launch<W3_333>(x, dy, slabs, bias_part, g, ksplit, lds, s);
         case 2: return w3_launch<W3_133>(x, dy, slabs, bias_part, g, ksplit, lds, s);
         case 3: return w3_launch<W3_311>(x, dy, slabs, bias_part, g, ksplit, lds, s);
+        case 4: return w3_launch<W3_111>(x, dy, slabs, bias_part, g, ksplit, lds, s);
     }
     set_error("conv3d_bwd_weight(v3): no variant");
     return DIQT_E_UNSUPPORTED;

@@ -52,6 +52,9 @@ CONV_CASES = [
     (1, (7, 9, 10), 20, 24, (3, 3, 3), (1, 1, 1)),         # ragged extents, Cin % 32 != 0, Cout % 32 != 0
     (2, (4, 4, 4), 512, 64, (1, 1, 1), (0, 0, 0)),         # 1x1x1 after space-to-depth
     (1, (16, 16, 16), 64, 1, (1, 1, 1), (0, 0, 0)),        # final conv Cout = 1
+    (2, (16, 16, 16), 64, 512, (1, 1, 1), (0, 0, 0)),      # attention to_q-shaped pointwise conv: weight gradient on conv_wgrad3_kernel<1,1,1> (8 co blocks x 32 row slices)
+    (1, (8, 8, 8), 256, 72, (1, 1, 1), (0, 0, 0)),         # ... 4 ci blocks, ragged co block
+    (3, (4, 4, 12), 48, 136, (1, 1, 1), (0, 0, 0)),        # ... 9 row tiles over 256 workgroups' worth of slices, ragged ci / co blocks
     (2, (6, 8, 8), 32, 32, (1, 3, 3), (0, 1, 1)),          # pseudo-3D spatial conv
     (2, (6, 8, 8), 8, 40, (1, 7, 7), (0, 3, 3)),           # cross-embed (1,7,7)
     (2, (5, 1, 1), 33, 7, (3, 1, 1), (1, 0, 0)),           # temporal conv, odd channels
@@ -726,6 +729,28 @@ def test_depthwise_temporal_conv_matches_grouped_conv3d(ops, B, F_, H, W, C, cau
     close(bd.grad, br.grad, tol=1e-4, what="d bias")
     if res:
         close(cf(rd.grad), rr.grad, what="d residual")
+
+
+def test_pointwise_weight_gradient_routes_to_the_dma_kernel(ops):
+    """1x1x1 convs and Linear layers (= one long row axis) whose row count is a multiple of 64: the weight gradient runs on
+    conv_wgrad3_kernel's pointwise variant (kernel id 3), other row counts stay on the batched-GEMM path (0); Linear gradients vs float64."""
+    from diffusioniqt_amd import _lib
+    assert _lib.query("diqt_conv3d_bwd_weight_kernel_id", 8, 32, 32, 32, 64, 512, 1, 1, 1, 0, 0, 0, 0, 0, 0) == 3
+    assert _lib.query("diqt_conv3d_bwd_weight_kernel_id", 1, 1, 1, 262144, 512, 64, 1, 1, 1, 0, 0, 0, 0, 0, 0) == 3
+    assert _lib.query("diqt_conv3d_bwd_weight_kernel_id", 1, 1, 1, 4100, 128, 64, 1, 1, 1, 0, 0, 0, 0, 0, 0) == 0
+    g = torch.Generator().manual_seed(77)
+    for rows, Cin, Cout in ((8192, 64, 128), (4100, 128, 64)):
+        x = torch.randn(4, rows // 4, Cin, generator=g)
+        w = torch.randn(Cout, Cin, generator=g) / math.sqrt(Cin)
+        b = torch.randn(Cout, generator=g)
+        dy = torch.randn(4, rows // 4, Cout, generator=g)
+        xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+        F.linear(xr, wr, br).backward(dy.double())
+        xd, wd, bd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        ops.linear(xd, wd, bd).backward(dy.to(DEV))
+        close(xd.grad, xr.grad, what=f"linear dx rows={rows}")
+        close(wd.grad, wr.grad, tol=1e-4, what=f"linear dw rows={rows}")
+        close(bd.grad, br.grad, tol=1e-4, what=f"linear db rows={rows}")
 
 
 def test_multi_accumulate_matches_per_tensor_adds(ops):

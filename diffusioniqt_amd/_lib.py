@@ -15,7 +15,7 @@ import torch  # noqa: F401
 from ctypes import c_int, c_float, c_size_t, c_void_p, c_longlong, c_char_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdiqt_hip.so")
+LIB_PATH = os.environ.get("DIQT_LIB") or os.path.join(_HERE, "csrc", "libdiqt_hip.so")      # DIQT_LIB: another build of the same library (A/B timing)
 
 P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_longlong
 

@@ -40,10 +40,23 @@ __device__ __forceinline__ void f9_dma(__amdgpu_buffer_rsrc_t rs, unsigned lds, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void9*)(size_t)lds, 16, voff, 0, 0, 0);
 }
 
+// s_waitcnt vmcnt(n) + s_barrier with nothing else attached (n is a constant after unrolling; the asm needs a literal)
+__device__ __forceinline__ void f9_step_end(int n) {
+#define F9_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory"); break;
+    switch (n) {
+        F9_WB(0) F9_WB(1) F9_WB(2) F9_WB(3) F9_WB(4) F9_WB(5) F9_WB(6) F9_WB(7) F9_WB(8) F9_WB(9) F9_WB(10) F9_WB(11) F9_WB(12)
+        F9_WB(13) F9_WB(14) F9_WB(15) F9_WB(16)
+        default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+#undef F9_WB
+}
+
 template <class C>
 __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias, const float* __restrict__ residual,
                                                            float* __restrict__ y, F9Geom g) {
+    constexpr int NSPREAD = C::NSTEP > 1 ? C::NSTEP - 1 : 1;                  // steps that issue halo pieces of the next chunk
+    auto nh_in_step = [](int s_) constexpr { int n_ = 0; for (int r = 0; r < C::NPH; ++r) n_ += (r * NSPREAD / C::NPH == s_) ? 1 : 0; return n_; };
     constexpr int T = C::T, NSTEP = C::NSTEP, HB = C::HB, NPH = C::NPH, NVB = C::NVB, HH = C::HH, HWd = C::HWd, HV = C::HV;
     constexpr int CH = F9_CH, ROWB = F9_ROWB, WTAP = F9_WTAP, WSLOT = F9_WSLOT, NWS = F9_NWS;
     constexpr unsigned OOB = F9_OOB;
@@ -199,8 +212,8 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
                     dma_w(c2, 2 * s2, slot, 0);
                     if (2 * s2 + 1 < T) dma_w(c2, 2 * s2 + 1, slot, 1);
 #pragma unroll
-                    for (int r = 0; r < NPH; ++r)
-                        if (r * NSTEP / NPH == s) dma_h(r, hbufN, cNext);           // the next chunk's pieces, spread over the steps
+                    for (int r = 0; r < NPH; ++r)                                   // the next chunk's pieces, spread over all steps
+                        if (r * NSPREAD / NPH == s) dma_h(r, hbufN, cNext);         // but the last (whose end is the chunk's end)
                 }
                 // ---- taps 2s, 2s + 1 ----
                 if (2 * s + 1 < T) {
@@ -211,8 +224,12 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
                 } else {
                     F9_MM(A0, B0);
                 }
-                __builtin_amdgcn_s_waitcnt(0x0f70);        // this step's pieces (issued a whole step ago) have landed ...
-                __syncthreads();                           // ... everybody's have, and everybody is done with this step's weight slot
+                // End of the step.  The weight group issued at its start (a whole step ago; needed from the next step on) has to be
+                // in the LDS, and at the end of a chunk the next chunk's halo image; the halo pieces issued IN this step (behind the
+                // weights in program order: loads retire in order) may stay in flight for another step -- `vmcnt(0)` here made every
+                // piece's HBM latency (~3 us under load) the step's problem.  Raw s_barrier: __syncthreads() would bring its own
+                // vmcnt(0) lgkmcnt(0), which also drains the fragment reads prefetched for the next step.
+                f9_step_end(s + 1 == NSTEP ? 0 : nh_in_step(s));
                 wcur = wnext;
             }
 #undef F9_RD

@@ -711,12 +711,20 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
                                                                    int E, int ns, int causal, float scale, int KW) {
     constexpr int D = 32 * ND, ROW = D + 4, NPQ = 32 * D / 4 / 64;       // float4 pieces of a 32-row tile per lane
     extern __shared__ __attribute__((aligned(16))) float smem_dkv[];
-    const int g = blockIdx.y;
+    // XCD-aware block mapping: workgroups are dealt to the 8 XCDs round-robin by linear id.  All key-tile workgroups of a batch entry
+    // walk the same Q / dO tiles at the same pace, so they belong behind ONE L2: batch entry g = xcd + 8 * (...) instead of every
+    // XCD streaming every entry's Q and dO (the joint space-time attentions: 8 entries x 64 key tiles, 8.4 MB of Q + dO each).
+    int g = blockIdx.y, bx = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {
+        const unsigned id = blockIdx.y * gridDim.x + blockIdx.x, slot = id >> 3;
+        g = (int)((id & 7u) + 8u * (slot / gridDim.x));
+        bx = (int)(slot % gridDim.x);
+    }
     const int M = E + ns, R = n * h;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hf = lane >> 5;
     const int QW = 4 / KW;                                 // waves that share a key tile and split the query tiles
-    const int kt = blockIdx.x * KW + wave % KW, qw = wave / KW;
+    const int kt = bx * KW + wave % KW, qw = wave / KW;
     // a lone null key (E == 1) is taken by the VALU (below) instead of costing a 32-key tile of its own
     const int kbase = (E == 1) ? 1 : 0;
     const int j = kbase + kt * 32 + l31;                   // this lane's key (column)

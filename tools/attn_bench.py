@@ -36,3 +36,23 @@ for name, G, n, h, d, E, use_rel, causal in SHAPES:
     ms = s.elapsed_time(e) / it
     fl = 4.0 * G * n * h * (E + n) * d * (0.5 if causal else 1.0)
     print(f"{name:38s} G={G:5d} n={n:6d}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s (algorithmic{', causal half' if causal else ''})")
+    if os.environ.get("BWD") == "1" and ops.mqa_attention_fused_ok(G, n, h, d, n, use_rel):
+        # training path: forward with the row log-sum-exp + flash-style backward (dQ kernel, dK/dV kernel, bias-gradient reduce)
+        qg, kvg = q.clone().requires_grad_(), kv.clone().requires_grad_()
+        relg = rel.clone().requires_grad_() if use_rel else None
+        nbg = nb.clone().requires_grad_() if use_rel else None
+        out = ops.mqa_attention(qg, kvg, relg, nbg, n, h, d, E, n, causal, d ** -0.5)
+        dout = torch.randn_like(out)
+        def bw():
+            qg.grad = kvg.grad = None
+            out.backward(dout, retain_graph=True)
+        for _ in range(3):
+            bw()
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(it):
+            bw()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / it
+        print(f"{'':38s} backward: {ms:8.3f} ms  {2.5 * fl / ms / 1e9:7.1f} TFLOP/s (5 products)")

@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/fbprof_${1:-x}
 mkdir -p $OUT
 cd $R
-timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_family_b.py -x -q -k "attention or family or unet3d" 2>&1 | tail -3
+
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_e -o e -- python3 $R/tools/unet3d_bench.py 64 32 8 > $OUT/eval.log 2>&1
 cp $(find /tmp/p_e -name "*kernel_stats.csv" | head -1) $OUT/eval_kernel_stats.csv

@@ -484,6 +484,8 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
         if tr is not None:
             tr["all_weight_gradient_kernels"] = tr.pop("all_conv_kernels")
             tr["note"] = "launch interval = the weight-gradient kernel + its fixed-order split-K slab sum (conv_reduce_dw3_kernel)"
+            tr["traffic"] = pmc_traffic(tr["kernel"], B, S)       # HBM bytes per average launch, committed --pmc passes of `--mode both`
+            tr["traffic_note"] = "the kernel alone (without the slab sum), from the committed rocprofv3 --pmc passes of this command (profiles/)"
             result["train_roofline"] = tr
         if world > 1:
             ddp = ddp_stats(torch, dist, ops, trainer, train_step, sync_all, device, world)

@@ -11,6 +11,11 @@ struct F9Geom {
     unsigned slabElems;
     unsigned xBytes, yBytes, wBytes;
     float* stats;                // optional per-tile column sums of the output: [B][tiles per batch][2][Cout]
+    // GroupNorm-backward epilogue (this launch is the backward-data pass of the conv behind a GroupNorm + activation): with gx set,
+    // the statistics rows hold sum(dz), sum(dz * xhat) of dz = output * act'(A gx + B), xhat = (gx - mean) rstd instead of the
+    // output's sums -- the reduction pass of the GroupNorm backward, without its read of gx and of this output
+    const float *gx, *gmean, *grstd, *ggamma, *gbeta, *gscale, *gshift;
+    int gG, gcs, gact;
 };
 
 // maySplit: the caller has a workspace for split-K slabs (g.ksplit * output elements floats when g.ksplit > 1; the kernel then gets

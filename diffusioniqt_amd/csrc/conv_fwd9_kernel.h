@@ -40,6 +40,21 @@ __device__ __forceinline__ void f9_dma(__amdgpu_buffer_rsrc_t rs, unsigned lds, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void9*)(size_t)lds, 16, voff, 0, 0, 0);
 }
 
+// Mish / SiLU derivative for the GroupNorm-backward epilogue (same expressions as act_grad in common.h, without its other cases:
+// the call sits in a 128-fold unrolled store loop)
+__device__ __forceinline__ float f9_act_grad(float x, int act) {
+    if (act == DIQT_ACT_MISH) {
+        if (x > 20.f) return 1.f;
+        const float n = __expf(x);
+        const float m = n * (n + 2.f);
+        const float t = m / (m + 2.f);
+        const float sg = n / (1.f + n);
+        return t + x * sg * (1.f - t * t);
+    }
+    const float s = 1.f / (1.f + __expf(-x));
+    return s * (1.f + x * (1.f - s));
+}
+
 // s_waitcnt vmcnt(n) + s_barrier with nothing else attached (n is a constant after unrolling; the asm needs a literal)
 __device__ __forceinline__ void f9_step_end(int n) {
 #define F9_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory"); break;
@@ -240,6 +255,22 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
         //      column bw8 + (i & 3) + 4 hf ----
         {
             float cs0 = 0.f, cq0 = 0.f, cs1 = 0.f, cq1 = 0.f;
+            // GroupNorm-backward epilogue: z = gA x + gB (the forward's fused GN + scale/shift), xhat = (x - gm) gr for this lane's two channels
+            float gA0 = 0.f, gB0 = 0.f, gm0 = 0.f, gr0 = 0.f, gA1 = 0.f, gB1 = 0.f, gm1 = 0.f, gr1 = 0.f;
+            if (g.gx) {            // kernel-uniform
+                const int cpg = g.Cout / g.gG;
+                auto coef = [&](int co, float& A, float& Bc, float& m, float& r) __attribute__((always_inline)) {
+                    const int cc = min(co, g.Cout - 1);
+                    m = g.gmean[tb * g.gG + cc / cpg]; r = g.grstd[tb * g.gG + cc / cpg];
+                    const float ga = g.ggamma ? g.ggamma[cc] : 1.f, be = g.gbeta ? g.gbeta[cc] : 0.f;
+                    const float sc = g.gscale ? g.gscale[tb * g.gcs + cc] + 1.f : 1.f, sf = g.gshift ? g.gshift[tb * g.gcs + cc] : 0.f;
+                    A = r * ga * sc;
+                    Bc = (be - m * r * ga) * sc + sf;
+                };
+                coef(co0, gA0, gB0, gm0, gr0);
+                coef(co1, gA1, gB1, gm1, gr1);
+            }
+            const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.gx), 0, g.gx ? (int)g.yBytes : 0, 0x00020000);
 #pragma unroll
             for (int vb = 0; vb < NVB; ++vb) {
                 const int od = d0 + bd[vb];
@@ -258,13 +289,27 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
                         r1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, offs[i] + c1o, 0, 0));
                     }
                 }
+                float x0[16], x1[16];
+                if (g.gx) {                // kernel-uniform: the GroupNorm input at this block's voxels, all loads in flight together
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        x0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offs[i] + c0o, 0, 0));
+                        x1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offs[i] + c1o, 0, 0));
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float v0 = acc[vb][0][i] + bias0, v1 = acc[vb][1][i] + bias1;
                     if (residual) { v0 += r0[i]; v1 += r1[i]; }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, offs[i] + c0o, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, offs[i] + c1o, 0, 0);
-                    if (g.stats && offs[i] != OOB) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
+                    if (g.gx) {
+                        if (offs[i] != OOB) {      // out-of-range loads returned 0 and out-of-range channels are never read back
+                            const float dz0 = v0 * f9_act_grad(gA0 * x0[i] + gB0, g.gact), dz1 = v1 * f9_act_grad(gA1 * x1[i] + gB1, g.gact);
+                            cs0 += dz0; cq0 = fmaf(dz0, (x0[i] - gm0) * gr0, cq0);
+                            cs1 += dz1; cq1 = fmaf(dz1, (x1[i] - gm1) * gr1, cq1);
+                        }
+                    } else if (g.stats && offs[i] != OOB) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
                     acc[vb][0][i] = 0.f; acc[vb][1][i] = 0.f;
                 }
             }

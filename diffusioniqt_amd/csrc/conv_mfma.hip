@@ -1758,6 +1758,45 @@ extern "C" int diqt_conv3d_fwd_ex(const float* x, const float* packed, const flo
                            epd, eph, epw, stream, stats);
 }
 
+// The backward-data pass of a conv that sits behind a fused GroupNorm + scale/shift + Mish/SiLU (Block.forward: GN -> act -> conv,
+// imagen_pytorch3D.py:535-566 / imagen_video.py:671-697): y = conv(x = dY of the conv, flipped packed weights) is the gradient w.r.t.
+// the activated tensor, and the epilogue of conv_fwd9_kernel -- which holds that gradient in registers -- also reads the GroupNorm
+// input gn_x at the same voxels and writes the per-tile partial sums of the GroupNorm backward (sum dz, sum dz xhat per channel):
+// partials[B][nblk][2][Cout], nblk = diqt_conv3d_fwd_gnbwd_blocks(...) (0: this shape does not run on conv_fwd9_kernel un-split; use
+// diqt_conv3d_fwd + diqt_gn_act_bwd).  diqt_gn_act_bwd_from_partials finishes the GroupNorm backward without its reduction pass.
+extern "C" int diqt_conv3d_fwd_gnbwd_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                            int epd, int eph, int epw) {
+    static const bool off = [] { const char* e = getenv("DIQT_NO_GNBWD_FUSE"); return e && e[0] == '1'; }();
+    F9Geom g9;
+    size_t l9;
+    unsigned gr9;
+    if (off || Cin % 4 != 0 || smallcin_pad(Cin, kd * kh * kw)) return 0;
+    if (!fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw), false))
+        return 0;
+    return g9.tilesD * g9.tilesH * g9.tilesW;
+}
+extern "C" int diqt_conv3d_fwd_gnbwd(const float* x, const float* packed, float* y, float* partials, const float* gn_x, const float* mean,
+                                     const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
+                                     int cond_stride, int G, int act, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw,
+                                     int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
+    DIQT_REQUIRE(x && packed && y && partials && gn_x && mean && rstd, DIQT_E_ALIGN, "conv3d_fwd_gnbwd: null pointer");
+    DIQT_REQUIRE(aligned16(x) && aligned16(packed), DIQT_E_ALIGN, "conv3d_fwd_gnbwd: x and packed weights must be 16-byte aligned");
+    DIQT_REQUIRE(G > 0 && Cout % G == 0 && (act == DIQT_ACT_MISH || act == DIQT_ACT_SILU), DIQT_E_UNSUPPORTED,
+                 "conv3d_fwd_gnbwd: Mish / SiLU, groups dividing the channels");
+    DIQT_REQUIRE((scale == nullptr) == (shift == nullptr) && (!scale || cond_stride >= Cout), DIQT_E_SHAPE, "conv3d_fwd_gnbwd: scale / shift");
+    F9Geom g9;
+    size_t l9;
+    unsigned gr9;
+    DIQT_REQUIRE(diqt_conv3d_fwd_gnbwd_blocks(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw) > 0 &&
+                     fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw,
+                               diqt_conv_packed_elems(Cout, Cin, kd, kh, kw), false),
+                 DIQT_E_UNSUPPORTED, "conv3d_fwd_gnbwd: shape not taken by conv_fwd9_kernel (diqt_conv3d_fwd_gnbwd_blocks == 0)");
+    g9.stats = partials;
+    g9.gx = gn_x; g9.gmean = mean; g9.grstd = rstd; g9.ggamma = gamma; g9.gbeta = beta; g9.gscale = scale; g9.gshift = shift;
+    g9.gG = G; g9.gcs = cond_stride; g9.gact = act;
+    return fwd9_launch(x, packed, nullptr, nullptr, y, g9, l9, gr9, stream);
+}
+
 static int conv3d_fwd_one(const float* x, const float* packed, const float* bias, const float* residual,
                           float* y, void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int Cin, int Cout,
                           int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats,

@@ -1482,10 +1482,13 @@ extern "C" int diqt_gn_act_fwd(const float* x, const float* mean, const float* r
     return check_launch("gn_act_fwd");
 }
 
-extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd,
-                               const float* gamma, const float* beta, const float* scale, const float* shift,
-                               int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
-                               size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream) {
+// ext_partials: the reduction pass already done elsewhere (the epilogue of the conv that produced dy, diqt_conv3d_fwd_gnbwd):
+// [B][ext_nblk][2][C] partial sums of (dz, dz xhat)
+static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, const float* scale, const float* shift,
+                           int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
+                           size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream, const float* ext_partials,
+                           int ext_nblk) {
     DIQT_REQUIRE(x && dy && mean && rstd && dx && workspace, DIQT_E_ALIGN, "gn_act_bwd: null pointer");
     DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_act_bwd: bad shape");
     DIQT_REQUIRE(workspace_bytes >= diqt_reduce_workspace_bytes(B, C), DIQT_E_WORKSPACE, "gn_act_bwd: workspace too small");
@@ -1499,16 +1502,19 @@ extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mea
     const size_t per = (size_t)rows * C;
     const bool vec = vec_ok(x, dy, dx, per, C);
     GnBwdF f{x, dy, k, act};
-    if (vec || C % 4 != 0 || C > 1024) {
+    int rc = DIQT_OK;
+    if (ext_partials) {
+        DIQT_REQUIRE(ext_nblk > 0, DIQT_E_SHAPE, "gn_act_bwd_from_partials: nblk");
+    } else if (vec || C % 4 != 0 || C > 1024) {
         hipLaunchKernelGGL((colreduce_kernel<2, GnBwdF>), dim3(nblk, B), dim3(256), 0, STREAM, f, partial, rows, C);
+        rc = check_launch("gn_act_bwd/reduce");
+        if (rc) return rc;
     } else {
         set_error("gn_act_bwd: C %% 4 == 0 requires 16-byte aligned x, dy, dx");
         return DIQT_E_ALIGN;
     }
-    int rc = check_launch("gn_act_bwd/reduce");
-    if (rc) return rc;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((B * 2 * C + 3) / 4), dim3(256), 0, STREAM, partial, S, nblk, 2 * C,
-                       B * 2 * C, 1.f);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((B * 2 * C + 3) / 4), dim3(256), 0, STREAM, ext_partials ? ext_partials : partial, S,
+                       ext_partials ? ext_nblk : nblk, 2 * C, B * 2 * C, 1.f);
     rc = check_launch("gn_act_bwd/sum");
     if (rc) return rc;
     hipLaunchKernelGGL(gn_bwd_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, STREAM, S, k, dgamma, dbeta, dscale,
@@ -1519,6 +1525,23 @@ extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mea
     if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
     else hipLaunchKernelGGL(gn_act_bwd_dx_kernel<false>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
     return check_launch("gn_act_bwd/dx");
+}
+
+extern "C" int diqt_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, const float* scale, const float* shift,
+                               int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
+                               size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream) {
+    return gn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, scale, shift, cond_stride, dx, dgamma, dbeta, dscale, dshift, workspace,
+                           workspace_bytes, B, rows, C, G, act, stream, nullptr, 0);
+}
+extern "C" int diqt_gn_act_bwd_from_partials(const float* x, const float* dy, const float* partials, int nblk, const float* mean,
+                                             const float* rstd, const float* gamma, const float* beta, const float* scale,
+                                             const float* shift, int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale,
+                                             float* dshift, void* workspace, size_t workspace_bytes, int B, int rows, int C, int G, int act,
+                                             void* stream) {
+    DIQT_REQUIRE(partials, DIQT_E_ALIGN, "gn_act_bwd_from_partials: null pointer");
+    return gn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, scale, shift, cond_stride, dx, dgamma, dbeta, dscale, dshift, workspace,
+                           workspace_bytes, B, rows, C, G, act, stream, partials, nblk);
 }
 
 extern "C" int diqt_chan_layernorm_fwd_res(const float* x, const float* g, const float* b, const float* residual, float* y,

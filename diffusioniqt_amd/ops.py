@@ -235,10 +235,49 @@ def _conv_fwd_raw(x5, packed, bias, residual, Cout, k, pad, epad=(0, 0, 0), stat
     return y
 
 
+class GnCtx:
+    """What the backward-data pass of a conv needs to know about the fused GroupNorm + activation that produced its input."""
+    __slots__ = ("x", "mean", "rstd", "gamma", "beta", "ss", "groups", "act")
+
+    def __init__(self, x, mean, rstd, gamma, beta, ss, groups, act):
+        self.x, self.mean, self.rstd, self.gamma, self.beta, self.ss, self.groups, self.act = x, mean, rstd, gamma, beta, ss, groups, act
+
+
+def _conv_bwd_data_gn(dy, packed, Cout, k, pad, epad, gn):
+    """dX of a conv whose input was act(GN(gn.x)): the conv_fwd9_kernel launch that computes dX also reduces the GroupNorm backward's
+    per-channel sums in its epilogue; they travel to _GnActFn.backward on the gradient tensor (``_diqt_gnbwd``).  None: not this shape."""
+    B, D, H, W, Cin = dy.shape
+    kd, kh, kw = k
+    geo = (B, D, H, W, Cin, Cout, kd, kh, kw, *pad, *epad)
+    if gn.act not in (ACT_MISH, ACT_SILU) or tuple(gn.x.shape[-1:]) != (Cout,):
+        return None
+    nblk = _lib.query("diqt_conv3d_fwd_gnbwd_blocks", *geo)
+    Do, Ho, Wo = D + 2 * pad[0] + epad[0] - kd + 1, H + 2 * pad[1] + epad[1] - kh + 1, W + 2 * pad[2] + epad[2] - kw + 1
+    if nblk <= 0 or tuple(gn.x.shape) != (B, Do, Ho, Wo, Cout) or Cout % gn.groups != 0:
+        return None
+    dx = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=dy.device)
+    partials = torch.empty((B, nblk, 2, Cout), dtype=torch.float32, device=dy.device)
+    scale = shift = None
+    cs = 0
+    if gn.ss is not None:
+        scale, shift, cs = gn.ss.data_ptr(), gn.ss.data_ptr() + 4 * Cout, 2 * Cout
+    if TIMER.enabled:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+    _lib.call("diqt_conv3d_fwd_gnbwd", dy, packed, dx, partials, gn.x, gn.mean, gn.rstd, gn.gamma, gn.beta, scale, shift, cs, gn.groups,
+              gn.act, *geo, _stream())
+    if TIMER.enabled:
+        e.record()
+        TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd9_kernel", geo[:9]))
+    dx._diqt_gnbwd = (partials, nblk, dx._version, dx.data_ptr())
+    return dx
+
+
 class _Conv3dFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, residual, epad=(0, 0, 0), stats_out=None):
+    def forward(ctx, x, weight, bias, pad, residual, epad=(0, 0, 0), stats_out=None, gnctx=None):
         _chk(x, weight, bias, residual)
+        ctx.gnctx = gnctx           # x = act(GN(.)): the backward-data pass can do the GroupNorm backward's reduction in its epilogue
         Cout, Cin, kd, kh, kw = weight.shape
         assert x.dim() == 5 and x.shape[-1] == Cin, f"conv3d: x {tuple(x.shape)} vs weight {tuple(weight.shape)}"
         lp = lp_mode()
@@ -268,6 +307,9 @@ class _Conv3dFn(Function):
             # bf16 training: backward-data on the bf16 MFMA kernel too (the reference's autocast backward runs in the forward's
             # type).  fp16 gradients would need the GradScaler the reference pairs with fp16; they stay on the fp32 kernel.
             dx = _conv_fwd_half(dy, weight, None, None, bpad, bepad, 1, mode=1) if ctx.lp == 1 else None
+            gn = ctx.gnctx
+            if dx is None and gn is not None:
+                dx = _conv_bwd_data_gn(dy, _packed(weight, 1), Cin, (kd, kh, kw), bpad, bepad, gn)
             if dx is None:
                 dx = _conv_fwd_raw(dy, _packed(weight, 1), None, None, Cin, (kd, kh, kw), bpad, bepad)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -288,7 +330,7 @@ class _Conv3dFn(Function):
                 kid = _lib.query("diqt_conv3d_bwd_weight_kernel_id", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
                 tag = ("conv_bwd_weight_gemm", "conv_bwd_weight_kernel", "conv_bwd_weight2_kernel", "conv_wgrad3_kernel")[max(kid, 0)]
                 TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, tag, (B, D, H, W, Cin, Cout, kd, kh, kw)))
-        return dx, dw, db, None, (dy if ctx.has_res else None), None, None
+        return dx, dw, db, None, (dy if ctx.has_res else None), None, None, None
 
 
 def conv3d(x, weight, bias=None, padding=(0, 0, 0), residual=None, extra_pad=(0, 0, 0), want_stats=False):
@@ -303,10 +345,11 @@ def conv3d(x, weight, bias=None, padding=(0, 0, 0), residual=None, extra_pad=(0,
     if _lib.query("diqt_conv3d_lds_bytes", D, H, W, kd, kh, kw, *padding, *extra_pad) > 160 * 1024:
         y = _ConvDirectFn.apply(x, weight, bias, (1, 1, 1), padding, 1, extra_pad)
         return y if residual is None else add(y, residual)
+    gnctx = getattr(x, "_diqt_gnctx", None) if torch.is_grad_enabled() else None
     if not want_stats:
-        return _Conv3dFn.apply(x, weight, bias, padding, residual, extra_pad)
+        return _Conv3dFn.apply(x, weight, bias, padding, residual, extra_pad, None, gnctx)
     holder = []
-    y = _Conv3dFn.apply(x, weight, bias, padding, residual, extra_pad, holder)
+    y = _Conv3dFn.apply(x, weight, bias, padding, residual, extra_pad, holder, gnctx)
     if holder:
         y._diqt_stats = holder[0]           # consumed by groupnorm_act / se_gate_residual on this exact tensor
     return y
@@ -475,7 +518,7 @@ class SSView:
 
 class _GnActFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, groups, act, eps, pre=None):
+    def forward(ctx, x, gamma, beta, ss, groups, act, eps, pre=None, gn_out=None):
         _chk(x, gamma, beta, ss.base if isinstance(ss, SSView) else ss)
         B, C = x.shape[0], x.shape[-1]
         rows = x.numel() // (B * C)
@@ -504,12 +547,19 @@ class _GnActFn(Function):
         _lib.call("diqt_gn_act_fwd", x, mean, rstd, gamma, beta, scale, shift, cs, y, B, rows, C, groups, act, s)
         ctx.save_for_backward(x, gamma, beta, ss, mean, rstd)
         ctx.cfg = (B, rows, C, groups, act)
+        if gn_out is not None and x.dim() == 5:
+            gn_out.append(GnCtx(x, mean, rstd, gamma, beta, ss, groups, act))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, ss, mean, rstd = ctx.saved_tensors
         B, rows, C, groups, act = ctx.cfg
+        # partial sums from the producer of dy -- valid only for the very tensor they were computed for (autograd adds other
+        # branches' gradients in place: the version counter tells)
+        pre = getattr(dy, "_diqt_gnbwd", None)
+        if pre is not None and (pre[2] != dy._version or pre[3] != dy.data_ptr() or not dy.is_contiguous()):
+            pre = None
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgamma = torch.empty_like(gamma) if gamma is not None else None
@@ -522,14 +572,25 @@ class _GnActFn(Function):
             scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, 2 * C
             dscale, dshift = dss.data_ptr(), dss.data_ptr() + 4 * C
         ws, n = _reduce_ws(B, C, x.device)
-        _lib.call("diqt_gn_act_bwd", x, dy, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta, dscale,
-                  dshift, ws, n, B, rows, C, groups, act, _stream())
-        return dx, dgamma, dbeta, dss, None, None, None, None
+        if pre is not None and pre[0].shape == (B, pre[1], 2, C):
+            # the conv behind this GroupNorm reduced (sum dz, sum dz xhat) in the epilogue of its backward-data pass
+            _lib.call("diqt_gn_act_bwd_from_partials", x, dy, pre[0], pre[1], mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
+                      dscale, dshift, ws, n, B, rows, C, groups, act, _stream())
+        else:
+            _lib.call("diqt_gn_act_bwd", x, dy, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta, dscale,
+                      dshift, ws, n, B, rows, C, groups, act, _stream())
+        return dx, dgamma, dbeta, dss, None, None, None, None, None
 
 
 def groupnorm_act(x, gamma, beta, scale_shift=None, groups=8, act=ACT_MISH, eps=1e-5):
     """act(GN(x) * (scale+1) + shift) with scale_shift = one [B, 2C] embedding (scale first)."""
-    return _GnActFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None))
+    if not torch.is_grad_enabled() or isinstance(scale_shift, SSView):
+        return _GnActFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None))
+    holder = []
+    y = _GnActFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None), holder)
+    if holder:
+        y._diqt_gnctx = holder[0]           # read by conv3d on this exact tensor (Block: GN -> act -> conv)
+    return y
 
 
 class _ActFn(Function):

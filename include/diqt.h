@@ -197,6 +197,23 @@ int diqt_gn_act_bwd(const float* x, const float* dy, const float* mean, const fl
                     void* workspace, size_t workspace_bytes,
                     int B, int rows_per_batch, int C, int G, int act, void* stream);
 
+/* The GroupNorm + activation backward split around the conv it feeds (Block = GN -> act -> conv): diqt_conv3d_fwd_gnbwd is the
+ * conv's backward-data pass (x = gradient of the conv output, flipped packed weights) whose epilogue also reduces the GroupNorm
+ * backward's per-channel sums over each output tile, reading the GroupNorm input gn_x at the tile's voxels:
+ * partials[B][nblk][2][Cout], nblk = diqt_conv3d_fwd_gnbwd_blocks(...) (0: shape not taken; use diqt_conv3d_fwd + diqt_gn_act_bwd).
+ * diqt_gn_act_bwd_from_partials then finishes the GroupNorm backward without its own reduction pass over x and dy.
+ * Replaces autograd of Block.forward (imagen_pytorch3D.py:535-566, imagen_video.py:671-697).                                       */
+int diqt_conv3d_fwd_gnbwd_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd,
+                                 int eph, int epw);
+int diqt_conv3d_fwd_gnbwd(const float* x, const float* packed, float* y, float* partials, const float* gn_x, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
+                          int cond_stride, int G, int act, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
+                          int ph, int pw, int epd, int eph, int epw, void* stream);
+int diqt_gn_act_bwd_from_partials(const float* x, const float* dy, const float* partials, int nblk, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, const float* scale, const float* shift, int cond_stride,
+                                  float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
+                                  size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream);
+
 /* Per-position LayerNorm over the channel axis, biased variance; gain `g` and optional bias `b` (NULL for the
  * gain-only ChanLayerNorm imagen_pytorch3D.py:361-382 / LayerNorm imagen_video.py:172-200; non-NULL for
  * nn.LayerNorm at imagen_video.py:444,1306).                                                           */

@@ -753,6 +753,62 @@ def test_pointwise_weight_gradient_routes_to_the_dma_kernel(ops):
         close(bd.grad, br.grad, tol=1e-4, what=f"linear db rows={rows}")
 
 
+@pytest.mark.parametrize("B,sp,Cin,Cout,k,act,with_ss", [
+    (4, (32, 32, 32), 16, 64, (3, 3, 3), "mish", True),       # backward-data 64 -> 16 on 512-voxel tiles, one round
+    (8, (16, 16, 16), 128, 64, (3, 3, 3), "mish", False),     # ... 256-voxel tiles (backward-data 64 -> 128: two channel blocks), no scale / shift
+    (8, (32, 8, 8), 256, 64, (1, 3, 3), "silu", True)])       # the pseudo-3D block: SiLU, (1,3,3) filter, four 64-channel blocks
+def test_block_backward_with_groupnorm_reduction_in_the_conv_epilogue(ops, B, sp, Cin, Cout, k, act, with_ss):
+    """Block = GroupNorm -> (scale + 1) x + shift -> Mish / SiLU -> conv (imagen_pytorch3D.py:535-566, imagen_video.py:671-697).  The
+    backward-data pass of the conv reduces the GroupNorm backward's per-channel sums in its epilogue (diqt_conv3d_fwd_gnbwd) and
+    diqt_gn_act_bwd_from_partials finishes without a reduction pass: every gradient of the chain against float64 autograd."""
+    from diffusioniqt_amd import _lib
+    D, H, W = sp
+    pads = tuple(kk // 2 for kk in k)
+    bp = tuple(kk - 1 - p for kk, p in zip(k, pads))
+    assert _lib.query("diqt_conv3d_fwd_gnbwd_blocks", B, D, H, W, Cout, Cin, *k, *bp, 0, 0, 0) > 0, "backward-data pass not on conv_fwd9_kernel"
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, D, H, W, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.randn(Cin, generator=g), torch.randn(Cin, generator=g) * 0.3
+    ss = torch.randn(B, 2 * Cin, generator=g) * 0.3 if with_ss else None
+    w = torch.randn(Cout, Cin, *k, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
+    bias = torch.randn(Cout, generator=g) * 0.1
+    dy = torch.randn(B, Cout, D, H, W, generator=g)
+    # float64 reference
+    xr, gr, br, wr, cr = (t.double().requires_grad_() for t in (x, gamma, beta, w, bias))
+    sr = ss.double().requires_grad_() if with_ss else None
+    h = F.group_norm(xr, 8, gr, br, eps=1e-5)
+    if with_ss:
+        h = h * (sr[:, :Cin, None, None, None] + 1) + sr[:, Cin:, None, None, None]
+    h = F.mish(h) if act == "mish" else F.silu(h)
+    F.conv3d(h, wr, cr, padding=pads).backward(dy.double())
+    # device
+    xd = cl(x).requires_grad_()
+    gd, bd, wd, cd = (t.to(DEV).requires_grad_() for t in (gamma, beta, w, bias))
+    sd = ss.to(DEV).requires_grad_() if with_ss else None
+    a = ops.groupnorm_act(xd, gd, bd, sd, 8, ops.ACT_MISH if act == "mish" else ops.ACT_SILU)
+    assert getattr(a, "_diqt_gnctx", None) is not None, "GroupNorm context not published to the conv"
+    y = ops.conv3d(a, wd, cd, pads)
+    y.backward(cl(dy))
+    close(cf(xd.grad), xr.grad, tol=5e-5, what="d x through conv + GroupNorm")
+    close(gd.grad, gr.grad, tol=1e-4, what="d gamma")
+    close(bd.grad, br.grad, tol=1e-4, what="d beta")
+    close(wd.grad, wr.grad, tol=1e-4, what="d weight")
+    if with_ss:
+        close(sd.grad, sr.grad, tol=1e-4, what="d scale / shift")
+    # two consumers of the activated tensor: autograd sums their gradients in place, the partial sums of one branch must not be used
+    xd2 = cl(x).requires_grad_()
+    a2 = ops.groupnorm_act(xd2, gd.detach(), bd.detach(), sd.detach() if with_ss else None, 8, ops.ACT_MISH if act == "mish" else ops.ACT_SILU)
+    y2 = ops.conv3d(a2, wd.detach(), cd.detach(), pads)
+    (y2.float() * cl(dy)).sum().add((a2 * 0.5).sum()).backward()
+    xr2 = x.double().requires_grad_()
+    h2 = F.group_norm(xr2, 8, gamma.double(), beta.double(), eps=1e-5)
+    if with_ss:
+        h2 = h2 * (ss.double()[:, :Cin, None, None, None] + 1) + ss.double()[:, Cin:, None, None, None]
+    h2 = F.mish(h2) if act == "mish" else F.silu(h2)
+    ((F.conv3d(h2, w.double(), bias.double(), padding=pads) * dy.double()).sum() + (h2 * 0.5).sum()).backward()
+    close(cf(xd2.grad), xr2.grad, tol=5e-5, what="d x with a second consumer of the activated tensor")
+
+
 def test_multi_accumulate_matches_per_tensor_adds(ops):
     """Gradient accumulation into the flat arena: one launch == the per-parameter `grad += new` adds (bit-exact)."""
     g = torch.Generator().manual_seed(11)

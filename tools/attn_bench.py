@@ -14,6 +14,8 @@ SHAPES = [  # name, G, n, h, d, E, rel, causal
     ("temporal full-res 32 frames, B=8", 8192, 32, 8, 64, 1, True, True),
     ("spatial 16x16 per frame, B=2 x 64", 128, 256, 8, 64, 1, False, False),
 ]
+if os.environ.get('ONLY'):
+    SHAPES = [SHAPES[int(os.environ['ONLY'])]]
 for name, G, n, h, d, E, use_rel, causal in SHAPES:
     q = torch.randn(G, n, h * d, device=dev)
     kv = torch.randn(G, E + n, 2 * d, device=dev)

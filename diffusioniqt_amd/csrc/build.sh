@@ -10,11 +10,11 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Wn
 if [ "$1" = "--force" ]; then
   rm -f *.o *.stamp libdiqt_hip.so
 fi
-stamp_of() { cat "$1" common.h conv_wgrad.h conv_fwd9.h conv_fwd9_kernel.h ../../include/diqt.h | cat - <(echo "$FLAGS $HIPCC") | sha256sum | cut -d' ' -f1; }
+stamp_of() { cat "$1" common.h conv_wgrad.h conv_fwd9.h conv_fwd9_kernel.h conv_pw.h ../../include/diqt.h | cat - <(echo "$FLAGS $HIPCC") | sha256sum | cut -d' ' -f1; }
 OBJS=""
 PIDS=""
 BUILT=""
-for f in conv_fwd9 conv_fwd9_b conv_fwd9_c conv_mfma conv_wgrad conv_half elementwise bgemm conv_direct attention datapath lib; do
+for f in conv_fwd9 conv_fwd9_b conv_fwd9_c conv_mfma conv_wgrad conv_pw conv_half elementwise bgemm conv_direct attention datapath lib; do
   src=$f.hip; xflag=""
   if [ $f = lib ]; then src=lib.cpp; xflag="-x hip"; fi
   want=$(stamp_of $src)

@@ -22,6 +22,7 @@
 //   layout and are reduced in a fixed order (deterministic) by conv_reduce_dw_kernel.
 #include "common.h"
 #include "conv_wgrad.h"
+#include "conv_pw.h"
 #include "conv_fwd9.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -1997,6 +1998,8 @@ static int conv3d_fwd_one(const float* x, const float* packed, const float* bias
     }
     static const bool no1x1 = [] { const char* e = getenv("DIQT_CONV_NO1X1"); return e && e[0] == '1'; }();
     if (buf && !stats && !dbg_on && !no1x1 && kd * kh * kw == 1 && g.B == 1 && g.D == 1 && g.H == 1 && g.Wo == g.W && g.TW == MTILE) {     // the flattened-rows geometry of make_geom
+        if (pw64_ok((long long)g.W, Cin, Cout, x, packed, y))      // few input channels, many output channels: x resident, persistent row walk
+            return pw64_launch(x, packed, bias, residual, y, (long long)g.W, Cout, g.CoutPad, stream);
         hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, packed, bias, residual, y, g);
         return check_launch("conv3d_fwd(1x1x1)");
     }

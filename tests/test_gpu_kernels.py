@@ -809,6 +809,26 @@ def test_block_backward_with_groupnorm_reduction_in_the_conv_epilogue(ops, B, sp
     close(cf(xd2.grad), xr2.grad, tol=5e-5, what="d x with a second consumer of the activated tensor")
 
 
+@pytest.mark.parametrize("rows_shape,Cout,res", [((2, 16, 16, 16), 512, True), ((1, 17, 17, 17), 264, False), ((1, 1, 1, 4100), 256, True)])
+def test_pointwise_conv_with_64_input_channels_on_the_resident_kernel(ops, rows_shape, Cout, res):
+    """conv1x1_k64_kernel (x tile resident, every 64-channel block of the output from one workgroup, persistent row walk): the
+    attention to_q / feed-forward shapes 64 -> 512 / 128, a ragged channel block, a ragged last row tile, bias and residual; float64."""
+    B, D, H, W = rows_shape
+    g = torch.Generator().manual_seed(Cout)
+    x = torch.randn(B, 64, D, H, W, generator=g)
+    w = torch.randn(Cout, 64, 1, 1, 1, generator=g) / 8.0
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, D, H, W, generator=g) if res else None
+    ref = F.conv3d(x.double(), w.double(), b.double())
+    if res:
+        ref = ref + r.double()
+    with torch.no_grad():
+        y = ops.conv3d(cl(x), w.to(DEV), b.to(DEV), (0, 0, 0), residual=cl(r) if res else None)
+        y2 = ops.conv3d(cl(x), w.to(DEV), b.to(DEV), (0, 0, 0), residual=cl(r) if res else None)
+    close(cf(y), ref, what="pointwise conv, K = 64")
+    assert torch.equal(y, y2)
+
+
 def test_multi_accumulate_matches_per_tensor_adds(ops):
     """Gradient accumulation into the flat arena: one launch == the per-parameter `grad += new` adds (bit-exact)."""
     g = torch.Generator().manual_seed(11)

@@ -14,7 +14,7 @@ stamp_of() { cat "$1" common.h conv_wgrad.h conv_fwd9.h conv_fwd9_kernel.h conv_
 OBJS=""
 PIDS=""
 BUILT=""
-for f in conv_fwd9 conv_fwd9_b conv_fwd9_c conv_mfma conv_wgrad conv_pw conv_half elementwise bgemm conv_direct attention datapath lib; do
+for f in conv_fwd9 conv_fwd9_d conv_fwd9_b conv_fwd9_c conv_fwd9_e conv_mfma conv_wgrad conv_pw conv_half elementwise bgemm conv_direct attention datapath lib; do
   src=$f.hip; xflag=""
   if [ $f = lib ]; then src=lib.cpp; xflag="-x hip"; fi
   want=$(stamp_of $src)

@@ -4,6 +4,11 @@
 
 namespace diqt {
 
+struct F9GnParams {          // device-resident parameters of the GroupNorm-backward epilogue
+    const float *mean, *rstd, *gamma, *beta, *scale, *shift;
+    int G, cs, act, pad;
+};
+
 struct F9Geom {
     int B, D, H, W, Cin, Cout, Do, Ho, Wo, pd, ph, pw;
     int tilesD, tilesH, tilesW, MT, nNt, CoutPad, variant;
@@ -14,8 +19,11 @@ struct F9Geom {
     // GroupNorm-backward epilogue (this launch is the backward-data pass of the conv behind a GroupNorm + activation): with gx set,
     // the statistics rows hold sum(dz), sum(dz * xhat) of dz = output * act'(A gx + B), xhat = (gx - mean) rstd instead of the
     // output's sums -- the reduction pass of the GroupNorm backward, without its read of gx and of this output
+    // (the kernel gets gx alone -- the flag -- and a device copy of the other fields through gnp, so that they occupy no scalar registers
+    // in the main loop)
     const float *gx, *gmean, *grstd, *ggamma, *gbeta, *gscale, *gshift;
     int gG, gcs, gact;
+    const struct F9GnParams* gnp;
 };
 
 // maySplit: the caller has a workspace for split-K slabs (g.ksplit * output elements floats when g.ksplit > 1; the kernel then gets

@@ -66,7 +66,9 @@ __device__ __forceinline__ void f9_step_end(int n) {
 #undef F9_WB
 }
 
-template <class C>
+// GNB: the GroupNorm-backward epilogue (F9Geom::gx).  A separate instantiation: with the epilogue's 64 extra live registers and
+// branches compiled into the plain kernel its main loop lost 10 % (448 vs 405 us on the dominant launch).
+template <class C, bool GNB>
 __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias, const float* __restrict__ residual,
                                                            float* __restrict__ y, F9Geom g) {
@@ -257,20 +259,23 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
             float cs0 = 0.f, cq0 = 0.f, cs1 = 0.f, cq1 = 0.f;
             // GroupNorm-backward epilogue: z = gA x + gB (the forward's fused GN + scale/shift), xhat = (x - gm) gr for this lane's two channels
             float gA0 = 0.f, gB0 = 0.f, gm0 = 0.f, gr0 = 0.f, gA1 = 0.f, gB1 = 0.f, gm1 = 0.f, gr1 = 0.f;
-            if (g.gx) {            // kernel-uniform
-                const int cpg = g.Cout / g.gG;
+            int gact = 0;
+            if constexpr (GNB) {
+                const F9GnParams gp = *g.gnp;              // scalar loads, here and not before the main loop
+                gact = gp.act;
+                const int cpg = g.Cout / gp.G;
                 auto coef = [&](int co, float& A, float& Bc, float& m, float& r) __attribute__((always_inline)) {
                     const int cc = min(co, g.Cout - 1);
-                    m = g.gmean[tb * g.gG + cc / cpg]; r = g.grstd[tb * g.gG + cc / cpg];
-                    const float ga = g.ggamma ? g.ggamma[cc] : 1.f, be = g.gbeta ? g.gbeta[cc] : 0.f;
-                    const float sc = g.gscale ? g.gscale[tb * g.gcs + cc] + 1.f : 1.f, sf = g.gshift ? g.gshift[tb * g.gcs + cc] : 0.f;
+                    m = gp.mean[tb * gp.G + cc / cpg]; r = gp.rstd[tb * gp.G + cc / cpg];
+                    const float ga = gp.gamma ? gp.gamma[cc] : 1.f, be = gp.beta ? gp.beta[cc] : 0.f;
+                    const float sc = gp.scale ? gp.scale[tb * gp.cs + cc] + 1.f : 1.f, sf = gp.shift ? gp.shift[tb * gp.cs + cc] : 0.f;
                     A = r * ga * sc;
                     Bc = (be - m * r * ga) * sc + sf;
                 };
                 coef(co0, gA0, gB0, gm0, gr0);
                 coef(co1, gA1, gB1, gm1, gr1);
             }
-            const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.gx), 0, g.gx ? (int)g.yBytes : 0, 0x00020000);
+            const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.gx), 0, GNB ? (int)g.yBytes : 0, 0x00020000);
 #pragma unroll
             for (int vb = 0; vb < NVB; ++vb) {
                 const int od = d0 + bd[vb];
@@ -282,32 +287,32 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
                     const bool ok = od < g.Do && oh < g.Ho && ow < g.Wo;
                     offs[i] = ok ? (unsigned)((((tb * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout) * 4u : OOB;
                 }
-                if (residual) {            // kernel-uniform; all 32 loads of the block in flight before the first add
+                // r0 / r1: the residual of a forward launch, or (GNB: a backward-data launch, which has none) the GroupNorm input at this
+                // block's voxels -- one set of 32 registers either way; all loads in flight before the first use
+                if constexpr (GNB) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        r0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offs[i] + c0o, 0, 0));
+                        r1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offs[i] + c1o, 0, 0));
+                    }
+                } else if (residual) {     // kernel-uniform
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         r0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, offs[i] + c0o, 0, 0));
                         r1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, offs[i] + c1o, 0, 0));
                     }
                 }
-                float x0[16], x1[16];
-                if (g.gx) {                // kernel-uniform: the GroupNorm input at this block's voxels, all loads in flight together
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        x0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offs[i] + c0o, 0, 0));
-                        x1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offs[i] + c1o, 0, 0));
-                    }
-                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float v0 = acc[vb][0][i] + bias0, v1 = acc[vb][1][i] + bias1;
-                    if (residual) { v0 += r0[i]; v1 += r1[i]; }
+                    if constexpr (!GNB) { if (residual) { v0 += r0[i]; v1 += r1[i]; } }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, offs[i] + c0o, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, offs[i] + c1o, 0, 0);
-                    if (g.gx) {
+                    if constexpr (GNB) {
                         if (offs[i] != OOB) {      // out-of-range loads returned 0 and out-of-range channels are never read back
-                            const float dz0 = v0 * f9_act_grad(gA0 * x0[i] + gB0, g.gact), dz1 = v1 * f9_act_grad(gA1 * x1[i] + gB1, g.gact);
-                            cs0 += dz0; cq0 = fmaf(dz0, (x0[i] - gm0) * gr0, cq0);
-                            cs1 += dz1; cq1 = fmaf(dz1, (x1[i] - gm1) * gr1, cq1);
+                            const float dz0 = v0 * f9_act_grad(gA0 * r0[i] + gB0, gact), dz1 = v1 * f9_act_grad(gA1 * r1[i] + gB1, gact);
+                            cs0 += dz0; cq0 = fmaf(dz0, (r0[i] - gm0) * gr0, cq0);
+                            cs1 += dz1; cq1 = fmaf(dz1, (r1[i] - gm1) * gr1, cq1);
                         }
                     } else if (g.stats && offs[i] != OOB) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
                     acc[vb][0][i] = 0.f; acc[vb][1][i] = 0.f;
@@ -338,9 +343,9 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
     }
 }
 
-template <class C> static int f9_launch(const float* x, const float* packed, const float* bias, const float* residual, float* y,
+template <class C, bool GNB = false> static int f9_launch(const float* x, const float* packed, const float* bias, const float* residual, float* y,
                                         const F9Geom& g, size_t lds, unsigned grid, void* stream) {
-    auto kern = conv_fwd9_kernel<C>;
+    auto kern = conv_fwd9_kernel<C, GNB>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd(v9): hipFuncSetAttribute: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(grid, g.ksplit), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
@@ -361,6 +366,11 @@ using F9_311_256 = F9Cfg<3, 1, 1, 4, 8, 8, 2>;
 int fwd9_launch_b(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
                   unsigned grid, void* stream);
 int fwd9_launch_c(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
+                  unsigned grid, void* stream);
+// ... and of the instantiations with the GroupNorm-backward epilogue (g.gx set)
+int fwd9_launch_d(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
+                  unsigned grid, void* stream);
+int fwd9_launch_e(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
                   unsigned grid, void* stream);
 
 }  // namespace diqt

@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# opt-in kernel paths that production leaves off by default run under test (read once by the library, so set before it loads):
+# the GroupNorm backward's reduction in the epilogue of the conv's backward-data pass (diqt_conv3d_fwd_gnbwd)
+os.environ.setdefault("DIQT_GNBWD_FUSE", "1")
 
 
 def pytest_configure(config):

@@ -13,6 +13,8 @@
 #include "common.h"
 
 namespace diqt {
+
+typedef float f32x4a __attribute__((ext_vector_type(4)));       // LDS operand quads (plain vector registers)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int AQ = 128;     // query rows per workgroup (4 waves x 32)
 constexpr int AKT = 32;     // keys per tile
@@ -21,6 +23,22 @@ constexpr int AKT = 32;     // keys per tile
 // bias on the self keys, the null-key bias on the last extra key, -inf for causal-masked and out-of-range keys.  Branch-free on
 // purpose (clamped unconditional gather + selects): a guarded form compiles to four exec-mask branches per element, each gather
 // behind its own s_waitcnt vmcnt(0) -- which also drains the next tile's prefetch.
+// The two halves of attn_bias_mask for callers that apply it to the 16 accumulator rows of a tile: FIRST all 16 table gathers (one
+// kernel-uniform `if (rel)` around the loop, the loads back to back), THEN the branch-free combine.  Calling attn_bias_mask per element
+// compiles to a branch + global load + `s_waitcnt vmcnt(0)` per element: 16 serialised L2 round trips per tile (~10k cycles beside
+// 8k cycles of MFMA on the temporal attentions), and each wait also drains the next tile's prefetch.
+__device__ __forceinline__ int attn_rel_index(int j, int E, int ns, int h, int qi, int qh) {
+    return max(0, min(qi - (j - E) + ns - 1, 2 * ns - 2)) * h + qh;
+}
+__device__ __forceinline__ float attn_bias_apply(float v, int j, int M, int E, int qi, int causal, bool hasRel, float rv, float nbv) {
+    const int jj = j - E;
+    const bool self = j >= E;
+    float b = (j == E - 1) ? nbv : 0.f;
+    b = (hasRel && self) ? rv : b;
+    const bool dead = j >= M || (causal && self && jj > qi);
+    return dead ? -INFINITY : v + b;
+}
+
 __device__ __forceinline__ float attn_bias_mask(float v, int j, int M, int E, int ns, int h, int qi, int qh, int causal,
                                                 const float* __restrict__ rel, float nbv) {
     const int jj = j - E;
@@ -123,21 +141,35 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
         const float* kp = Ks + l31 * ROW + 4 * hf;
+        // operand reads run one group ahead of their MFMAs (left alone hipcc issues each read right in front of its first use and
+        // waits: ~130 cycles of LDS latency per 4 MFMAs here, per 2 MFMAs in the P V loop below)
+        f32x4a ka = *reinterpret_cast<const f32x4a*>(kp);
 #pragma unroll
         for (int gq = 0; gq < D / 8; ++gq) {
-            const float4 a = *reinterpret_cast<const float4*>(kp + 8 * gq);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * gq], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * gq + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * gq + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * gq + 3], s, 0, 0, 0);
+            f32x4a kn = ka;
+            if (gq + 1 < D / 8) kn = *reinterpret_cast<const f32x4a*>(kp + 8 * (gq + 1));
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[0], qreg[4 * gq], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[1], qreg[4 * gq + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2], qreg[4 * gq + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[3], qreg[4 * gq + 3], s, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            ka = kn;
         }
         // ---- bias, mask, online softmax (per lane = per query; rows of s are keys) ----
         float tmax = -INFINITY;
         const bool plain = !causal && !rel && kbase + t * AKT >= E && kbase + (t + 1) * AKT <= M;     // every key of the tile is an unbiased self key
         if (!plain) {
+            float rv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rv[i] = 0.f;
+            if (rel) {                                     // kernel-uniform: 16 gathers in flight together
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rv[i] = rel[attn_rel_index(kbase + t * AKT + (i & 3) + 8 * (i >> 2) + 4 * hf, E, ns, h, qi, qh)];
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                s[i] = attn_bias_mask(s[i], kbase + t * AKT + (i & 3) + 8 * (i >> 2) + 4 * hf, M, E, ns, h, qi, qh, causal, rel, nbv);
+                s[i] = attn_bias_apply(s[i], kbase + t * AKT + (i & 3) + 8 * (i >> 2) + 4 * hf, M, E, qi, causal, rel != nullptr, rv[i], nbv);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
@@ -161,12 +193,24 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
                 for (int i = 0; i < 16; ++i) o[c][i] *= corr;
         }
         // ---- O^T += V^T P^T : step i uses the key pair held in register i of the two lane halves ----
+        {
+            float vc[ND], vn[ND];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = (i & 3) + 8 * (i >> 2) + 4 * hf;
-            const float* vp = Vs + key * ROW + l31;
+            for (int c = 0; c < ND; ++c) vc[c] = Vs[(4 * hf) * ROW + l31 + 32 * c];
 #pragma unroll
-            for (int c = 0; c < ND; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * c], s[i], o[c], 0, 0, 0);
+            for (int i = 0; i < 16; ++i) {
+                if (i + 1 < 16) {
+                    const float* vp = Vs + (((i + 1) & 3) + 8 * ((i + 1) >> 2) + 4 * hf) * ROW + l31;
+#pragma unroll
+                    for (int c = 0; c < ND; ++c) vn[c] = vp[32 * c];
+                }
+#pragma unroll
+                for (int c = 0; c < ND; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[c], s[i], o[c], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, ND, 0);
+#pragma unroll
+                for (int c = 0; c < ND; ++c) vc[c] = vn[c];
+            }
         }
         if (t + 1 < ntiles) store_tile((t + 1) & 1);       // that buffer was last read in tile t-1, retired by its barrier
         __syncthreads();
@@ -329,12 +373,24 @@ __global__ __launch_bounds__(512, 1) void mqa_flash_fwd_h_kernel(const float* __
         float tmax = -INFINITY;
         const bool plain = !causal && !rel && t * HKT >= E && (t + 1) * HKT <= M;
         if (!plain) {
+            float rv[2][16];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rv[kb][i] = 0.f;
+            if (rel) {                                     // kernel-uniform: 32 gathers in flight together
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        rv[kb][i] = rel[attn_rel_index(t * HKT + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf, E, ns, h, qi, qh)];
+            }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    sacc[kb][i] = attn_bias_mask(sacc[kb][i], t * HKT + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf, M, E, ns, h, qi, qh,
-                                                 causal, rel, nbv);
+                    sacc[kb][i] = attn_bias_apply(sacc[kb][i], t * HKT + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf, M, E, qi, causal,
+                                                  rel != nullptr, rv[kb][i], nbv);
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -589,24 +645,35 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_bwd_dq_kernel(const float* _
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
             const float* kp = Ks + l31 * ROW + 4 * hf;
             const float* vp4 = Vs + l31 * ROW + 4 * hf;
+            f32x4a ka = *reinterpret_cast<const f32x4a*>(kp), va = *reinterpret_cast<const f32x4a*>(vp4);      // reads one group ahead
 #pragma unroll
             for (int gq = 0; gq < D / 8; ++gq) {
-                const float4 a = *reinterpret_cast<const float4*>(kp + 8 * gq);
-                const float4 b = *reinterpret_cast<const float4*>(vp4 + 8 * gq);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * gq], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, doreg[4 * gq], dp, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * gq + 1], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, doreg[4 * gq + 1], dp, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * gq + 2], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, doreg[4 * gq + 2], dp, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * gq + 3], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, doreg[4 * gq + 3], dp, 0, 0, 0);
+                f32x4a kn = ka, vn4 = va;
+                if (gq + 1 < D / 8) {
+                    kn = *reinterpret_cast<const f32x4a*>(kp + 8 * (gq + 1));
+                    vn4 = *reinterpret_cast<const f32x4a*>(vp4 + 8 * (gq + 1));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qreg[4 * gq + e], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], doreg[4 * gq + e], dp, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                ka = kn; va = vn4;
             }
             // ---- P^T = exp(S^T + bias - L), dS^T = P^T (dP^T - delta); bias-gradient tables ----
+            float rv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rv[i] = 0.f;
+            if (rel) {                                     // kernel-uniform: 16 gathers in flight together
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rv[i] = rel[attn_rel_index(kbase + t * AKT + acc_row(i, hf), E, ns, h, qi, qh)];
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int j = kbase + t * AKT + acc_row(i, hf);
-                const float sv = attn_bias_mask(s[i], j, M, E, ns, h, qi, qh, causal, rel, nbv);
+                const float sv = attn_bias_apply(s[i], j, M, E, qi, causal, rel != nullptr, rv[i], nbv);
                 const float p = (sv == -INFINITY) ? 0.f : __expf(sv - L);
                 s[i] = rvalid ? p * (dp[i] - dl) : 0.f;
             }
@@ -628,11 +695,24 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_bwd_dq_kernel(const float* _
                 }
             }
             // ---- dQ^T += K^T dS^T : step i uses the key pair held in register i of the two lane halves ----
+            {
+                float kc[ND], kn2[ND];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float* kq = Ks + acc_row(i, hf) * ROW + l31;
+                for (int c = 0; c < ND; ++c) kc[c] = Ks[acc_row(0, hf) * ROW + l31 + 32 * c];
 #pragma unroll
-                for (int c = 0; c < ND; ++c) dqt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kq[32 * c], s[i], dqt[c], 0, 0, 0);
+                for (int i = 0; i < 16; ++i) {
+                    if (i + 1 < 16) {
+                        const float* kq = Ks + acc_row(i + 1, hf) * ROW + l31;
+#pragma unroll
+                        for (int c = 0; c < ND; ++c) kn2[c] = kq[32 * c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < ND; ++c) dqt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[c], s[i], dqt[c], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, ND, 0);
+#pragma unroll
+                    for (int c = 0; c < ND; ++c) kc[c] = kn2[c];
+                }
             }
             if (t + 1 < ntiles) store_tile((t + 1) & 1);
             __syncthreads();
@@ -708,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
                                                                    const float* __restrict__ rel, const float* __restrict__ null_bias,
                                                                    const float* __restrict__ dout, const float* __restrict__ lse,
                                                                    const float* __restrict__ delta, float* __restrict__ dkv, int n, int h,
-                                                                   int E, int ns, int causal, float scale, int KW) {
+                                                                   int E, int ns, int causal, float scale, int KW, int G) {
     constexpr int D = 32 * ND, ROW = D + 4, NPQ = 32 * D / 4 / 64;       // float4 pieces of a 32-row tile per lane
     extern __shared__ __attribute__((aligned(16))) float smem_dkv[];
     // XCD-aware block mapping: workgroups are dealt to the 8 XCDs round-robin by linear id.  All key-tile workgroups of a batch entry
@@ -723,8 +803,17 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
     const int M = E + ns, R = n * h;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hf = lane >> 5;
-    const int QW = 4 / KW;                                 // waves that share a key tile and split the query tiles
-    const int kt = bx * KW + wave % KW, qw = wave / KW;
+    // KW == 0: thousands of SHORT sequences (one key tile each: the temporal attentions, 8192 x 32 frames).  A workgroup per sequence is
+    // a latency chain -- K/V load, two query tiles per wave, a 48-KB combine through LDS, store, and the next workgroup's dispatch --
+    // that leaves the CU idle two thirds of the time at one workgroup per CU.  Instead every WAVE takes a sequence of its own and walks
+    // all its query tiles (next tile prefetched in registers): no combine, no barrier, four independent chains per CU.
+    const bool perWave = KW == 0;
+    if (perWave) {
+        g = g * 4 + wave;
+        if (g >= G) return;                                // (no barriers on this path)
+    }
+    const int QW = perWave ? 1 : 4 / KW;                   // waves that share a key tile and split the query tiles
+    const int kt = perWave ? bx : bx * KW + wave % KW, qw = perWave ? 0 : wave / KW;
     // a lone null key (E == 1) is taken by the VALU (below) instead of costing a 32-key tile of its own
     const int kbase = (E == 1) ? 1 : 0;
     const int j = kbase + kt * 32 + l31;                   // this lane's key (column)
@@ -833,54 +922,94 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
         f32x16 s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+        f32x4a qa = *reinterpret_cast<const f32x4a*>(qp), da = *reinterpret_cast<const f32x4a*>(dop);      // reads one group ahead
 #pragma unroll
         for (int gq = 0; gq < D / 8; ++gq) {
-            const float4 a = *reinterpret_cast<const float4*>(qp + 8 * gq);
-            const float4 b = *reinterpret_cast<const float4*>(dop + 8 * gq);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kreg[4 * gq], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, vreg[4 * gq], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kreg[4 * gq + 1], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, vreg[4 * gq + 1], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kreg[4 * gq + 2], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, vreg[4 * gq + 2], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kreg[4 * gq + 3], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, vreg[4 * gq + 3], dp, 0, 0, 0);
+            f32x4a qn = qa, dn = da;
+            if (gq + 1 < D / 8) {
+                qn = *reinterpret_cast<const f32x4a*>(qp + 8 * (gq + 1));
+                dn = *reinterpret_cast<const f32x4a*>(dop + 8 * (gq + 1));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kreg[4 * gq + e], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da[e], vreg[4 * gq + e], dp, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            qa = qn; da = dn;
         }
         // ---- P = exp(S + bias - L[row]), dS = P (dP - delta[row]) ----
+        // row statistics of the 16 accumulator rows: 4 vector reads each instead of a read + wait per row inside the loop below
+        float lrow[16], drow[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 lv = *reinterpret_cast<const float4*>(Ls + 8 * q4 + 4 * hf);
+            const float4 dv = *reinterpret_cast<const float4*>(Dls + 8 * q4 + 4 * hf);
+            lrow[4 * q4] = lv.x; lrow[4 * q4 + 1] = lv.y; lrow[4 * q4 + 2] = lv.z; lrow[4 * q4 + 3] = lv.w;
+            drow[4 * q4] = dv.x; drow[4 * q4 + 1] = dv.y; drow[4 * q4 + 2] = dv.z; drow[4 * q4 + 3] = dv.w;
+        }
         f32x16 ds;
         if (plain) {
             // no bias, no mask (the joint space-time attentions: 2048 tokens x 8 heads per batch entry): only ragged keys / rows die
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int row = acc_row(i, hf), rr = r0 + row;
-                const float p = (!jvalid || rr >= R) ? 0.f : __expf(s[i] - Ls[row]);
+                const int rr = r0 + acc_row(i, hf);
+                const float e = __expf(s[i] - lrow[i]);
+                const float p = (!jvalid || rr >= R) ? 0.f : e;
                 s[i] = p;
-                ds[i] = p * (dp[i] - Dls[row]);
+                ds[i] = p * (dp[i] - drow[i]);
             }
         } else {
+            int qis[16];
+            float rv[16], nbvs[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {                 // token, head of the row: shifts when h is a power of two (an integer
+                const int rcl = min(r0 + acc_row(i, hf), R - 1);                 // division costs ~2 MFMAs)
+                int qh;
+                if (hs >= 0) { qis[i] = rcl >> hs; qh = rcl & (h - 1); } else { qis[i] = rcl / h; qh = rcl - qis[i] * h; }
+                rv[i] = __int_as_float(qh);                // parked until the gathers below
+                nbvs[i] = 0.f;
+            }
+            if (null_bias) {                               // kernel-uniform
+#pragma unroll
+                for (int i = 0; i < 16; ++i) nbvs[i] = null_bias[__float_as_int(rv[i])];
+            }
+            if (rel) {                                     // kernel-uniform: 16 gathers in flight together
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rv[i] = rel[attn_rel_index(j, E, ns, h, qis[i], __float_as_int(rv[i]))];
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int row = acc_row(i, hf), rr = r0 + row;
-                const int rcl = min(rr, R - 1);
-                int qi, qh;                                    // token, head of the row: shifts when h is a power of two (an integer
-                if (hs >= 0) { qi = rcl >> hs; qh = rcl & (h - 1); } else { qi = rcl / h; qh = rcl - qi * h; }      // division costs ~2 MFMAs)
-                const float nbv = null_bias ? null_bias[qh] : 0.f;
-                const float sv = attn_bias_mask(s[i], j, M, E, ns, h, qi, qh, causal, rel, nbv);
-                const float p = (sv == -INFINITY || rr >= R) ? 0.f : __expf(sv - Ls[row]);
+                const int rr = r0 + acc_row(i, hf);
+                const float sv = attn_bias_apply(s[i], j, M, E, qis[i], causal, rel != nullptr, rv[i], nbvs[i]);
+                const float e = __expf(sv - lrow[i]);      // exp(-inf) = 0 for masked scores
+                const float p = (sv == -INFINITY || rr >= R) ? 0.f : e;
                 s[i] = p;
-                ds[i] = p * (dp[i] - Dls[row]);
+                ds[i] = p * (dp[i] - drow[i]);
             }
         }
         // ---- dV^T += dO^T P, dK^T += Q^T dS : step i contracts the query pair held in register i of the two lane halves ----
+        {
+            float oc[ND], qc[ND], on[ND], qn2[ND];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = acc_row(i, hf);
-            const float* dor = dOs + row * ROW + l31;
-            const float* qr = Qs + row * ROW + l31;
+            for (int c = 0; c < ND; ++c) { oc[c] = dOs[acc_row(0, hf) * ROW + l31 + 32 * c]; qc[c] = Qs[acc_row(0, hf) * ROW + l31 + 32 * c]; }
 #pragma unroll
-            for (int c = 0; c < ND; ++c) {
-                dvt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(dor[32 * c], s[i], dvt[c], 0, 0, 0);
-                dkt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[32 * c], ds[i], dkt[c], 0, 0, 0);
+            for (int i = 0; i < 16; ++i) {
+                if (i + 1 < 16) {
+                    const int row = acc_row(i + 1, hf);
+#pragma unroll
+                    for (int c = 0; c < ND; ++c) { on[c] = dOs[row * ROW + l31 + 32 * c]; qn2[c] = Qs[row * ROW + l31 + 32 * c]; }
+                }
+#pragma unroll
+                for (int c = 0; c < ND; ++c) {
+                    dvt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(oc[c], s[i], dvt[c], 0, 0, 0);
+                    dkt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[c], ds[i], dkt[c], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * ND, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * ND, 0);
+#pragma unroll
+                for (int c = 0; c < ND; ++c) { oc[c] = on[c]; qc[c] = qn2[c]; }
             }
         }
         }
@@ -997,18 +1126,21 @@ extern "C" int diqt_mqa_attention_bwd(const float* q, const float* kv, const flo
         // G = 8) need the finer split to fill 256 CUs: every workgroup walks ALL query rows of its batch entry.
         int KW = Mt <= 32 ? 1 : (Mt <= 64 ? 2 : 4);
         while (KW > 1 && (long long)((Mt + 32 * KW - 1) / (32 * KW)) * G < 512) KW >>= 1;
-        const int nkt = Mt > 0 ? (Mt + 32 * KW - 1) / (32 * KW) : 1;
-        const dim3 grid((unsigned)nkt, G);
+        static const bool noPerWave = [] { const char* e = getenv("DIQT_ATTN_NO_PERWAVE"); return e && e[0] == '1'; }();
+        const bool perWave = !noPerWave && Mt <= 32 && G >= 2048;      // one sequence per wave (see the kernel)
+        if (perWave) KW = 0;
+        const int nkt = perWave ? 1 : (Mt > 0 ? (Mt + 32 * KW - 1) / (32 * KW) : 1);
+        const dim3 grid((unsigned)nkt, perWave ? (unsigned)((G + 3) / 4) : (unsigned)G);
         const int ROW = d + 4;
         size_t lds = (size_t)4 * (2 * 32 * ROW + 128) * sizeof(float);
-        const size_t red = (size_t)(4 - KW) * (2 * (d / 32) * 16 * 64 + 128) * sizeof(float);
+        const size_t red = (size_t)(perWave ? 0 : 4 - KW) * (2 * (d / 32) * 16 * 64 + 128) * sizeof(float);
         if (red > lds) lds = red;
         auto kern = d == 64 ? mqa_flash_bwd_dkv_kernel<2> : mqa_flash_bwd_dkv_kernel<1>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "mqa_attention_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, kv, rel, null_bias, dout, lse, delta, dkv, n, h, n_extra, n_self, causal, scale, KW);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, kv, rel, null_bias, dout, lse, delta, dkv, n, h, n_extra, n_self, causal, scale, KW, G);
         return check_launch("mqa_attention_bwd(dkv)");
     }
 }

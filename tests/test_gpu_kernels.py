@@ -534,6 +534,8 @@ def _mqa_ref(q, kv, rel, nb, n, h, d, E, causal, scale):
     (1, 150, 2, 32, 3, False, False),    # context tokens in front of the null key (E = 3): all keys through the tile loop; > 128 keys
     (2, 16, 8, 64, 2, True, True),       # E = 2 with bias and mask
     (300, 8, 2, 32, 1, True, True),      # more batch entries than resident workgroups: the persistent walk of the dQ kernel
+    (2051, 12, 2, 32, 1, True, True),    # thousands of short sequences: the dK/dV kernel gives every WAVE a sequence (ragged last workgroup)
+    (2048, 20, 4, 64, 1, False, False),  # ... dim_head 64, no bias / mask
     (1, 1, 8, 64, 1, True, True)])
 def test_fused_mqa_attention_backward(ops, G, n, h, d, E, use_rel, causal):
     """diqt_mqa_attention_fwd_lse / diqt_mqa_attention_bwd (flash-style: no stored scores) against float64 autograd of the

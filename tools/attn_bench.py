@@ -13,6 +13,8 @@ SHAPES = [  # name, G, n, h, d, E, rel, causal
     ("temporal full-res 64 frames, B=2", 8192, 64, 8, 64, 1, True, True),
     ("temporal full-res 32 frames, B=8", 8192, 32, 8, 64, 1, True, True),
     ("spatial 16x16 per frame, B=2 x 64", 128, 256, 8, 64, 1, False, False),
+    ("temporal 32 frames, no bias, causal", 8192, 32, 8, 64, 1, False, True),          # 5, 6: what the bias table / the mask cost
+    ("temporal 32 frames, no bias, no mask", 8192, 32, 8, 64, 1, False, False),
 ]
 if os.environ.get('ONLY'):
     SHAPES = [SHAPES[int(os.environ['ONLY'])]]

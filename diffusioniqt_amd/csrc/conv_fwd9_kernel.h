@@ -42,16 +42,19 @@ __device__ __forceinline__ void f9_dma(__amdgpu_buffer_rsrc_t rs, unsigned lds, 
 
 // Mish / SiLU derivative for the GroupNorm-backward epilogue (same expressions as act_grad in common.h, without its other cases:
 // the call sits in a 128-fold unrolled store loop)
+// Hardware reciprocals (v_rcp_f32, 1 ulp) instead of IEEE divisions: a division is ~10 instructions, and this runs 256 times per lane
+// and tile on a wave that has nothing else to issue.
 __device__ __forceinline__ float f9_act_grad(float x, int act) {
     if (act == DIQT_ACT_MISH) {
-        if (x > 20.f) return 1.f;
-        const float n = __expf(x);
+        const float xc = fminf(x, 20.f);                   // e^x (e^x + 2) stays finite; the derivative is 1 to fp32 precision beyond
+        const float n = __expf(xc);
         const float m = n * (n + 2.f);
-        const float t = m / (m + 2.f);
-        const float sg = n / (1.f + n);
-        return t + x * sg * (1.f - t * t);
+        const float t = m * __builtin_amdgcn_rcpf(m + 2.f);
+        const float sg = n * __builtin_amdgcn_rcpf(1.f + n);
+        const float r = t + xc * sg * (1.f - t * t);
+        return x > 20.f ? 1.f : r;
     }
-    const float s = 1.f / (1.f + __expf(-x));
+    const float s = __builtin_amdgcn_rcpf(1.f + __expf(-x));
     return s * (1.f + x * (1.f - s));
 }
 
@@ -66,8 +69,8 @@ __device__ __forceinline__ void f9_step_end(int n) {
 #undef F9_WB
 }
 
-// GNB: the GroupNorm-backward epilogue (F9Geom::gx).  A separate instantiation: with the epilogue's 64 extra live registers and
-// branches compiled into the plain kernel its main loop lost 10 % (448 vs 405 us on the dominant launch).
+// GNB: the GroupNorm-backward epilogue (F9Geom::gx).  A separate instantiation: behind a runtime flag in the plain kernel it cost the
+// forward launches 10 % (448 vs 405 us on the dominant one); the epilogue itself is 8.6k instructions per tile (activation derivative).
 template <class C, bool GNB>
 __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias, const float* __restrict__ residual,

@@ -1768,9 +1768,9 @@ extern "C" int diqt_conv3d_fwd_ex(const float* x, const float* packed, const flo
 extern "C" int diqt_conv3d_fwd_gnbwd_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                                             int epd, int eph, int epw) {
     // Opt-in (DIQT_GNBWD_FUSE=1; the test suite sets it): the epilogue saves the GroupNorm backward's reduction pass (35 us and 134 MB per
-    // GroupNorm at the 32^3 level) but the instantiation that carries it runs its main loop ~8 % slower than the plain kernel
-    // (hipcc's register allocation of the 1728-MFMA loop changes with the epilogue), which cancels the gain: 42.1-42.3 ms per training
-    // micro-step either way, A/B on one box.
+    // GroupNorm at the 32^3 level) but costs the launch as much: the activation derivative per output element (exp + two reciprocals at
+    // quarter rate) is ~8.6k instructions per tile on a kernel with one wave per SIMD and nothing to overlap them with.  42.1-42.3 ms
+    // per training micro-step either way, A/B on one box.
     static const bool off = [] { const char* e = getenv("DIQT_GNBWD_FUSE"); return !(e && e[0] == '1'); }();
     F9Geom g9;
     size_t l9;

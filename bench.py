@@ -311,6 +311,9 @@ def bench_c5(args, torch, ops, device, world, timed, instrumented, roofline_of):
 
 # ---------------------------------------------------------------------------------------------------------------------------
 def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented, roofline_of, sync_all):
+    # the side lines (API sampling, autocast, EDM, Unet3D, bf16 trainer) are single-GPU information: a multi-rank run measures the
+    # headline loops (sampler step, training micro-step + gradient all-reduce) only -- less to go wrong in lockstep
+    extras = not args.no_extras and world == 1
     from diffusioniqt_amd.imagen_pytorch3D import SRUnet256, Imagen, NullUnet
     from diffusioniqt_amd.trainer import ImagenTrainer
     B, S = args.batch or 8, args.size
@@ -396,7 +399,7 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
             roof["traffic"] = pmc_traffic(roof["kernel"], B, S)
             roof["traffic_note"] = "HBM bytes per average launch from the committed rocprofv3 --pmc passes of this command (profiles/), not re-measured in this run"
 
-    if args.mode in ("sample", "both") and not args.no_extras:
+    if args.mode in ("sample", "both") and extras:
         # the same sampling through the reference's own call, trainer.sample (EMA swap, per-step host lists): a check that the
         # hand-rolled loop above is what the API delivers
         lr_api = lr.clone()
@@ -428,7 +431,7 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
                              patch_steps_per_s=world * B * n_edm / dt, patch_evals_per_s=world * B * (2 * n_edm - 1) / dt)
 
     # ---------------- Family B: Unet3D + ElucidatedImagen.sample — the pairing BASELINE.json's metric names ----
-    if args.mode == "both" and not args.no_extras:
+    if args.mode == "both" and extras:
         from diffusioniqt_amd.imagen_video import Unet3D
         from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
         torch.manual_seed(43)
@@ -489,7 +492,7 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
             result["train_roofline"] = tr
         if world > 1:
             ddp = ddp_stats(torch, dist, ops, trainer, train_step, sync_all, device, world)
-        if not args.no_extras:
+        if extras:
             # the same micro-steps with ImagenTrainer's mixed-precision switch (precision='bf16', trainer.py:293-311)
             trainer.mixed_precision = 'bf16'
             dtb = timed(train_step, 4, kt)

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_bwd_dq_kernel(const float* _
                             if (j >= E && j < M) {
                                 if (rel) {
                                     const int idx = max(0, min(qi - (j - E) + ns - 1, 2 * ns - 2));
-                                    tbl[idx * h + qh] += s[i];          // masked entries carry dS = 0
+                                    tbl[idx * h + qh] += s[i];          // masked entries carry dS = 0 (an LDS atomic add here is slower: 1010 vs 855 us)
                                 }
                             } else if (j == E - 1 && null_bias) dnb += s[i];
                         }
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
                                                                    const float* __restrict__ rel, const float* __restrict__ null_bias,
                                                                    const float* __restrict__ dout, const float* __restrict__ lse,
                                                                    const float* __restrict__ delta, float* __restrict__ dkv, int n, int h,
-                                                                   int E, int ns, int causal, float scale, int KW, int G) {
+                                                                   int E, int ns, int causal, float scale, int KW, int G, int relLds) {
     constexpr int D = 32 * ND, ROW = D + 4, NPQ = 32 * D / 4 / 64;       // float4 pieces of a 32-row tile per lane
     extern __shared__ __attribute__((aligned(16))) float smem_dkv[];
     // XCD-aware block mapping: workgroups are dealt to the 8 XCDs round-robin by linear id.  All key-tile workgroups of a batch entry
@@ -808,9 +808,20 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
     // that leaves the CU idle two thirds of the time at one workgroup per CU.  Instead every WAVE takes a sequence of its own and walks
     // all its query tiles (next tile prefetched in registers): no combine, no barrier, four independent chains per CU.
     const bool perWave = KW == 0;
+    // The bias tables -- rel[(2 ns - 1) x h] and null_bias[h] -- are gathered 16 times per lane and tile.  Global loads inside the tile
+    // loop queue BEHIND the next tile's prefetch and their `s_waitcnt vmcnt` waits for it too (loads retire in order), so short tables
+    // (relLds floats reserved by the host behind the staging regions) are copied to LDS once and read with ds_read.
+    float* const Rs = smem_dkv + (size_t)4 * (2 * 32 * ROW + 128 + 2 * D);
+    float* const NBs = Rs + relLds;
+    const bool tblLds = relLds > 0;
+    if (tblLds) {
+        for (int e = threadIdx.x; e < relLds; e += 256) Rs[e] = rel[e];
+        if (null_bias && threadIdx.x < h) NBs[threadIdx.x] = null_bias[threadIdx.x];
+        __syncthreads();
+    }
     if (perWave) {
         g = g * 4 + wave;
-        if (g >= G) return;                                // (no barriers on this path)
+        if (g >= G) return;                                // (no barriers behind this point on this path)
     }
     const int QW = perWave ? 1 : 4 / KW;                   // waves that share a key tile and split the query tiles
     const int kt = perWave ? bx : bx * KW + wave % KW, qw = perWave ? 0 : wave / KW;
@@ -820,7 +831,7 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
     const bool jvalid = j < M;
     const int jc = jvalid ? j : M - 1;
     const float* kvg = kv + ((size_t)g * M + jc) * 2 * D;
-    float* Qs = smem_dkv + (size_t)wave * (2 * 32 * ROW + 128);      // wave-private: Q tile, dO tile, lse, delta, p0, ds0 of 32 query rows
+    float* Qs = smem_dkv + (size_t)wave * (2 * 32 * ROW + 128 + 2 * D);      // wave-private: Q tile, dO tile, lse, delta, p0, ds0 of 32 query rows, null k | v
     float* dOs = Qs + 32 * ROW;
     float* Ls = dOs + 32 * ROW;
     float* Dls = Ls + 32;
@@ -843,6 +854,13 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
         for (int i = 0; i < 16; ++i) { dkt[c][i] = 0.f; dvt[c][i] = 0.f; }
     const bool doNull = kbase && kt == 0;                  // wave-uniform: the waves of key tile 0 also own the null key row
     const float* kv0 = kv + (size_t)g * M * 2 * D;         // the null key / value row
+    // ... kept in the wave's LDS region: read from global memory inside the tile loop its loads queue BEHIND the next tile's prefetch,
+    // and the `s_waitcnt vmcnt(0)` in front of their first use waits for that prefetch too (the temporal attentions, where every wave
+    // owns the null key: 714 -> 505 us of this kernel were that wait and the scalar column sums below)
+    float* K0s = Qs + 2 * 32 * ROW + 128;
+    if (doNull) {
+        for (int e = lane; e < 2 * D; e += 64) K0s[e] = kv0[e];
+    }
     float dkn = 0.f, dvn = 0.f;                            // d k_null[lane], d v_null[lane] (lane = head-dim index, lanes < D)
 
     const int nqt = (R + 31) / 32;
@@ -897,23 +915,26 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
             for (int gq = 0; gq < D / 8; ++gq) {
                 const float4 a = *reinterpret_cast<const float4*>(qp + 8 * gq);
                 const float4 b = *reinterpret_cast<const float4*>(dop + 8 * gq);
-                const float4 kk = *reinterpret_cast<const float4*>(kv0 + 8 * gq + 4 * hf);
-                const float4 vv = *reinterpret_cast<const float4*>(kv0 + D + 8 * gq + 4 * hf);
+                const float4 kk = *reinterpret_cast<const float4*>(K0s + 8 * gq + 4 * hf);
+                const float4 vv = *reinterpret_cast<const float4*>(K0s + D + 8 * gq + 4 * hf);
                 s0 = fmaf(a.x, kk.x, s0); s0 = fmaf(a.y, kk.y, s0); s0 = fmaf(a.z, kk.z, s0); s0 = fmaf(a.w, kk.w, s0);
                 dp0 = fmaf(b.x, vv.x, dp0); dp0 = fmaf(b.y, vv.y, dp0); dp0 = fmaf(b.z, vv.z, dp0); dp0 = fmaf(b.w, vv.w, dp0);
             }
             s0 += __shfl_xor(s0, 32, 64);
             dp0 += __shfl_xor(dp0, 32, 64);
             const int rr = r0 + l31;
-            const float nbv0 = null_bias ? null_bias[min(rr, R - 1) % h] : 0.f;
+            const float nbv0 = null_bias ? (tblLds ? NBs[min(rr, R - 1) % h] : null_bias[min(rr, R - 1) % h]) : 0.f;
             const float p0 = rr < R ? __expf(s0 * scale + nbv0 - Ls[l31]) : 0.f;
-            if (hf == 0) { P0s[l31] = p0; dS0s[l31] = p0 * (dp0 - Dls[l31]); }
-            // lane = head-dim index: column sums over the 32 rows
+            const float ds0 = p0 * (dp0 - Dls[l31]);
+            // lane = head-dim index: column sums over the 32 rows.  p0 / ds0 of row rq live in lane rq: broadcast through a scalar
+            // register (v_readlane) instead of an LDS round trip per row; the 64 operand reads of the unrolled loop pipeline freely.
             if (lane < D) {
-#pragma unroll 8
+#pragma unroll
                 for (int rq = 0; rq < 32; ++rq) {
-                    dvn = fmaf(P0s[rq], dOs[rq * ROW + lane], dvn);
-                    dkn = fmaf(dS0s[rq], Qs[rq * ROW + lane], dkn);
+                    const float pb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p0), rq));
+                    const float db = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ds0), rq));
+                    dvn = fmaf(pb, dOs[rq * ROW + lane], dvn);
+                    dkn = fmaf(db, Qs[rq * ROW + lane], dkn);
                 }
             }
         }
@@ -971,13 +992,22 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
                 rv[i] = __int_as_float(qh);                // parked until the gathers below
                 nbvs[i] = 0.f;
             }
-            if (null_bias) {                               // kernel-uniform
+            if (tblLds) {                                  // kernel-uniform: tables in LDS
+                if (null_bias) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) nbvs[i] = null_bias[__float_as_int(rv[i])];
-            }
-            if (rel) {                                     // kernel-uniform: 16 gathers in flight together
+                    for (int i = 0; i < 16; ++i) nbvs[i] = NBs[__float_as_int(rv[i])];
+                }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) rv[i] = rel[attn_rel_index(j, E, ns, h, qis[i], __float_as_int(rv[i]))];
+                for (int i = 0; i < 16; ++i) rv[i] = Rs[attn_rel_index(j, E, ns, h, qis[i], __float_as_int(rv[i]))];
+            } else {
+                if (null_bias) {                           // kernel-uniform
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) nbvs[i] = null_bias[__float_as_int(rv[i])];
+                }
+                if (rel) {                                 // kernel-uniform: 16 gathers in flight together
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) rv[i] = rel[attn_rel_index(j, E, ns, h, qis[i], __float_as_int(rv[i]))];
+                }
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -1132,15 +1162,17 @@ extern "C" int diqt_mqa_attention_bwd(const float* q, const float* kv, const flo
         const int nkt = perWave ? 1 : (Mt > 0 ? (Mt + 32 * KW - 1) / (32 * KW) : 1);
         const dim3 grid((unsigned)nkt, perWave ? (unsigned)((G + 3) / 4) : (unsigned)G);
         const int ROW = d + 4;
-        size_t lds = (size_t)4 * (2 * 32 * ROW + 128) * sizeof(float);
+        size_t lds = (size_t)4 * (2 * 32 * ROW + 128 + 2 * d) * sizeof(float);
+        const int relLds = (rel && h <= 64 && (2 * n_self - 1) * h <= 4096) ? (2 * n_self - 1) * h : 0;      // bias tables in LDS (<= 16 KB)
         const size_t red = (size_t)(perWave ? 0 : 4 - KW) * (2 * (d / 32) * 16 * 64 + 128) * sizeof(float);
-        if (red > lds) lds = red;
+        DIQT_REQUIRE(red <= lds, DIQT_E_UNSUPPORTED, "mqa_attention_bwd: combine region larger than the staging regions");
+        lds += (size_t)(relLds + 64) * sizeof(float);          // bias tables behind the staging regions
         auto kern = d == 64 ? mqa_flash_bwd_dkv_kernel<2> : mqa_flash_bwd_dkv_kernel<1>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "mqa_attention_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, kv, rel, null_bias, dout, lse, delta, dkv, n, h, n_extra, n_self, causal, scale, KW, G);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, kv, rel, null_bias, dout, lse, delta, dkv, n, h, n_extra, n_self, causal, scale, KW, G, relLds);
         return check_launch("mqa_attention_bwd(dkv)");
     }
 }

@@ -326,14 +326,20 @@ __global__ __launch_bounds__(256, CKT == 16 ? 3 : 2) void conv_fwd_kernel(const 
         const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
         const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
         float cs0 = 0.f, cq0 = 0.f, cs1 = 0.f, cq1 = 0.f;      // column sums for the consumer's GroupNorm / SE pooling
+        float rr0[16], rr1[16];
+        if (residual) {            // wave-uniform: all 32 loads in flight before the first add
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned off = (unsigned)out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                rr0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+                rr1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const unsigned off = (unsigned)out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
             float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-            if (residual) {        // wave-uniform
-                v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
-                v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
-            }
+            if (residual) { v0 += rr0[r]; v1 += rr1[r]; }
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
             if (g.stats && off != BUF_OOB) { cs0 += v0; cq0 = fmaf(v0, v0, cq0); cs1 += v1; cq1 = fmaf(v1, v1, cq1); }
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd8_kernel(const float* __restri
         for (int r = 0; r < 16; ++r) {
             const unsigned off = (unsigned)out_off[slot * F8_MT + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
             float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-            if (residual) {        // wave-uniform
+            if (residual) {        // wave-uniform (kept per element: batching the 32 loads costs this kernel's main loop 4 %)
                 v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
                 v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
             }
@@ -739,15 +745,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_fwd_kernel(const float* __rest
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
     const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
     const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : BUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : BUF_OOB_C;
+    // residual: all 32 loads in flight before the first add (a load + wait + add per element serialises 16 L2 round trips)
+    float rr0[16], rr1[16];
+    if (residual) {            // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = r0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned off = row < rows ? (unsigned)(row * g.Cout * 4) : BUF_OOB;
+            rr0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+            rr1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const long long row = r0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const unsigned off = row < rows ? (unsigned)(row * g.Cout * 4) : BUF_OOB;
         float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-        if (residual) {        // wave-uniform
-            v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
-            v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
-        }
+        if (residual) { v0 += rr0[r]; v1 += rr1[r]; }
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
     }

@@ -113,15 +113,22 @@ __global__ __launch_bounds__(256, 1) void conv1x1_k64_kernel(const float* __rest
             const float bias0 = (bias && co0 < Cout) ? bias[co0] : 0.f;
             const float bias1 = (bias && co1 < Cout) ? bias[co1] : 0.f;
             const unsigned c0 = co0 < Cout ? (unsigned)co0 * 4u : PW_OOB_C, c1 = co1 < Cout ? (unsigned)co1 * 4u : PW_OOB_C;
+            float rr0[16], rr1[16];
+            if (residual) {            // kernel-uniform: all 32 loads in flight before the first add
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = r0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const unsigned off = row < rows ? (unsigned)(row * Cout * 4) : PW_OOB;
+                    rr0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+                    rr1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long row = r0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const unsigned off = row < rows ? (unsigned)(row * Cout * 4) : PW_OOB;
                 float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-                if (residual) {        // kernel-uniform
-                    v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
-                    v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
-                }
+                if (residual) { v0 += rr0[r]; v1 += rr1[r]; }
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
             }

@@ -303,15 +303,23 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
     const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
     const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : HBUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : HBUF_OOB_C;
+    // residual: all 32 loads in flight before the first add (a load + wait + add per element serialises 16 L2 round trips; the
+    // pseudo-3D blocks under autocast pass their `+ res` here)
+    float rr0[16], rr1[16];
+    if (residual) {            // kernel-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned off = (unsigned)out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+            rr0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+            rr1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const unsigned off = (unsigned)out_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
         float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
         if (g.roundOut) { v0 = round_through<BF>(v0); v1 = round_through<BF>(v1); }
-        if (residual) {
-            v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
-            v1 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
-        }
+        if (residual) { v0 += rr0[r]; v1 += rr1[r]; }
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
     }

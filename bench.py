@@ -142,6 +142,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.rehearse))
 
+    if os.environ.get("DIQT_BENCH_WATCHDOG"):              # diagnostic: dump every thread's stack and exit if this rank is still running
+        import faulthandler                                # after that many seconds (a hung collective shows where each rank stands)
+        faulthandler.dump_traceback_later(int(os.environ["DIQT_BENCH_WATCHDOG"]), exit=True)
     import torch
     import torch.distributed as dist
     from diffusioniqt_amd import distributed as D, ops, _lib

@@ -11,10 +11,14 @@ xGMI is point-to-point (7 links per GPU), so few, large buckets are used: the 54
 gradients go out as ~25 MB buckets (first bucket 1 MB so the first collective starts early).
 """
 import os
+import sys
 from typing import List
 
 import torch
 import torch.distributed as dist
+
+
+_TRACE = os.environ.get("DIQT_DDP_TRACE") == "1"      # diagnostic: every collective of the gradient reducer on stderr
 
 
 def env_world():
@@ -189,6 +193,8 @@ class BucketedGradReducer:
         self.arena.collect(only)
         buf = self.arena.grad[lo:hi]
         native_avg = dist.get_backend(self.pg) == "nccl"        # RCCL averages in the collective; gloo sums, divided after the wait
+        if _TRACE:
+            print(f"[ddp rank {dist.get_rank()}] launch bucket {b} [{lo}:{hi}] params {len(only)} handles {len(self._handles)}", file=sys.stderr, flush=True)
         h = dist.all_reduce(buf, op=dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._launched.add(b)
         self._handles.append((h, buf, native_avg))
@@ -219,7 +225,9 @@ class BucketedGradReducer:
             self.used |= set(stragglers)
 
     def _wait(self):
-        for h, buf, native_avg in self._handles:
+        for k, (h, buf, native_avg) in enumerate(self._handles):
+            if _TRACE:
+                print(f"[ddp rank {dist.get_rank()}] wait {k} of {len(self._handles)}", file=sys.stderr, flush=True)
             h.wait()
             if not native_avg:
                 buf.div_(self.world)

@@ -89,13 +89,16 @@ def _reducer_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_bucketed_reducer_world2_gloo():
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_reducer_world2_gloo(world):
+    """Bucketed all-reduce from the gradient hooks, a no_sync micro-step in between, unused parameters, replicas synchronised from
+    rank 0 -- at 2 and at 4 ranks (power-of-two worlds take gloo's other reduction schedule)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    results = [q.get(timeout=120) for _ in range(2)]
+    results = [q.get(timeout=120) for _ in range(world)]
     [p.join(60) for p in procs]
     for r in results:
         assert all(r[1:]), r

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "diqt_gn_act_bwd": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_gn_act_bwd_from_partials": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_conv3d_fwd_gnbwd_blocks": (I, [I] * 15),
+    "diqt_get_gnbwd_fuse": (I, []),
+    "diqt_set_gnbwd_fuse": (I, [I]),
     "diqt_conv3d_fwd_gnbwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I] + [I] * 15 + [P]),
     "diqt_chan_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "diqt_chan_layernorm_fwd_res": (I, [P, P, P, P, P, P, P, I, I, F, P]),

@@ -26,6 +26,7 @@
 #include "conv_fwd9.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <atomic>
 
 namespace diqt {
 
@@ -1779,13 +1780,30 @@ extern "C" int diqt_conv3d_fwd_ex(const float* x, const float* packed, const flo
 // input gn_x at the same voxels and writes the per-tile partial sums of the GroupNorm backward (sum dz, sum dz xhat per channel):
 // partials[B][nblk][2][Cout], nblk = diqt_conv3d_fwd_gnbwd_blocks(...) (0: this shape does not run on conv_fwd9_kernel un-split; use
 // diqt_conv3d_fwd + diqt_gn_act_bwd).  diqt_gn_act_bwd_from_partials finishes the GroupNorm backward without its reduction pass.
+// Process-wide switch of that fusion: -1 = not set yet (the first query reads DIQT_GNBWD_FUSE, default off), 0 / 1 = set by the caller.
+// Both modes are product paths (the parity suite runs the whole-network gradient tests in each, tests/test_gpu_fullsize.py).
+static std::atomic<int> g_gnbwd_fuse{-1};
+extern "C" int diqt_get_gnbwd_fuse(void) {
+    int v = g_gnbwd_fuse.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("DIQT_GNBWD_FUSE");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_gnbwd_fuse.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+extern "C" int diqt_set_gnbwd_fuse(int on) {
+    const int prev = diqt_get_gnbwd_fuse();
+    g_gnbwd_fuse.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
 extern "C" int diqt_conv3d_fwd_gnbwd_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                                             int epd, int eph, int epw) {
-    // Opt-in (DIQT_GNBWD_FUSE=1; the test suite sets it): the epilogue saves the GroupNorm backward's reduction pass (35 us and 134 MB per
+    // Opt-in (DIQT_GNBWD_FUSE=1 or diqt_set_gnbwd_fuse(1)): the epilogue saves the GroupNorm backward's reduction pass (35 us and 134 MB per
     // GroupNorm at the 32^3 level) but costs the launch as much: the activation derivative per output element (exp + two reciprocals at
     // quarter rate) is ~8.6k instructions per tile on a kernel with one wave per SIMD and nothing to overlap them with.  42.1-42.3 ms
     // per training micro-step either way, A/B on one box.
-    static const bool off = [] { const char* e = getenv("DIQT_GNBWD_FUSE"); return !(e && e[0] == '1'); }();
+    const bool off = !diqt_get_gnbwd_fuse();
     F9Geom g9;
     size_t l9;
     unsigned gr9;

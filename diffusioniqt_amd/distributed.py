@@ -76,6 +76,7 @@ class FlatArena:
             off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
         self.numel = off
         self._collected = set()
+        self.touched = set()                 # indices of parameters that have ever handed over a gradient (Adam's lazy state)
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev) if with_grad else None
         with torch.no_grad():
@@ -109,6 +110,7 @@ class FlatArena:
             if g is not None and g.data_ptr() != view.data_ptr():
                 srcs.append(g.detach().contiguous().view(-1))
                 offs.append(o)
+                self.touched.add(i)
             p.grad = view
             done.append(i)
         self._collected.update(done)

@@ -4,6 +4,8 @@ PyTorch supplies device memory, streams and the autograd tape; all arithmetic ru
 of ``csrc/``.  Activations are fp32 channels-last: ``x[B, D, H, W, C]`` (or ``[rows, C]``).
 There is no CPU fallback: a non-CUDA tensor raises.
 """
+import contextlib
+
 import torch
 from torch.autograd import Function
 
@@ -17,6 +19,22 @@ _WEIGHT_EPOCH = 0     # bumped by the fused optimiser (it writes parameters thro
 def bump_weight_epoch():
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
+
+
+def set_gnbwd_fuse(on: bool) -> bool:
+    """Switches the GroupNorm-backward reduction between its own pass (False, the default) and the epilogue of the conv's
+    backward-data launch (True; ``diqt_conv3d_fwd_gnbwd``).  Returns the previous setting.  Both are product paths and the parity
+    suite runs whole-network gradients in each."""
+    return bool(_lib.query("diqt_set_gnbwd_fuse", int(bool(on))))
+
+
+@contextlib.contextmanager
+def gnbwd_fuse(on: bool):
+    prev = set_gnbwd_fuse(on)
+    try:
+        yield
+    finally:
+        set_gnbwd_fuse(prev)
 
 
 # --------------------------------------------------------------------------------------------

@@ -19,7 +19,6 @@ from collections.abc import Iterable
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch import nn
 from torch.utils.data import DataLoader, random_split
 
@@ -28,9 +27,11 @@ from . import distributed as D
 from .imagen_pytorch3D import Imagen, NullUnet
 from .utils_mine import convertVolume2subVolume, merge_sub_volumes
 from .metrics import SSIM, PSNR
-from . import __version__
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+# the checkpoint dictionary follows the layout of the reference at its version.py:1 ('1.20.1'); that string goes into the
+# ``version`` entry so that either trainer loads the other's files without the version notice (trainer.py:833, 896-897)
+CHECKPOINT_VERSION = '1.20.1'
 
 
 def exists(val):
@@ -100,30 +101,28 @@ def cast_torch_tensor(fn, cast_fp16=False):
     return inner
 
 
-def split(t, split_size=None):
-    if not exists(split_size):
-        return t
-    if isinstance(t, torch.Tensor):
-        return t.split(split_size, dim=0)
-    if isinstance(t, Iterable):
-        return [t[i * split_size:(i + 1) * split_size] for i in range(ceil(len(t) / split_size))]
-    return TypeError
+def _cut(value, size, n_chunks):
+    """One share per gradient-accumulation chunk: tensors and sequences are cut along the batch, anything else is repeated."""
+    if isinstance(value, torch.Tensor):
+        return value.split(size, dim=0)
+    if isinstance(value, (list, tuple)):
+        return [value[s:s + size] for s in range(0, len(value), size)]
+    return [value] * n_chunks
 
 
 def split_args_and_kwargs(*args, split_size=None, **kwargs):
-    """trainer.py:176-197: gradient-accumulation chunks, each with its share of the batch."""
-    all_args = (*args, *kwargs.values())
-    first_tensor = next((t for t in all_args if isinstance(t, torch.Tensor)), None)
-    assert exists(first_tensor)
-    batch_size = len(first_tensor)
-    split_size = default(split_size, batch_size)
-    num_chunks = ceil(batch_size / split_size)
-    keys = list(kwargs.keys())
-    split_index = len(all_args) - len(keys)
-    split_all = [split(a, split_size=split_size) if exists(a) and isinstance(a, (torch.Tensor, Iterable)) and not isinstance(a, str)
-                 else ((a,) * num_chunks) for a in all_args]
-    for chunk_size, *chunked in zip(num_to_groups(batch_size, split_size), *split_all):
-        yield chunk_size / batch_size, (tuple(chunked[:split_index]), dict(zip(keys, chunked[split_index:])))
+    """Gradient-accumulation chunks of a call (the reference's generator of the same name, trainer.py:176-197): yields
+    ``(share of the batch, (args, kwargs))`` per chunk of at most ``split_size`` samples; the batch size is that of the first
+    tensor argument."""
+    values = list(args) + list(kwargs.values())
+    batch = next((len(v) for v in values if isinstance(v, torch.Tensor)), None)
+    assert batch is not None, 'split_args_and_kwargs needs at least one tensor argument'
+    size = batch if split_size is None else split_size
+    starts = range(0, batch, size)
+    columns = [_cut(v, size, len(starts)) for v in values]
+    for c, start in enumerate(starts):
+        piece = [col[c] for col in columns]
+        yield min(size, batch - start) / batch, (tuple(piece[:len(args)]), dict(zip(kwargs, piece[len(args):])))
 
 
 def imagen_sample_in_chunks(fn):
@@ -143,14 +142,15 @@ def imagen_sample_in_chunks(fn):
 
 
 def restore_parts(state_dict_target, state_dict_from):
-    """trainer.py:222-233: partial load on shape mismatch."""
-    for name, param in state_dict_from.items():
-        if name not in state_dict_target:
+    """Partial load (trainer.py:222-233): every entry whose name AND shape match is copied, mismatching shapes are reported."""
+    for name, src in state_dict_from.items():
+        dst = state_dict_target.get(name)
+        if dst is None:
             continue
-        if param.size() == state_dict_target[name].size():
-            state_dict_target[name].copy_(param)
+        if tuple(dst.shape) == tuple(src.shape):
+            dst.copy_(src)
         else:
-            print(f"layer {name}({param.size()} different than target: {state_dict_target[name].size()}")
+            print(f'skipped {name}: checkpoint {tuple(src.shape)} vs model {tuple(dst.shape)}')
     return state_dict_target
 
 
@@ -166,11 +166,12 @@ class FusedAdam:
         self.params = [p for p in params]
         self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False,
                                   maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
-                                  params=list(range(len(self.params))))]
+                                  decoupled_weight_decay=False, params=list(range(len(self.params))))]
         self.arena = None
         self.exp_avg = self.exp_avg_sq = None
         self.step_count = 0
         self._pending_state = None
+        self.stateful = set()      # parameter indices with Adam state: torch creates it lazily, for parameters that had a gradient
 
     def attach(self, arena: D.FlatArena):
         self.arena = arena
@@ -184,6 +185,7 @@ class FusedAdam:
         assert self.arena is not None, 'optimizer used before the trainer prepared the unet'
         g = self.param_groups[0]
         self.step_count += 1
+        self.stateful |= self.arena.touched
         ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0],
                       g['betas'][1], g['eps'], g['weight_decay'], self.step_count, zero_grad=True)
 
@@ -194,7 +196,12 @@ class FusedAdam:
     def state_dict(self):
         state = {}
         if self.arena is not None and self.step_count > 0:
-            for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+            # like torch.optim.Adam, parameters that never had a gradient (mid_block / norm_cond of the C2 net) carry no state --
+            # pinned by the reference-made manifest tests/golden/ckpt_manifest.npz; gradients that bypassed the arena's
+            # collect() leave no record, then every parameter is listed
+            listed = sorted(self.stateful) if self.stateful else range(len(self.arena.params))
+            for i in listed:
+                p, o = self.arena.params[i], self.arena.offsets[i]
                 n = p.numel()
                 state[i] = dict(step=torch.tensor(float(self.step_count)),
                                 exp_avg=self.exp_avg[o:o + n].view_as(p).clone(),
@@ -210,6 +217,7 @@ class FusedAdam:
             self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
             self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
             self.step_count = max(self.step_count, int(float(st['step'])))
+            self.stateful.add(i)
 
     def load_state_dict(self, sd):
         for k in ('lr', 'betas', 'eps', 'weight_decay'):
@@ -345,7 +353,6 @@ class ImagenTrainer(nn.Module):
         self.num_unets = len(self.imagen.unets)
         self.use_ema = use_ema and self.is_main
         self.ema_unets = nn.ModuleList([])
-        self.ema_unet_being_trained_index = -1
         self.train_dl_iter = self.train_dl = self.valid_dl_iter = self.valid_dl = None
         self.dl_tuple_output_keywords_names = dl_tuple_output_keywords_names
         self.split_valid_from_train = split_valid_from_train
@@ -610,7 +617,7 @@ class ImagenTrainer(nn.Module):
             return
         assert not (os.path.exists(path) and not overwrite)
         self.reset_ema_unets_all_one_device()
-        save_obj = dict(model=self.imagen.state_dict(), version=__version__, steps=self.steps.cpu(), **kwargs)
+        save_obj = dict(model=self.imagen.state_dict(), version=CHECKPOINT_VERSION, steps=self.steps.cpu(), **kwargs)
         for ind in (range(0, self.num_unets) if not without_optim_and_sched else tuple()):
             save_obj = {**save_obj, f'scaler{ind}': getattr(self, f'scaler{ind}').state_dict(),
                         f'optim{ind}': getattr(self, f'optim{ind}').state_dict()}
@@ -630,8 +637,8 @@ class ImagenTrainer(nn.Module):
         self.reset_ema_unets_all_one_device()
         with open(path, 'rb') as f:
             loaded_obj = torch.load(f, map_location='cpu', weights_only=False)
-        if str(loaded_obj.get('version')) != str(__version__):
-            self.print(f'loading saved imagen at version {loaded_obj.get("version")}, but current package version is {__version__}')
+        if str(loaded_obj.get('version')) != CHECKPOINT_VERSION:
+            self.print(f'checkpoint written at version {loaded_obj.get("version")}; this trainer reads and writes the {CHECKPOINT_VERSION} layout')
         try:
             self.imagen.load_state_dict(loaded_obj['model'], strict=strict)
         except RuntimeError:
@@ -667,49 +674,44 @@ class ImagenTrainer(nn.Module):
             arena.reinstall_grads()
 
     # ---- EMA unets (trainer.py:949-1005) -----------------------------------------------------------------
+    # One process drives one GPU and every U-Net of the cascade lives there, so the reference's shuffling of EMA copies between
+    # the device and the host has no counterpart: ``ema_unets`` stays one ModuleList (its state_dict keys ``{i}.ema_model.*`` /
+    # ``{i}.online_model.*`` / ``{i}.initted`` / ``{i}.step`` are the checkpoint contract, tests/golden/ckpt_manifest.npz).
     @property
     def unets(self):
         return nn.ModuleList([ema.ema_model for ema in self.ema_unets])
 
     def get_ema_unet(self, unet_number=None):
         if not self.use_ema:
-            return
-        unet_number = self.validate_unet_number(unet_number)
-        index = unet_number - 1
-        if isinstance(self.unets, nn.ModuleList):
-            unets_list = [unet for unet in self.ema_unets]
-            delattr(self, 'ema_unets')
-            self.ema_unets = unets_list
-        if index != self.ema_unet_being_trained_index:
-            for unet_index, unet in enumerate(self.ema_unets):
-                unet.to(self.device if unet_index == index else 'cpu')
-        self.ema_unet_being_trained_index = index
-        return self.ema_unets[index]
+            return None
+        return self.ema_unets[self.validate_unet_number(unet_number) - 1]
 
     def reset_ema_unets_all_one_device(self, device=None):
+        """Kept for callers of the reference API; a no-op unless something moved an EMA copy off the trainer's device."""
         if not self.use_ema:
             return
-        device = default(device, self.device)
-        self.ema_unets = nn.ModuleList([*self.ema_unets])
-        self.ema_unets.to(device)
-        self.ema_unet_being_trained_index = -1
+        target = torch.device(default(device, self.device))
+        for ema in self.ema_unets:
+            if any(p.device != target for p in ema.ema_model.parameters()):
+                ema.ema_model.to(target)
 
     @torch.no_grad()
     @contextmanager
     def use_ema_unets(self):
+        """Inside the context ``self.imagen`` samples with the EMA weights (trainer.py:982-1005)."""
         if not self.use_ema:
-            output = yield
-            return output
+            yield
+            return
         self.reset_ema_unets_all_one_device()
         self.imagen.reset_unets_all_one_device()
-        self.unets.eval()
-        trainable_unets = self.imagen.unets
-        self.imagen.unets = self.unets
-        output = yield
-        self.imagen.unets = trainable_unets
-        for ema in self.ema_unets:
-            ema.restore_ema_model_device()
-        return output
+        online = self.imagen.unets
+        swapped = self.unets
+        swapped.eval()
+        self.imagen.unets = swapped
+        try:
+            yield
+        finally:
+            self.imagen.unets = online
 
     def state_dict(self, *args, **kwargs):
         self.reset_ema_unets_all_one_device()
@@ -734,14 +736,10 @@ class ImagenTrainer(nn.Module):
             optimizer.step()            # fused Adam + zero_grad
             self._sync_now = False
         if self.use_ema:
-            self.get_ema_unet(unet_number).update()
-        self.steps += F.one_hot(torch.tensor(unet_number - 1, device=self.steps.device), num_classes=len(self.steps))
-        if not exists(self.checkpoint_path):
-            return
-        total_steps = int(self.steps.sum().item())
-        if total_steps % self.checkpoint_every:
-            return
-        self.save_to_checkpoint_folder()
+            self.ema_unets[index].update()
+        self.steps[index] += 1
+        if exists(self.checkpoint_path) and int(self.steps.sum().item()) % self.checkpoint_every == 0:
+            self.save_to_checkpoint_folder()
 
     @torch.no_grad()
     @cast_torch_tensor

@@ -205,6 +205,11 @@ int diqt_gn_act_bwd(const float* x, const float* dy, const float* mean, const fl
  * Replaces autograd of Block.forward (imagen_pytorch3D.py:535-566, imagen_video.py:671-697).                                       */
 int diqt_conv3d_fwd_gnbwd_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd,
                                  int eph, int epw);
+/* Process-wide switch of that fusion (default: off unless DIQT_GNBWD_FUSE=1 in the environment at the first query).  The setter
+ * returns the previous value; with the switch off diqt_conv3d_fwd_gnbwd_blocks answers 0 for every shape.  Host-side state only
+ * (no reference counterpart: both settings compute autograd of Block.forward, imagen_pytorch3D.py:535-566).                        */
+int diqt_get_gnbwd_fuse(void);
+int diqt_set_gnbwd_fuse(int on);
 int diqt_conv3d_fwd_gnbwd(const float* x, const float* packed, float* y, float* partials, const float* gn_x, const float* mean,
                           const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
                           int cond_stride, int G, int act, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,

@@ -8,9 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-# opt-in kernel paths that production leaves off by default run under test (read once by the library, so set before it loads):
-# the GroupNorm backward's reduction in the epilogue of the conv's backward-data pass (diqt_conv3d_fwd_gnbwd)
-os.environ.setdefault("DIQT_GNBWD_FUSE", "1")
+# The suite runs the library's DEFAULT configuration (what bench.py and users run).  The opt-in GroupNorm-backward fusion
+# (diqt_conv3d_fwd_gnbwd) is switched on per test through ops.gnbwd_fuse(True) -- a runtime setter, so the whole-network gradient
+# tests run in BOTH modes inside one process (tests/test_gpu_fullsize.py, tests/test_gpu_unet.py).
+os.environ.pop("DIQT_GNBWD_FUSE", None)
 
 
 def pytest_configure(config):

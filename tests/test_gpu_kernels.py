@@ -767,7 +767,17 @@ def test_block_backward_with_groupnorm_reduction_in_the_conv_epilogue(ops, B, sp
     D, H, W = sp
     pads = tuple(kk // 2 for kk in k)
     bp = tuple(kk - 1 - p for kk, p in zip(k, pads))
-    assert _lib.query("diqt_conv3d_fwd_gnbwd_blocks", B, D, H, W, Cout, Cin, *k, *bp, 0, 0, 0) > 0, "backward-data pass not on conv_fwd9_kernel"
+    assert _lib.query("diqt_conv3d_fwd_gnbwd_blocks", B, D, H, W, Cout, Cin, *k, *bp, 0, 0, 0) == 0, "the fusion is off by default"
+    with ops.gnbwd_fuse(True):
+        assert _lib.query("diqt_conv3d_fwd_gnbwd_blocks", B, D, H, W, Cout, Cin, *k, *bp, 0, 0, 0) > 0, "backward-data pass not on conv_fwd9_kernel"
+        _block_backward_case(ops, B, sp, Cin, Cout, k, act, with_ss)
+    assert not _lib.query("diqt_get_gnbwd_fuse")
+    _block_backward_case(ops, B, sp, Cin, Cout, k, act, with_ss)            # and the default: reduction in its own pass
+
+
+def _block_backward_case(ops, B, sp, Cin, Cout, k, act, with_ss):
+    D, H, W = sp
+    pads = tuple(kk // 2 for kk in k)
     g = torch.Generator().manual_seed(Cin * 7 + Cout)
     x = torch.randn(B, Cin, D, H, W, generator=g) * 1.5 + 0.3
     gamma, beta = torch.randn(Cin, generator=g), torch.randn(Cin, generator=g) * 0.3

@@ -228,6 +228,54 @@ def test_unet_config2_at_32cubed_on_the_headline_conv_kernel_vs_oracle(B, kid):
     assert rel <= 2e-5, rel
 
 
+_C2_GRAD_ORACLE = {}
+
+
+@pytest.mark.parametrize("fuse", [False, True], ids=["gn_reduce_own_pass(default)", "gn_reduce_in_conv_epilogue"])
+def test_unet_config2_at_32cubed_whole_network_gradients_vs_oracle_in_both_groupnorm_backward_modes(fuse):
+    """Whole-network backward of the exact BASELINE config-2 net at its real 32^3 size (B = 2: the 32^3-level backward-data convs run on
+    ``conv_fwd9_kernel``, so the fused mode really takes ``diqt_conv3d_fwd_gnbwd``): loss and EVERY parameter gradient against autograd
+    of the CPU oracle, once with the GroupNorm-backward reduction as its own pass (the default: what bench.py times) and once in the
+    conv epilogue.  Reference: imagen_pytorch3D.py:535-614, 1554-1684."""
+    from bench import unet_kwargs
+    from diffusioniqt_amd import ops, _lib
+    from diffusioniqt_amd.imagen_pytorch3D import SRUnet256
+    B = 2
+    kw = unet_kwargs(32)
+    unet = SRUnet256(**kw)
+    sd = O.hash_fill_state_dict(unet.state_dict(), 9)
+    unet.load_state_dict(sd)
+    unet = unet.to(DEV).train()
+    gen = torch.Generator().manual_seed(777)
+    x, lr = torch.randn(B, 1, 32, 32, 32, generator=gen), torch.randn(B, 1, 32, 32, 32, generator=gen)
+    t = torch.rand(B, generator=gen)
+    ls = O.alpha_cosine_log_snr(t)
+    if not _C2_GRAD_ORACLE:
+        sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        yr = O.unet_forward(sdg, O.unet_config(**kw), x, t, ls, lowres_cond_img=lr)
+        (yr ** 2).mean().backward()
+        _C2_GRAD_ORACLE.update(y=yr.detach(), grads={k: v.grad for k, v in sdg.items() if v.grad is not None})
+    with ops.gnbwd_fuse(fuse):
+        bp = (1, 1, 1)
+        took = _lib.query("diqt_conv3d_fwd_gnbwd_blocks", B, 32, 32, 32, 64, 64, 3, 3, 3, *bp, 0, 0, 0) > 0
+        assert took == fuse
+        y = unet(x.to(DEV), t.to(DEV), ls.to(DEV), lowres_cond_img=lr.to(DEV))
+        (y ** 2).mean().backward()
+    rel = close(y, _C2_GRAD_ORACLE['y'], 2e-4, "config-2 unet at 32^3 (train mode)")
+    assert rel <= 2e-5, rel
+    named = dict(unet.named_parameters())
+    ref = _C2_GRAD_ORACLE['grads']
+    n = 0
+    for k, p in named.items():
+        if k in ref:
+            assert p.grad is not None, k
+            close(p.grad, ref[k], 1e-3, f"grad {k} (fuse={fuse})")
+            n += 1
+        else:
+            assert p.grad is None, k
+    assert n > 200
+
+
 SAMPLER_OPTION_CASES = [
     ('noise_dyn', 'noise', True, 'z-score', 4, {}),
     ('v_static', 'v', False, 'z-score', 4, {}),

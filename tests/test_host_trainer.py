@@ -116,3 +116,113 @@ def test_ema_schedule_matches_published_defaults():
     assert decays[:3] == [0.0, 0.0, 0.0]
     assert abs(decays[3] - (1 - 2 ** (-2 / 3))) < 1e-9 and abs(decays[4] - (1 - 11 ** (-2 / 3))) < 1e-9
     assert decays[-1] == 0.9999
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# checkpoint interop against what the REAL reference's trainer.save wrote (tests/golden/ckpt_manifest.npz, oracle/make_golden_ckpt.py;
+# /root/reference/trainer.py:813-945)
+# ------------------------------------------------------------------------------------------------------------------------------------
+def load_manifest():
+    return json.loads(str(load_golden('ckpt_manifest')['manifest']))
+
+
+def entries(sd):
+    return [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in sd.items()]
+
+
+def checkpoint_from_manifest(man, seed=3):
+    """A checkpoint dictionary with the reference file's exact structure and seeded values (the fixture holds no payloads)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def tensor(shape, dtype):
+        if dtype == 'bool':
+            return torch.zeros(shape, dtype=torch.bool)
+        if dtype.startswith('int'):
+            return torch.full(shape, 5, dtype=getattr(torch, dtype))
+        return torch.randn(shape, generator=g, dtype=getattr(torch, dtype)) * 0.1
+    obj = {}
+    for k in man['top_keys']:
+        if k == 'model':
+            obj[k] = {name: tensor(shape, dt) for name, shape, dt in man[k]}
+        elif k == 'ema':
+            # ``{i}.online_model.X`` IS ``unets.{i}.X`` (the EMA wrapper holds the trained module): one tensor in a real file
+            obj[k] = {}
+            for name, shape, dt in man[k]:
+                i, kind, rest = (name.split('.', 2) + [''])[:3]
+                obj[k][name] = obj['model'][f'unets.{i}.{rest}'].clone() if kind == 'online_model' else tensor(shape, dt)
+        elif k == 'version':
+            obj[k] = man['version']
+        elif k == 'steps':
+            obj[k] = torch.tensor(man['steps'])
+        elif k.startswith('scaler'):
+            obj[k] = dict(man['scaler'][k])
+        elif k.startswith('optim'):
+            o = man['optim'][k]
+            groups = [{**gr, 'betas': tuple(gr['betas'])} for gr in o['param_groups']]
+            state = {}
+            for i, st in o['state'].items():
+                d = {name: (tensor(shape, dt).abs() if name == 'exp_avg_sq' else tensor(shape, dt)) for name, shape, dt in st['entries']}
+                d['step'] = torch.tensor(st['step'])
+                state[int(i)] = d
+            obj[k] = dict(state=state, param_groups=groups)
+    return obj
+
+
+def make_real_module_trainer(**kw):
+    """ImagenTrainer over the product's real SRUnet256 (constructing and (de)serialising need no GPU; a forward would)."""
+    from diffusioniqt_amd.imagen_pytorch3D import Imagen, NullUnet, SRUnet256
+    from diffusioniqt_amd.trainer import ImagenTrainer
+    gu = load_golden('unetA_tiny')
+    unet = SRUnet256(**json.loads(str(gu['kwargs'])))
+    configs = {'Data': {'norm': 'z-score'}, 'Train': {'batch_sample': False, 'patch_size_sub': 8, 'pred_obj': 'x_start'}, 'Eval': {'repeat': 1}}
+    imagen = Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=float(gu['min_bound']), image_sizes=(8, 8), channels=1,
+                    pred_objectives='x_start', timesteps=4, dynamic_thresholding=False, p2_loss_weight_gamma=0.0, cond_drop_prob=0.0)
+    ImagenTrainer.locked = False
+    return ImagenTrainer(configs=configs, imagen=imagen, gradient_accumulation_steps=4, verbose=False, **kw)
+
+
+def test_saved_checkpoint_has_the_reference_manifest_before_any_step(tmp_path):
+    """Key order of the file, every ``model`` / ``ema`` entry (name, shape, dtype, order), scaler dicts, Adam hyper-parameters and
+    parameter index lists equal what the reference's own ``trainer.save`` produced for the same network."""
+    man = load_manifest()
+    trainer = make_real_module_trainer()
+    path = os.path.join(tmp_path, '3dimagen.pt')
+    trainer.save(path)
+    obj = torch.load(path, map_location='cpu', weights_only=False)
+    assert list(obj.keys()) == man['top_keys']
+    assert entries(obj['model']) == man['model']
+    assert entries(obj['ema']) == man['ema']
+    assert str(obj['version']) == man['version']
+    assert obj['steps'].dtype == torch.int64 and obj['steps'].tolist() == [0, 0]
+    for k, ref in man['scaler'].items():
+        assert obj[k] == ref
+    for k, ref in man['optim'].items():
+        assert list(obj[k].keys()) == ref['keys']
+        got = [{**g, 'betas': list(g['betas'])} for g in obj[k]['param_groups']]
+        assert got == ref['param_groups'], (k, got, ref['param_groups'])
+        assert obj[k]['state'] == {}
+
+
+def test_load_accepts_a_checkpoint_with_the_reference_layout(tmp_path):
+    """A file with the reference's structure (rebuilt from the manifest with seeded values) loads with ``strict=True``: weights, EMA
+    weights and buffers, ``steps``; the Adam state waits for the arena (its landing is checked on the GPU, tests/test_gpu_flow.py)."""
+    man = load_manifest()
+    obj = checkpoint_from_manifest(man)
+    path = os.path.join(tmp_path, 'ref_layout.pt')
+    torch.save(obj, path)
+    trainer = make_real_module_trainer()
+    trainer.load(path)
+    sd = trainer.imagen.state_dict()
+    for name, _, _ in man['model']:
+        assert torch.equal(sd[name].cpu(), obj['model'][name]), name
+    esd = trainer.ema_unets.state_dict()
+    for name, _, _ in man['ema']:
+        assert torch.equal(esd[name].cpu(), obj['ema'][name]), name
+    assert trainer.steps.tolist() == man['steps']
+    pend = trainer.optim1._pending_state
+    assert pend is not None and sorted(pend['state']) == sorted(int(i) for i in man['optim']['optim1']['state'])
+    # parameters without Adam state in the reference file are exactly the ones that never receive a gradient
+    names = man['optim1_param_names']
+    assert names == [n for n, _ in trainer.imagen.unets[1].named_parameters()]
+    stateless = {names[i] for i in range(len(names)) if str(i) not in man['optim']['optim1']['state']}
+    assert stateless and all(n.startswith(('mid_block.', 'norm_cond.')) for n in stateless), stateless

@@ -142,9 +142,20 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.rehearse))
 
-    if os.environ.get("DIQT_BENCH_WATCHDOG"):              # diagnostic: dump every thread's stack and exit if this rank is still running
-        import faulthandler                                # after that many seconds (a hung collective shows where each rank stands)
-        faulthandler.dump_traceback_later(int(os.environ["DIQT_BENCH_WATCHDOG"]), exit=True)
+    # Watchdog (default ON for N > 1): a rank that sits in a collective the others never join would hold the node until the lease
+    # runs out.  Every phase arms a bound; when it expires faulthandler dumps every thread's stack of this rank to stderr and the
+    # process exits non-zero (the launcher then ends the other ranks).  Start-up (import, RCCL communicator set-up, first launches)
+    # gets DIQT_BENCH_WATCHDOG seconds (default 600; 0 disables, also for N = 1 where it is off unless set); a timed loop gets
+    # 60 s + 20 x its expected duration, taken from its own first warm-up call (at least DIQT_BENCH_WATCHDOG when that is set).
+    import faulthandler
+    wd_env = os.environ.get("DIQT_BENCH_WATCHDOG")
+    wd_start = int(wd_env) if wd_env else (600 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0)
+
+    def arm_watchdog(seconds):
+        if wd_start > 0:
+            faulthandler.cancel_dump_traceback_later()
+            faulthandler.dump_traceback_later(max(1, int(seconds)), exit=True)
+    arm_watchdog(wd_start)
     import torch
     import torch.distributed as dist
     from diffusioniqt_amd import distributed as D, ops, _lib
@@ -163,9 +174,16 @@ def main():
 
     def timed(fn, n_warm, n_steps):
         """W untimed warm-up calls, then exactly n_steps calls bracketed by barrier + synchronize; MAX over ranks."""
-        for _ in range(n_warm):
+        arm_watchdog(wd_start)
+        tp = time.perf_counter()
+        for i in range(n_warm):
             fn()
+            if i == 0:
+                torch.cuda.synchronize()
+                arm_watchdog(max(60 + 20 * (n_warm + n_steps) * (time.perf_counter() - tp), wd_start if wd_env else 0))
         sync_all()
+        if n_warm == 0:
+            arm_watchdog(wd_start)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             fn()
@@ -175,6 +193,7 @@ def main():
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        arm_watchdog(wd_start)                               # whatever follows (instrumented pass, next phase set-up)
         return dt
 
     def instrumented(fn, n):
@@ -229,10 +248,11 @@ def main():
     else:
         out = bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented, roofline_of, sync_all)
     if rank == 0:
-        print(json.dumps({**out, **common}))
+        print(json.dumps({**out, **common}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

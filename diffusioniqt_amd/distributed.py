@@ -12,6 +12,7 @@ gradients go out as ~25 MB buckets (first bucket 1 MB so the first collective st
 """
 import os
 import sys
+import time
 from typing import List
 
 import torch
@@ -152,7 +153,7 @@ class BucketedGradReducer:
         self.active = self.world > 1 or (force and dist.is_initialized())
         self.sync = True
         self.used = None                    # learned set of parameter indices that receive gradients
-        self._seen, self._pending, self._handles = set(), {}, []
+        self._seen, self._pending, self._handles, self._order = set(), {}, [], []
         n = len(arena.params)
         ends = [arena.offsets[i + 1] if i + 1 < n else arena.numel for i in range(n)]
         self.buckets, cap, cur, cur_hi = [], int(first_bucket_mb * (1 << 18)), [], arena.numel
@@ -196,14 +197,16 @@ class BucketedGradReducer:
         buf = self.arena.grad[lo:hi]
         native_avg = dist.get_backend(self.pg) == "nccl"        # RCCL averages in the collective; gloo sums, divided after the wait
         if _TRACE:
-            print(f"[ddp rank {dist.get_rank()}] launch bucket {b} [{lo}:{hi}] params {len(only)} handles {len(self._handles)}", file=sys.stderr, flush=True)
+            print(f"[ddp rank {dist.get_rank()}] t={time.time() % 10000:.2f} launch bucket {b} [{lo}:{hi}] params {len(only)} handles {len(self._handles)}", file=sys.stderr, flush=True)
         h = dist.all_reduce(buf, op=dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._launched.add(b)
+        self._order.append(b)
         self._handles.append((h, buf, native_avg))
 
     def prepare_backward(self, sync=True):
         self.sync = sync
         self._seen, self._pending, self._handles, self._launched = set(), {}, [], set()
+        self._order = []                    # bucket indices in the order this rank enqueued their collectives
 
     def finalize_backward(self):
         """Call after ``loss.backward()`` of a synchronised micro-step: launches whatever is left and waits."""
@@ -213,6 +216,12 @@ class BucketedGradReducer:
             if b not in self._launched:
                 self._launch(b)
         self._wait()
+        if _TRACE:
+            # every rank must enqueue the SAME collectives in the SAME order: compare the launch orders of this step
+            orders = [None] * self.world
+            dist.all_gather_object(orders, list(self._order), group=self.pg)
+            print(f"[ddp rank {dist.get_rank()}] step done, launch order {self._order}", file=sys.stderr, flush=True)
+            assert all(o == orders[0] for o in orders), f"ranks enqueued gradient buckets in different orders: {orders}"
         if self.used is None:
             self.used = set(self._seen)
         stragglers = sorted(self._seen - self.used)
@@ -229,8 +238,10 @@ class BucketedGradReducer:
     def _wait(self):
         for k, (h, buf, native_avg) in enumerate(self._handles):
             if _TRACE:
-                print(f"[ddp rank {dist.get_rank()}] wait {k} of {len(self._handles)}", file=sys.stderr, flush=True)
+                print(f"[ddp rank {dist.get_rank()}] t={time.time() % 10000:.2f} wait {k} of {len(self._handles)}", file=sys.stderr, flush=True)
             h.wait()
+            if _TRACE:
+                print(f"[ddp rank {dist.get_rank()}] t={time.time() % 10000:.2f} done {k}", file=sys.stderr, flush=True)
             if not native_avg:
                 buf.div_(self.world)
         self._handles = []

@@ -522,6 +522,28 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
             trainer.mixed_precision = 'no'
             result["train_bf16"] = dict(ms_per_step=1e3 * dtb / kt, patches_per_s=world * B * kt / dtb, steps=kt)
 
+    # ---------------- BASELINE configs[3] and configs[4] beside the headline (single GPU): C4 evals and a SHORT C5 cascade ----------------
+    if args.mode == "both" and extras and S == 32:
+        import copy
+        torch.cuda.empty_cache()
+        a4 = copy.copy(args)
+        a4.steps, a4.warmup, a4.batch = 3, 1, 1
+        c4 = bench_c4(a4, torch, ops, device, world, timed, instrumented, roofline_of)
+        result["c4"] = dict(workload=c4["config"]["workload"], volumes_per_s=c4["value"], eval_ms=c4["ms_per_step"], steps=3, dtype="f32",
+                            whole_eval_tflops=c4["whole_step_tflops"], whole_eval_frac_of_f32_mfma_peak=c4["whole_step_frac_of_f32_mfma_peak"],
+                            roofline=c4["roofline"], autocast_fp16_eval_ms=c4["autocast_fp16"]["ms_per_step"])
+        torch.cuda.empty_cache()
+        a5 = copy.copy(args)
+        a5.steps, a5.warmup, a5.batch = 2, 0, B
+        c5 = bench_c5(a5, torch, ops, device, world, timed, instrumented, roofline_of)
+        result["c5_short"] = dict(workload=c5["config"]["workload"], heun_steps_per_stage=2, unet_evals_per_stage=3, batch=B,
+                                  cascade_ms=c5["ms_per_step"], unet_evals_per_s=c5["unet_evals_per_s"], dtype=c5["dtype"],
+                                  whole_cascade_tflops=c5["whole_step_tflops"], whole_cascade_frac_of_f16_mfma_peak=c5["whole_step_frac_of_f16_mfma_peak"],
+                                  roofline=c5["roofline"],
+                                  note="the full 64-step cascade is `bench.py --config C5` (127 evals per stage); this line times 3 evals per stage so the "
+                                       "default run carries BASELINE configs[4] at all: per-eval rates are the same, the per-sample figure is not the 64-step one")
+        torch.cuda.empty_cache()
+
     # ---------------- CPU baseline: the oracle on the host cores, bounded sample ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -570,6 +592,9 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
         out["autocast_fp16"] = r3(result["autocast_fp16"])
         out["autocast_fp16"]["note"] = ("same DDPM sampler step under torch.autocast(float16): conv/linear forwards on v_mfma_f32_32x32x16_f16 "
                                         "(fp32 accumulate), all else fp32; reduced precision, NOT the headline")
+    for k in ("c4", "c5_short"):
+        if k in result:
+            out[k] = result[k]
     if "edm" in result:
         out["edm"] = r3(result["edm"])
         out["edm"]["note"] = "ElucidatedImagen.sample (stochastic Heun, 2 U-Net evals per step except the last) driving the same C2 U-Net"

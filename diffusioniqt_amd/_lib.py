@@ -42,6 +42,8 @@ PROTOTYPES = {
     "diqt_groupnorm_stats": (I, [P, P, P, P, Z, I, I, I, I, F, P]),
     "diqt_gn_act_fwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "diqt_gn_act_bwd": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "diqt_gn_act_bwd_ex": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "diqt_chan_layernorm_bwd_ex": (I, [P, P, P, P, P, P, P, P, P, P, Z, I, I, P]),
     "diqt_gn_act_bwd_from_partials": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_conv3d_fwd_gnbwd_blocks": (I, [I] * 15),
     "diqt_get_gnbwd_fuse": (I, []),

@@ -285,11 +285,15 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float* __restri
 template <bool VEC>
 __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ dx, GnCoef k,
-                                                            const float* __restrict__ m12, int rows, int act) {
+                                                            const float* __restrict__ m12, int rows, int act,
+                                                            const float* __restrict__ add) {
+    // add (optional, kernel-uniform): the gradient that reaches x through its OTHER consumer (the residual branch of a ResnetBlock),
+    // summed here instead of in a separate pass over three tensors
     const int b = blockIdx.y, C = k.C, G = k.G, Cg = C / G;
     const size_t per = (size_t)rows * C;
     const float* xb = x + (size_t)b * per;
     const float* dyb = dy + (size_t)b * per;
+    const float* adb = add ? add + (size_t)b * per : nullptr;
     float* dxb = dx + (size_t)b * per;
     auto one = [&](float xv, float dyv, int c) -> float {
         float A, Bc;
@@ -320,32 +324,34 @@ __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restr
         };
         const size_t st = (size_t)gridDim.x * 256;
         size_t i = i0;
-        for (; i + st < n4; i += 2 * st) {              // 4 loads in flight
-            float4 xv[2], dv[2];
+        for (; i + st < n4; i += 2 * st) {              // 4 (6) loads in flight
+            float4 xv[2], dv[2], av[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 xv[u] = *reinterpret_cast<const float4*>(xb + (i + u * st) * 4);
                 dv[u] = *reinterpret_cast<const float4*>(dyb + (i + u * st) * 4);
+                av[u] = adb ? *reinterpret_cast<const float4*>(adb + (i + u * st) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 float4 o;
-                o.x = onej(xv[u].x, dv[u].x, 0); o.y = onej(xv[u].y, dv[u].y, 1);
-                o.z = onej(xv[u].z, dv[u].z, 2); o.w = onej(xv[u].w, dv[u].w, 3);
+                o.x = onej(xv[u].x, dv[u].x, 0) + av[u].x; o.y = onej(xv[u].y, dv[u].y, 1) + av[u].y;
+                o.z = onej(xv[u].z, dv[u].z, 2) + av[u].z; o.w = onej(xv[u].w, dv[u].w, 3) + av[u].w;
                 *reinterpret_cast<float4*>(dxb + (i + u * st) * 4) = o;
             }
         }
         for (; i < n4; i += st) {
             const float4 xv = *reinterpret_cast<const float4*>(xb + i * 4);
             const float4 dv = *reinterpret_cast<const float4*>(dyb + i * 4);
+            const float4 av = adb ? *reinterpret_cast<const float4*>(adb + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 o;
-            o.x = onej(xv.x, dv.x, 0); o.y = onej(xv.y, dv.y, 1);
-            o.z = onej(xv.z, dv.z, 2); o.w = onej(xv.w, dv.w, 3);
+            o.x = onej(xv.x, dv.x, 0) + av.x; o.y = onej(xv.y, dv.y, 1) + av.y;
+            o.z = onej(xv.z, dv.z, 2) + av.z; o.w = onej(xv.w, dv.w, 3) + av.w;
             *reinterpret_cast<float4*>(dxb + i * 4) = o;
         }
     } else {
         for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256)
-            dxb[i] = one(xb[i], dyb[i], (int)(i % C));
+            dxb[i] = one(xb[i], dyb[i], (int)(i % C)) + (adb ? adb[i] : 0.f);
     }
 }
 
@@ -380,7 +386,8 @@ __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void chan_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ g, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, float* __restrict__ dx,
-                                                             int rows, int C) {
+                                                             int rows, int C, const float* __restrict__ add) {
+    // add (optional): the gradient reaching x through its other consumer (`LN(x) -> fn -> + x` blocks), summed in this pass
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb) {
@@ -395,7 +402,9 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_dx_kernel(const float* __rest
         a = wave_sum(a) / C; bsum = wave_sum(bsum) / C;
         for (int c = lane; c < C; c += 64) {
             const float dxh = dr[c] * g[c], xh = (xr[c] - m) * rs;
-            dx[(size_t)r * C + c] = rs * (dxh - a - xh * bsum);
+            float v = rs * (dxh - a - xh * bsum);
+            if (add) v += add[(size_t)r * C + c];
+            dx[(size_t)r * C + c] = v;
         }
     }
 }
@@ -1504,7 +1513,7 @@ static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
                            const float* gamma, const float* beta, const float* scale, const float* shift,
                            int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
                            size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream, const float* ext_partials,
-                           int ext_nblk) {
+                           int ext_nblk, const float* dx_add = nullptr) {
     DIQT_REQUIRE(x && dy && mean && rstd && dx && workspace, DIQT_E_ALIGN, "gn_act_bwd: null pointer");
     DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_act_bwd: bad shape");
     DIQT_REQUIRE(workspace_bytes >= diqt_reduce_workspace_bytes(B, C), DIQT_E_WORKSPACE, "gn_act_bwd: workspace too small");
@@ -1516,7 +1525,7 @@ static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
     float* S = partial + (size_t)B * RED_NBLK * 2 * C;
     float* m12 = S + (size_t)2 * B * C;
     const size_t per = (size_t)rows * C;
-    const bool vec = vec_ok(x, dy, dx, per, C);
+    const bool vec = vec_ok(x, dy, dx, per, C) && (!dx_add || aligned16(dx_add));
     GnBwdF f{x, dy, k, act};
     int rc = DIQT_OK;
     if (ext_partials) {
@@ -1538,8 +1547,8 @@ static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
     rc = check_launch("gn_act_bwd/final");
     if (rc) return rc;
     const dim3 grid(gn_grid(per, C, B), B);
-    if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
-    else hipLaunchKernelGGL(gn_act_bwd_dx_kernel<false>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act);
+    if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act, dx_add);
+    else hipLaunchKernelGGL(gn_act_bwd_dx_kernel<false>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act, dx_add);
     return check_launch("gn_act_bwd/dx");
 }
 
@@ -1560,6 +1569,17 @@ extern "C" int diqt_gn_act_bwd_from_partials(const float* x, const float* dy, co
                            workspace_bytes, B, rows, C, G, act, stream, partials, nblk);
 }
 
+// partials (optional): as diqt_gn_act_bwd_from_partials; dx_add (optional, same shape as x): dx = (GroupNorm backward) + dx_add -- the
+// gradient reaching x through its other consumer (ResnetBlock: x -> block1 AND x -> res_conv / identity, imagen_pytorch3D.py:601-614,
+// imagen_video.py:745-770), so that autograd's separate sum over the two branches disappears.
+extern "C" int diqt_gn_act_bwd_ex(const float* x, const float* dy, const float* partials, int nblk, const float* dx_add, const float* mean,
+                                  const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
+                                  int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
+                                  size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream) {
+    return gn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, scale, shift, cond_stride, dx, dgamma, dbeta, dscale, dshift, workspace,
+                           workspace_bytes, B, rows, C, G, act, stream, partials, nblk, dx_add);
+}
+
 extern "C" int diqt_chan_layernorm_fwd_res(const float* x, const float* g, const float* b, const float* residual, float* y,
                                            float* mean, float* rstd, int rows, int C, float eps, void* stream) {
     DIQT_REQUIRE(x && g && y, DIQT_E_ALIGN, "chan_layernorm_fwd: null pointer");
@@ -1576,10 +1596,17 @@ extern "C" int diqt_chan_layernorm_fwd(const float* x, const float* g, const flo
 extern "C" int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean,
                                        const float* rstd, float* dx, float* dg, float* db, void* workspace,
                                        size_t workspace_bytes, int rows, int C, void* stream) {
+    return diqt_chan_layernorm_bwd_ex(x, dy, nullptr, g, mean, rstd, dx, dg, db, workspace, workspace_bytes, rows, C, stream);
+}
+// dx_add (optional, same shape as x): dx = (LayerNorm backward) + dx_add, the gradient of the residual branch of
+// `fn(LN(x)) + x` (Attention / feed-forward blocks, imagen_video.py:410-525, 1004-1029)
+extern "C" int diqt_chan_layernorm_bwd_ex(const float* x, const float* dy, const float* dx_add, const float* g, const float* mean,
+                                          const float* rstd, float* dx, float* dg, float* db, void* workspace,
+                                          size_t workspace_bytes, int rows, int C, void* stream) {
     DIQT_REQUIRE(x && dy && g && mean && rstd && dx, DIQT_E_ALIGN, "chan_layernorm_bwd: null pointer");
     DIQT_REQUIRE(rows > 0 && C > 0, DIQT_E_SHAPE, "chan_layernorm_bwd: bad shape");
     hipLaunchKernelGGL(chan_ln_bwd_dx_kernel, dim3(grid_for((size_t)rows, 4, 4096)), dim3(256), 0, STREAM, x, dy, g, mean,
-                       rstd, dx, rows, C);
+                       rstd, dx, rows, C, dx_add);
     int rc = check_launch("chan_layernorm_bwd/dx");
     if (rc || !dg) return rc;
     DIQT_REQUIRE(workspace && workspace_bytes >= diqt_reduce_workspace_bytes(1, C), DIQT_E_WORKSPACE,

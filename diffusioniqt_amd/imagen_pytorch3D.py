@@ -308,14 +308,23 @@ class Block(nn.Module):
         self.factor = factor
         self.project = Conv3d(dim, dim_out, 3) if boundary else Conv3d(dim, dim_out, 3, padding=1)
 
-    def forward(self, x, scale_shift=None, residual=None, emit_stats=False):
-        """``emit_stats``: the conv epilogue also writes per-tile column sums of its output for the next GroupNorm / SE pool."""
+    def forward(self, x, scale_shift=None, residual=None, emit_stats=False, tap=False):
+        """``emit_stats``: the conv epilogue also writes per-tile column sums of its output for the next GroupNorm / SE pool.
+        ``tap``: also returns an alias of the input for its other consumer (ops.groupnorm_act): ``(y, x_alias)``."""
         gn = self.groupnorm
+        x_in = x
         if isinstance(gn, nn.GroupNorm):
-            x = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps)
+            x = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps, tap=tap)
+            if tap:
+                x, x_in = x
         else:
             assert scale_shift is None
             x = self.activation(x)
+        if tap:
+            return self._project(x, residual, emit_stats), x_in
+        return self._project(x, residual, emit_stats)
+
+    def _project(self, x, residual, emit_stats):
         if self.boundary:
             if not torch.is_grad_enabled():
                 # sampling: the conv reads each sub-volume's halo straight from its neighbours (no merged / re-split copies)
@@ -379,8 +388,16 @@ class BatchedTimeMLPs:
                 self.offs[id(l)] = (off, l.weight.shape[0])
                 off += l.weight.shape[0]
             self.key = key
+        if torch.is_grad_enabled():
+            # training: the same single launch with autograd (one backward launch set for all blocks, ops._BatchedLinearSmallFn)
+            if not BatchedTimeMLPs.train_batched:
+                return None
+            outs = ops.batched_linear_small(tc.activated(), self.w, self.b, self.linears)
+            return {id(l): o for l, o in zip(self.linears, outs)}
         out = ops.linear(tc.activated(), self.w, self.b)                              # ONE launch: [B, sum 2C_i]
         return {k: ops.SSView(out, off, n) for k, (off, n) in self.offs.items()}
+
+    train_batched = True       # False: per-block time MLPs when autograd records (A/B and tests)
 
 
 class ResnetBlock(nn.Module):
@@ -404,7 +421,9 @@ class ResnetBlock(nn.Module):
                 scale_shift = pre if pre is not None else self.time_mlp[1](time_emb.mish())
             else:
                 scale_shift = self.time_mlp(time_emb)
-        h = self.block1(x, emit_stats=True)                  # block2's GroupNorm statistics come from this conv's epilogue
+        # block2's GroupNorm statistics come from block1's conv epilogue; the residual branch reads x through block1's alias so that
+        # its gradient is added inside the GroupNorm backward (ops.groupnorm_act, tap)
+        h, x = self.block1(x, emit_stats=True, tap=True)
         res = self.res_conv(x)
         if isinstance(self.se, SE3D):
             h = self.block2(h, scale_shift=scale_shift, emit_stats=True)     # ... and the SE pooling from this one's
@@ -954,10 +973,9 @@ class Unet(nn.Module):
             x = self.init_conv(x)
 
         t = TimeCond(self.to_time_cond(self.to_time_hiddens(time.float().contiguous())))
-        if not torch.is_grad_enabled():
-            if getattr(self, '_time_mlps', None) is None:
-                self._time_mlps = BatchedTimeMLPs(m.time_mlp[1] for m in self.modules() if isinstance(m, ResnetBlock) and m.time_mlp is not None)
-            t.batched = self._time_mlps(t)
+        if getattr(self, '_time_mlps', None) is None:
+            self._time_mlps = BatchedTimeMLPs(m.time_mlp[1] for m in self.modules() if isinstance(m, ResnetBlock) and m.time_mlp is not None)
+        t.batched = self._time_mlps(t)
 
         hiddens = []
         last = len(self.downs)

@@ -41,8 +41,8 @@ class LayerNorm(nn.Module):
         assert not stable
         self.g = nn.Parameter(torch.ones(dim))
 
-    def forward(self, x, residual=None):
-        return ops.chan_layernorm(x, self.g, 1e-5, residual=residual)
+    def forward(self, x, residual=None, tap=False):
+        return ops.chan_layernorm(x, self.g, 1e-5, residual=residual, tap=tap)
 
 
 class ChanLayerNorm(nn.Module):
@@ -53,8 +53,8 @@ class ChanLayerNorm(nn.Module):
         assert not stable
         self.g = nn.Parameter(torch.ones(1, dim, 1, 1, 1))
 
-    def forward(self, x):
-        return ops.chan_layernorm(x, self.g, 1e-5)
+    def forward(self, x, tap=False):
+        return ops.chan_layernorm(x, self.g, 1e-5, tap=tap)
 
 
 class AffineLayerNorm(nn.LayerNorm):
@@ -100,9 +100,10 @@ class TokensOverSpaceTime(nn.Module):
 
     def forward(self, x, residual=None, **kwargs):
         B, F, H, W, C = x.shape
-        if residual is not None:                     # `fn(x) + residual`, added inside fn (Attention)
-            kwargs['residual'] = residual.reshape(B, F * H * W, -1)
-        return self.fn(x.reshape(B, F * H * W, C), **kwargs).reshape(B, F, H, W, -1)
+        tokens = x.reshape(B, F * H * W, C)
+        if residual is not None:                     # `fn(x) + residual`, added inside fn (Attention); `+ x` stays recognisable as such
+            kwargs['residual'] = tokens if residual is x else residual.reshape(B, F * H * W, -1)
+        return self.fn(tokens, **kwargs).reshape(B, F, H, W, -1)
 
 
 class TokensOverTime(nn.Module):
@@ -209,7 +210,10 @@ class Attention(nn.Module):
         assert mask is None and attn_bias is None
         G, n, _ = x.shape
         h, d = self.heads, self.dim_head
-        x = self.norm(x)
+        if residual is x:      # `attn(x) + x`: the skip reads x through the LayerNorm's alias (its gradient joins the LayerNorm backward)
+            x, residual = self.norm(x, tap=True)
+        else:
+            x = self.norm(x)
         q = self.to_q(x)                                                          # [G, n, h*d]
         kv = self.to_kv(x)                                                        # [G, n, 2d]  (k | v), shared by all heads
         extra = self.null_kv.reshape(1, 2 * d).expand(G, 2 * d)                   # null key/value row
@@ -291,8 +295,12 @@ class Block(nn.Module):
         self.activation = SiLU()
         self.project = Conv3d(dim, dim_out, 3, padding=1)
 
-    def forward(self, x, scale_shift=None, ignore_time=False, residual=None, emit_stats=False):
+    def forward(self, x, scale_shift=None, ignore_time=False, residual=None, emit_stats=False, tap=False):
+        """``tap``: also returns an alias of x for its other consumer (the ResnetBlock's residual branch; ops.groupnorm_act)."""
         gn = self.groupnorm
+        if tap:
+            x, alias = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_SILU, gn.eps, tap=True)
+            return self.project(x, ignore_time=ignore_time, residual=residual, want_stats=emit_stats), alias
         x = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_SILU, gn.eps)
         return self.project(x, ignore_time=ignore_time, residual=residual, want_stats=emit_stats)
 
@@ -338,7 +346,8 @@ class ResnetBlock(nn.Module):
             else:
                 scale_shift = self.time_mlp(time_emb)
         # block2's GroupNorm statistics come from the epilogue of block1's last conv (unless cross attention rewrites h in between)
-        h = self.block1(x, ignore_time=ignore_time, emit_stats=not exists(self.cross_attn))
+        # (the residual branch reads x through block1's alias: its gradient is added inside the GroupNorm backward)
+        h, x = self.block1(x, ignore_time=ignore_time, emit_stats=not exists(self.cross_attn), tap=True)
         if exists(self.cross_attn):
             assert exists(cond)
             h = ops.add(self.cross_attn(h, context=cond), h)
@@ -370,8 +379,8 @@ class TransformerBlock(nn.Module):
     def forward(self, x, context=None):
         for attn, ff in self.layers:
             x = attn(x, context=context, residual=x)                              # attn(x) + x in the attention's last LayerNorm
-            h = x
-            for layer in ff[:-1]:
+            h, x = ff[0](x, tap=True)                                             # ChanLayerNorm; the skip reads x through its alias
+            for layer in ff[1:-1]:
                 h = layer(h)
             x = ff[-1](h, residual=x)                                             # ff(x) + x in the last 1x1 conv's epilogue
         return x
@@ -643,10 +652,9 @@ class Unet3D(nn.Module):
         # every ResnetBlock's time_mlp starts with the same SiLU(t) (:716-719): evaluated once; on the sampling path the ~20 Linears run
         # as one launch over their concatenated weights
         t = TimeCond(t, ACT_SILU)
-        if not torch.is_grad_enabled():
-            if getattr(self, '_time_mlps', None) is None:
-                self._time_mlps = BatchedTimeMLPs(m.time_mlp[1] for m in self.modules() if isinstance(m, ResnetBlock) and m.time_mlp is not None)
-            t.batched = self._time_mlps(t)
+        if getattr(self, '_time_mlps', None) is None:
+            self._time_mlps = BatchedTimeMLPs(m.time_mlp[1] for m in self.modules() if isinstance(m, ResnetBlock) and m.time_mlp is not None)
+        t.batched = self._time_mlps(t)
 
         hiddens = []
         for _, init_block, resnet_blocks, attn_block, temporal_peg, temporal_attn, _, post_downsample in self.downs:

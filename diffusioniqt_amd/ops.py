@@ -278,7 +278,7 @@ def _conv_bwd_data_gn(dy, packed, Cout, k, pad, epad, gn):
     scale = shift = None
     cs = 0
     if gn.ss is not None:
-        scale, shift, cs = gn.ss.data_ptr(), gn.ss.data_ptr() + 4 * Cout, 2 * Cout
+        scale, shift, cs = gn.ss.data_ptr(), gn.ss.data_ptr() + 4 * Cout, gn.ss.stride(0)
     if TIMER.enabled:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -428,6 +428,71 @@ class _LinearSmallFn(Function):
         return dx, dw, db
 
 
+class _BatchedLinearSmallFn(Function):
+    """y_i = a W_i^T + b_i for n Linear layers that share the input a[M <= 64, K] (the time MLPs of a U-Net's ResnetBlocks,
+    imagen_pytorch3D.py:586-589 / imagen_video.py:716-719) as ONE launch over the concatenated weights, with autograd: the outputs are
+    column blocks of one [M, sum N_i] buffer, their gradients are written by the consumers (GroupNorm backward) into the same blocks of
+    one shared gradient buffer, and backward is one dx / dW / db launch set instead of three per layer plus a sum of n gradients of a."""
+    @staticmethod
+    def forward(ctx, a, wcat, bcat, gradbuf, sizes, *params):
+        _chk(a, wcat, bcat)
+        M, K = a.shape
+        N = wcat.shape[0]
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        _lib.call("diqt_linear_small_fwd", a, wcat, bcat, out, M, K, N, _stream())
+        ctx.save_for_backward(a, wcat)
+        ctx.gradbuf, ctx.sizes, ctx.has_bias = gradbuf, sizes, [b is not None for b in params[1::2]]
+        ctx.set_materialize_grads(False)
+        offs, o = [], 0
+        for n in sizes:
+            offs.append(o)
+            o += n
+        ctx.offs = offs
+        return tuple(out[:, o:o + n] for o, n in zip(offs, sizes))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        a, wcat = ctx.saved_tensors
+        M, K = a.shape
+        N = wcat.shape[0]
+        buf = ctx.gradbuf
+        used = [g is not None for g in grads]     # a layer whose output nobody consumed (mid_block) keeps grad None, like unbatched
+        for g, o, n in zip(grads, ctx.offs, ctx.sizes):
+            dst = buf[:, o:o + n]
+            if g is None:
+                dst.zero_()
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                dst.copy_(g)                    # a consumer that did not write in place (not the fused GroupNorm backward)
+        dx = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(wcat)
+        db = torch.empty(N, dtype=torch.float32, device=a.device)
+        n = _lib.query("diqt_linear_small_workspace_bytes", M, K, N)
+        ws = _workspace(n, a.device)
+        _lib.call("diqt_linear_small_bwd", a, wcat, buf, dx, dw, db, ws, n, M, K, N, _stream())
+        pg = []
+        for o, nn_, hb, u in zip(ctx.offs, ctx.sizes, ctx.has_bias, used):
+            pg.append(dw[o:o + nn_] if u else None)
+            pg.append(db[o:o + nn_] if (hb and u) else None)
+        return (dx, None, None, None, None, *pg)
+
+
+def batched_linear_small(a, wcat, bcat, linears):
+    """One launch for ``[l(a) for l in linears]`` (wcat / bcat: their concatenated weights / biases, rebuilt by the caller when a
+    parameter changes).  Returns the outputs as [M, N_i] column blocks; each carries ``_diqt_gradview``, its block of the shared
+    gradient buffer (ops.groupnorm_act's backward writes d scale/shift there)."""
+    sizes = tuple(l.weight.shape[0] for l in linears)
+    gradbuf = torch.empty((a.shape[0], wcat.shape[0]), dtype=torch.float32, device=a.device)
+    params = []
+    for l in linears:
+        params += [l.weight, l.bias]
+    outs = _BatchedLinearSmallFn.apply(a.contiguous(), wcat, bcat, gradbuf, sizes, *params)
+    o = 0
+    for t, n in zip(outs, sizes):
+        t._diqt_gradview = gradbuf[:, o:o + n]
+        o += n
+    return outs
+
+
 def linear(x, weight, bias=None):
     """x[..., Cin] @ weight[Cout, Cin]^T + bias: skinny kernel for <= 64 rows, otherwise the MFMA kernel (1x1x1 conv)."""
     Cout, Cin = weight.shape
@@ -481,7 +546,11 @@ def conv3d_direct(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), gro
 class _DwConvTemporalFn(Function):
     """Depthwise (3,1,1) temporal conv + bias (+ residual) on channels-last x[B,F,H,W,C] (the TemporalPEG of the pseudo-3D U-Net)."""
     @staticmethod
-    def forward(ctx, x, weight, bias, left, res):
+    def forward(ctx, x, weight, bias, left, res, res_is_x=False):
+        """res_is_x: the residual IS the input (`conv(x) + x`, the TemporalPEG): one autograd input, and the backward-data launch adds
+        dy to its own result -- otherwise autograd sums the two gradients of x in a separate pass."""
+        if res_is_x:
+            res = x
         _chk(x, weight, bias, res)
         B, F, H, W, C = x.shape
         kt = weight.shape[2]
@@ -489,7 +558,8 @@ class _DwConvTemporalFn(Function):
         y = torch.empty_like(x)
         _lib.call("diqt_dwconv_temporal_fwd", x, w2, bias, res, y, B, F, H * W, C, kt, int(left), 0, _stream())
         ctx.save_for_backward(x, w2)
-        ctx.cfg = (B, F, H * W, C, kt, int(left), bias is not None, res is not None, tuple(weight.shape))
+        ctx.cfg = (B, F, H * W, C, kt, int(left), bias is not None, res is not None and not res_is_x, tuple(weight.shape))
+        ctx.res_is_x = res_is_x
         return y
 
     @staticmethod
@@ -500,7 +570,7 @@ class _DwConvTemporalFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.call("diqt_dwconv_temporal_fwd", dy, w2, None, None, dx, B, F, P, C, kt, kt - 1 - left, 1, _stream())
+            _lib.call("diqt_dwconv_temporal_fwd", dy, w2, None, dy if ctx.res_is_x else None, dx, B, F, P, C, kt, kt - 1 - left, 1, _stream())
         if ctx.needs_input_grad[1]:
             n = _lib.query("diqt_dwconv_temporal_bwd_weight_workspace_bytes", B, F, P, C, kt)
             ws = _workspace(n, x.device)
@@ -508,7 +578,7 @@ class _DwConvTemporalFn(Function):
             _lib.call("diqt_dwconv_temporal_bwd_weight", x, dy, dwb, ws, n, B, F, P, C, kt, left, _stream())
             dw = dwb[:kt].t().reshape(wshape)
             db = dwb[kt].clone() if has_bias else None
-        return dx, dw, db, None, (dy if has_res else None)
+        return dx, dw, db, None, (dy if has_res else None), None
 
 
 def dwconv_temporal_ok(x, weight, groups, stride=(1, 1, 1)):
@@ -519,6 +589,8 @@ def dwconv_temporal_ok(x, weight, groups, stride=(1, 1, 1)):
 
 def dwconv_temporal(x, weight, bias, left, residual=None):
     """nn.Conv3d(C, C, (3,1,1), groups=C) on frames padded with ``left`` zero frames in front (2: causal, 1: symmetric), + residual."""
+    if residual is x:
+        return _DwConvTemporalFn.apply(x.contiguous(), weight, bias, int(left), None, True)
     return _DwConvTemporalFn.apply(x.contiguous(), weight, bias, int(left), residual.contiguous() if residual is not None else None)
 
 
@@ -536,8 +608,15 @@ class SSView:
 
 class _GnActFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, groups, act, eps, pre=None, gn_out=None):
-        _chk(x, gamma, beta, ss.base if isinstance(ss, SSView) else ss)
+    def forward(ctx, x, gamma, beta, ss, groups, act, eps, pre=None, gn_out=None, tap=False, ss_grad=None):
+        """tap=True: also returns x itself as a second output.  The caller routes x's OTHER consumer (the residual branch of a
+        ResnetBlock) through that alias, so autograd sees one consumer of x and hands the branch's gradient to backward(), where it is
+        added inside the dx kernel instead of by a separate elementwise pass."""
+        _chk(x, gamma, beta, ss.base if isinstance(ss, SSView) else None)
+        if ss is not None and not isinstance(ss, SSView):          # [B, 2C] rows, possibly a column block of a wider buffer
+            assert ss.is_cuda and ss.dtype == torch.float32 and ss.dim() == 2 and ss.stride(1) == 1, "scale/shift rows must be fp32 HIP tensors"
+        ctx.tap = tap
+        ctx.set_materialize_grads(False)
         B, C = x.shape[0], x.shape[-1]
         rows = x.numel() // (B * C)
         mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
@@ -560,19 +639,26 @@ class _GnActFn(Function):
             _lib.call("diqt_gn_act_fwd", x, mean, rstd, gamma, beta, scale, shift, cs, y, B, rows, C, groups, act, s)
             return y
         if ss is not None:
-            assert ss.shape == (B, 2 * C), f"scale/shift embedding must be [B, 2C], got {tuple(ss.shape)}"
-            scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, 2 * C
+            assert ss.shape == (B, 2 * C) and ss.stride(1) == 1, f"scale/shift embedding must be [B, 2C] rows, got {tuple(ss.shape)}"
+            scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, ss.stride(0)
         _lib.call("diqt_gn_act_fwd", x, mean, rstd, gamma, beta, scale, shift, cs, y, B, rows, C, groups, act, s)
+        # a column block of the batched time-MLP output (batched_time_mlps): its gradient is written straight into the block's place in
+        # the shared gradient buffer
+        ctx.ss_grad = ss_grad
         ctx.save_for_backward(x, gamma, beta, ss, mean, rstd)
         ctx.cfg = (B, rows, C, groups, act)
         if gn_out is not None and x.dim() == 5:
             gn_out.append(GnCtx(x, mean, rstd, gamma, beta, ss, groups, act))
-        return y
+        return (y, x) if tap else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dtap=None):
         x, gamma, beta, ss, mean, rstd = ctx.saved_tensors
         B, rows, C, groups, act = ctx.cfg
+        if dy is None:                      # only the alias was used downstream
+            return dtap, None, None, None, None, None, None, None, None, None, None
+        if dtap is not None:
+            dtap = dtap.contiguous()
         # partial sums from the producer of dy -- valid only for the very tensor they were computed for (autograd adds other
         # branches' gradients in place: the version counter tells)
         pre = getattr(dy, "_diqt_gnbwd", None)
@@ -586,29 +672,36 @@ class _GnActFn(Function):
         dss = None
         cs = 0
         if ss is not None:
-            dss = torch.empty_like(ss)
-            scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, 2 * C
+            cs = ss.stride(0)
+            dss = ctx.ss_grad if ctx.ss_grad is not None else torch.empty_strided(ss.shape, ss.stride(), dtype=ss.dtype, device=ss.device)
+            assert dss.stride() == ss.stride()
+            scale, shift = ss.data_ptr(), ss.data_ptr() + 4 * C
             dscale, dshift = dss.data_ptr(), dss.data_ptr() + 4 * C
         ws, n = _reduce_ws(B, C, x.device)
-        if pre is not None and pre[0].shape == (B, pre[1], 2, C):
-            # the conv behind this GroupNorm reduced (sum dz, sum dz xhat) in the epilogue of its backward-data pass
-            _lib.call("diqt_gn_act_bwd_from_partials", x, dy, pre[0], pre[1], mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
-                      dscale, dshift, ws, n, B, rows, C, groups, act, _stream())
-        else:
-            _lib.call("diqt_gn_act_bwd", x, dy, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta, dscale,
-                      dshift, ws, n, B, rows, C, groups, act, _stream())
-        return dx, dgamma, dbeta, dss, None, None, None, None, None
+        # pre: the conv behind this GroupNorm reduced (sum dz, sum dz xhat) in the epilogue of its backward-data pass; dtap: the
+        # gradient of x's other consumer, added in the dx pass
+        part, nblk = (pre[0], pre[1]) if pre is not None and pre[0].shape == (B, pre[1], 2, C) else (None, 0)
+        _lib.call("diqt_gn_act_bwd_ex", x, dy, part, nblk, dtap, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
+                  dscale, dshift, ws, n, B, rows, C, groups, act, _stream())
+        return dx, dgamma, dbeta, dss, None, None, None, None, None, None, None
 
 
-def groupnorm_act(x, gamma, beta, scale_shift=None, groups=8, act=ACT_MISH, eps=1e-5):
-    """act(GN(x) * (scale+1) + shift) with scale_shift = one [B, 2C] embedding (scale first)."""
+def groupnorm_act(x, gamma, beta, scale_shift=None, groups=8, act=ACT_MISH, eps=1e-5, tap=False):
+    """act(GN(x) * (scale+1) + shift) with scale_shift = one [B, 2C] embedding (scale first).
+    ``tap=True`` returns ``(y, x_alias)``: route x's other consumer through ``x_alias`` (see _GnActFn.forward)."""
     if not torch.is_grad_enabled() or isinstance(scale_shift, SSView):
-        return _GnActFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None))
+        y = _GnActFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None))
+        return (y, x) if tap else y
     holder = []
-    y = _GnActFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None), holder)
+    use_tap = tap and x.requires_grad
+    ss_grad = getattr(scale_shift, "_diqt_gradview", None)     # a block of the batched time-MLP output: its place in the shared gradient buffer
+    if scale_shift is not None and ss_grad is None and not scale_shift.is_contiguous():
+        scale_shift = scale_shift.contiguous()
+    out = _GnActFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None), holder, use_tap, ss_grad)
+    y, alias = out if use_tap else (out, x)
     if holder:
         y._diqt_gnctx = holder[0]           # read by conv3d on this exact tensor (Block: GN -> act -> conv)
-    return y
+    return (y, alias) if tap else y
 
 
 class _ActFn(Function):
@@ -639,8 +732,11 @@ def mish(x):
 
 class _ChanLayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, g, b, eps, res=None):
+    def forward(ctx, x, g, b, eps, res=None, tap=False):
+        """tap: as _GnActFn.forward -- x comes back as a second output for its other consumer (the `+ x` of the block)."""
         _chk(x, g, b, res)
+        ctx.tap = tap
+        ctx.set_materialize_grads(False)
         C = x.shape[-1]
         rows = x.numel() // C
         y = torch.empty_like(x)
@@ -650,11 +746,13 @@ class _ChanLayerNormFn(Function):
         ctx.save_for_backward(x, g, mean, rstd)
         ctx.has_bias = b is not None
         ctx.has_res = res is not None
-        return y
+        return (y, x) if tap else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dtap=None):
         x, g, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dtap, None, None, None, None, None
         C = x.shape[-1]
         rows = x.numel() // C
         dx = torch.empty_like(x)
@@ -662,18 +760,24 @@ class _ChanLayerNormFn(Function):
         db = torch.empty_like(g) if ctx.has_bias else None
         ws, n = _reduce_ws(1, C, x.device)
         dy = dy.contiguous()
-        _lib.call("diqt_chan_layernorm_bwd", x, dy, g, mean, rstd, dx, dg, db, ws, n, rows, C, _stream())
-        return dx, dg, db, None, (dy if ctx.has_res else None)
+        if dtap is not None:
+            dtap = dtap.contiguous()
+        _lib.call("diqt_chan_layernorm_bwd_ex", x, dy, dtap, g, mean, rstd, dx, dg, db, ws, n, rows, C, _stream())
+        return dx, dg, db, None, (dy if ctx.has_res else None), None
 
 
-def chan_layernorm(x, g, eps=1e-5, bias=None, residual=None):
+def chan_layernorm(x, g, eps=1e-5, bias=None, residual=None, tap=False):
     """LayerNorm over the channel (last) axis; g (and the optional bias) are any tensors with C elements.  ``residual`` (same shape as
-    x) is added to the result in the same pass."""
+    x) is added to the result in the same pass.  ``tap=True`` returns ``(y, x_alias)`` (see _GnActFn.forward)."""
     if residual is not None:
         assert residual.shape == x.shape, (tuple(residual.shape), tuple(x.shape))
         residual = residual.contiguous()
-    y = _ChanLayerNormFn.apply(x.contiguous(), g.reshape(-1), bias.reshape(-1) if bias is not None else None, eps, residual)
-    return y.view(x.shape)
+    xc = x.contiguous()
+    use_tap = tap and torch.is_grad_enabled() and xc.requires_grad
+    out = _ChanLayerNormFn.apply(xc, g.reshape(-1), bias.reshape(-1) if bias is not None else None, eps, residual, use_tap)
+    y, alias = out if use_tap else (out, x)
+    y = y.view(x.shape)
+    return (y, alias.view(x.shape)) if tap else y
 
 
 # --------------------------------------------------------------------------------------------

@@ -214,6 +214,13 @@ int diqt_conv3d_fwd_gnbwd(const float* x, const float* packed, float* y, float* 
                           const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
                           int cond_stride, int G, int act, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
                           int ph, int pw, int epd, int eph, int epw, void* stream);
+/* As diqt_gn_act_bwd (partials == NULL) / diqt_gn_act_bwd_from_partials, plus dx_add (optional, same shape as x): dx = GroupNorm
+ * backward + dx_add -- the gradient that reaches x through its second consumer (ResnetBlock: x feeds block1 AND the residual branch,
+ * imagen_pytorch3D.py:601-614, imagen_video.py:745-770), so the framework's separate sum over the two branches disappears.          */
+int diqt_gn_act_bwd_ex(const float* x, const float* dy, const float* partials, int nblk, const float* dx_add, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
+                       int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
+                       size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream);
 int diqt_gn_act_bwd_from_partials(const float* x, const float* dy, const float* partials, int nblk, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, const float* scale, const float* shift, int cond_stride,
                                   float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
@@ -243,6 +250,11 @@ int diqt_dwconv_temporal_bwd_weight(const float* x, const float* dy, float* dwb,
 int diqt_chan_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean,
                             const float* rstd, float* dx, float* dg, float* db, void* workspace,
                             size_t workspace_bytes, int rows, int C, void* stream);
+/* ... plus dx_add (optional, same shape as x): dx = LayerNorm backward + dx_add, the residual branch's gradient of `fn(LN(x)) + x`
+ * (Attention / ChanFeedForward blocks, imagen_video.py:410-525, 994-1029) summed in the same pass.                                   */
+int diqt_chan_layernorm_bwd_ex(const float* x, const float* dy, const float* dx_add, const float* g, const float* mean,
+                               const float* rstd, float* dx, float* dg, float* db, void* workspace,
+                               size_t workspace_bytes, int rows, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise activations (n floats) — nn.Mish / SiLU / GELU / ReLU / Sigmoid call sites above.

@@ -228,6 +228,36 @@ def test_unet_config2_at_32cubed_on_the_headline_conv_kernel_vs_oracle(B, kid):
     assert rel <= 2e-5, rel
 
 
+def test_batched_time_mlp_backward_and_residual_taps_equal_the_unfused_autograd_graph():
+    """Training path: the ~20 time-MLP Linears run as one launch with ONE backward launch set (ops._BatchedLinearSmallFn: the GroupNorm
+    backward writes d scale/shift into its block of a shared buffer), and a ResnetBlock's residual branch reads x through the GroupNorm's
+    alias so that its gradient is added inside the dx kernel.  Against the same network with per-block time MLPs: identical loss bits,
+    every gradient equal up to the summation order of the time-embedding gradient, the same set of parameters without gradient."""
+    from diffusioniqt_amd.imagen_pytorch3D import BatchedTimeMLPs
+    g = load_golden('unetA_tiny')
+    unet, sd, cfg = build(g, 0)
+    unet.train()
+    args = (T(g['x']).to(DEV), T(g['times']).to(DEV), T(g['log_snr']).to(DEV))
+    lr = T(g['lowres']).to(DEV)
+    res = {}
+    for mode in (True, False):
+        BatchedTimeMLPs.train_batched = mode
+        try:
+            unet.zero_grad(set_to_none=True)
+            y = unet(*args, lowres_cond_img=lr)
+            (y ** 2).mean().backward()
+        finally:
+            BatchedTimeMLPs.train_batched = True
+        res[mode] = (y.detach().clone(), {n: (p.grad.clone() if p.grad is not None else None) for n, p in unet.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0])
+    for n, ga in res[True][1].items():
+        gb = res[False][1][n]
+        assert (ga is None) == (gb is None), n
+        if ga is not None:
+            close(ga, gb, 2e-5, f"grad {n}: batched vs per-block time MLPs")
+    assert sum(v is None for v in res[True][1].values()) == len(g['unused'])
+
+
 _C2_GRAD_ORACLE = {}
 
 

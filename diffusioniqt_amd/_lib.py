@@ -42,6 +42,10 @@ PROTOTYPES = {
     "diqt_groupnorm_stats": (I, [P, P, P, P, Z, I, I, I, I, F, P]),
     "diqt_gn_act_fwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "diqt_gn_act_bwd": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "diqt_gn_coef_from_partials": (I, [P, I, I, P, P, P, P, I, P, P, P, I, I, I, F, P]),
+    "diqt_gn_coef": (I, [P, P, P, P, P, P, I, P, I, I, I, P]),
+    "diqt_conv3d_fwd_gn_supported": (I, [I] * 16),
+    "diqt_conv3d_fwd_gn": (I, [P, P, P, P, P, P, P, Z, P, I] + [I] * 15 + [P]),
     "diqt_gn_act_bwd_ex": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_chan_layernorm_bwd_ex": (I, [P, P, P, P, P, P, P, P, P, P, Z, I, I, P]),
     "diqt_gn_act_bwd_from_partials": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),

@@ -24,7 +24,17 @@ struct F9Geom {
     const float *gx, *gmean, *grstd, *ggamma, *gbeta, *gscale, *gshift;
     int gG, gcs, gact;
     const struct F9GnParams* gnp;
+    // GroupNorm-apply prologue (sampling path; the GNA instantiations): the input x is the RAW GroupNorm input and every halo piece is
+    // replaced in the LDS, right after it landed, by act(A[b][c] x + Bc[b][c]) -- the pass of gn_act_fwd_kernel over the tensor (a read
+    // and a write of the whole activation per conv) disappears.  gcoef = [2][B][Cin] floats: A, then Bc (diqt_gn_coef*).
+    const float* gcoef;
+    int gnaAct;                  // DIQT_ACT_MISH / DIQT_ACT_SILU, 0: none
 };
+
+// which (F9Geom::variant, activation) pairs have a GroupNorm-apply instantiation: Mish on the 3x3x3 tiles, SiLU on the (1,3,3) ones
+inline bool fwd9_gna_available(int variant, int act) {
+    return (act == 1 /* DIQT_ACT_MISH */ && (variant == 0 || variant == 1)) || (act == 2 /* DIQT_ACT_SILU */ && variant >= 2 && variant <= 4);
+}
 
 // maySplit: the caller has a workspace for split-K slabs (g.ksplit * output elements floats when g.ksplit > 1; the kernel then gets
 // the slab base as y and no bias / residual / statistics).

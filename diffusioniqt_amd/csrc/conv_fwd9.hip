@@ -69,6 +69,7 @@ bool fwd9_plan(F9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int 
     if (xb >= (1ull << 30) || yb >= (1ull << 30) || wb >= (1ull << 30)) return false;
     g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.wBytes = (unsigned)wb; g.stats = nullptr;
     g.gx = g.gmean = g.grstd = g.ggamma = g.gbeta = g.gscale = g.gshift = nullptr; g.gG = 1; g.gcs = 0; g.gact = 0; g.gnp = nullptr;
+    g.gcoef = nullptr; g.gnaAct = 0;
     // un-split launches first (the statistics query of the consumer's GroupNorm plans with maySplit = false and must see the same tiles)
     if (k333) {
         if (f9_try<F9_333_512>(g, lds, grid, mode, false)) { g.variant = 0; return true; }
@@ -101,6 +102,16 @@ int fwd9_launch(const float* x, const float* packed, const float* bias, const fl
                 unsigned grid, void* stream) {
     if (g.gx) return g.variant == 0 ? fwd9_launch_d(x, packed, bias, residual, y, g, lds, grid, stream)
                                     : fwd9_launch_e(x, packed, bias, residual, y, g, lds, grid, stream);
+    if (g.gcoef) {
+        switch (g.variant) {
+            case 0: return fwd9_launch_f(x, packed, bias, residual, y, g, lds, grid, stream);
+            case 1: case 4: return fwd9_launch_g(x, packed, bias, residual, y, g, lds, grid, stream);
+            case 2: return fwd9_launch_h(x, packed, bias, residual, y, g, lds, grid, stream);
+            case 3: return fwd9_launch_i(x, packed, bias, residual, y, g, lds, grid, stream);
+        }
+        set_error("conv3d_fwd(v9, GroupNorm-apply prologue): no variant %d", g.variant);
+        return DIQT_E_UNSUPPORTED;
+    }
     switch (g.variant) {
         case 0: return f9_launch<F9_333_512>(x, packed, bias, residual, y, g, lds, grid, stream);
         case 2: case 3: case 4: return fwd9_launch_b(x, packed, bias, residual, y, g, lds, grid, stream);

@@ -58,6 +58,10 @@ __device__ __forceinline__ float f9_act_grad(float x, int act) {
     return s * (1.f + x * (1.f - s));
 }
 
+// end of a chunk in the GroupNorm-apply instantiations: the in-place transform's LDS stores have to be complete, too, before the barrier
+// publishes the image (no fragment read is in flight across a chunk boundary: the first tap of a chunk is read cold)
+__device__ __forceinline__ void f9_chunk_end_gna() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // s_waitcnt vmcnt(n) + s_barrier with nothing else attached (n is a constant after unrolling; the asm needs a literal)
 __device__ __forceinline__ void f9_step_end(int n) {
 #define F9_WB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory"); break;
@@ -71,11 +75,17 @@ __device__ __forceinline__ void f9_step_end(int n) {
 
 // GNB: the GroupNorm-backward epilogue (F9Geom::gx).  A separate instantiation: behind a runtime flag in the plain kernel it cost the
 // forward launches 10 % (448 vs 405 us on the dominant one); the epilogue itself is 8.6k instructions per tile (activation derivative).
-template <class C, bool GNB>
+// GNA (0: none, DIQT_ACT_MISH, DIQT_ACT_SILU): the GroupNorm-apply prologue (F9Geom::gcoef) -- x is the raw GroupNorm input; a wave
+// rewrites each of ITS halo pieces in place, act(A x + Bc) with the per-(batch, channel) coefficients, two steps after it issued the
+// piece's DMA (landed by then: the counted vmcnt of the step in between covers it; lane-private 16 bytes, so no barrier is involved
+// until the chunk's last one).  Padding voxels (out-of-range pieces: the DMA wrote zeros) stay zero.  The pieces of the next chunk are
+// issued over the first NSTEP - 2 steps so that the last ones can still be rewritten before the chunk ends.
+template <class C, bool GNB, int GNA = 0>
 __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias, const float* __restrict__ residual,
                                                            float* __restrict__ y, F9Geom g) {
-    constexpr int NSPREAD = C::NSTEP > 1 ? C::NSTEP - 1 : 1;                  // steps that issue halo pieces of the next chunk
+    static_assert(!(GNB && GNA) && (!GNA || C::NSTEP >= 3), "GroupNorm-apply prologue: forward launches of filters with >= 5 taps");
+    constexpr int NSPREAD = GNA ? C::NSTEP - 2 : (C::NSTEP > 1 ? C::NSTEP - 1 : 1);   // steps that issue halo pieces of the next chunk
     auto nh_in_step = [](int s_) constexpr { int n_ = 0; for (int r = 0; r < C::NPH; ++r) n_ += (r * NSPREAD / C::NPH == s_) ? 1 : 0; return n_; };
     constexpr int T = C::T, NSTEP = C::NSTEP, HB = C::HB, NPH = C::NPH, NVB = C::NVB, HH = C::HH, HWd = C::HWd, HV = C::HV;
     constexpr int CH = F9_CH, ROWB = F9_ROWB, WTAP = F9_WTAP, WSLOT = F9_WSLOT, NWS = F9_NWS;
@@ -123,6 +133,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
     const int Dm1 = g.D - 1, Hm1 = g.H - 1, Wm1 = g.W - 1;
     int tb, d0, h0, w0;                                    // tile being computed
     int bz, by, bxx;                                       // tile whose halo is being fetched (origin minus padding) ...
+    int fb = 0;                                            // ... and its batch entry (GroupNorm-apply prologue)
     unsigned baseX = 0, deadX = OOB;                       // ... its byte base, and 0x80000000 when there is none
     auto tile_of = [&](unsigned Lt, int& b_, int& d_, int& h_, int& w_) __attribute__((always_inline)) {
         int mt = (int)(Lt / g.nNt);
@@ -137,6 +148,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
         bz = d_ - g.pd; by = h_ - g.ph; bxx = w_ - g.pw;
         baseX = (unsigned)((((b_ * g.D + bz) * g.H + by) * g.W + bxx) * g.Cin) * 4u;
         deadX = live ? 0u : OOB;
+        if constexpr (GNA != 0) fb = b_;
     };
     auto dma_h = [&](int r, unsigned hbuf, int c16) __attribute__((always_inline)) {     // r static
         const unsigned p = posH[r];
@@ -144,6 +156,74 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
         const unsigned m = (unsigned)(iz | iy | ix) | (unsigned)((Dm1 - iz) | (Hm1 - iy) | (Wm1 - ix)) | (p << 7) | deadX;
         const unsigned voff = (baseX + relH[r] + (unsigned)c16 * ROWB) | (m & OOB);
         f9_dma(rs_x, hbuf + (unsigned)(wave + 4 * r) * 1024u, voff);
+    };
+
+    // ---- GroupNorm-apply prologue: coefficients of the fetched (batch entry, chunk) for this lane's channel quad, the in-place rewrite ----
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.gcoef), 0, GNA ? (int)(2u * (unsigned)g.B * (unsigned)g.Cin * 4u) : 0, 0x00020000);
+    f32x4v cA = {0.f, 0.f, 0.f, 0.f}, cB = {0.f, 0.f, 0.f, 0.f};
+    auto gna_coef = [&](int c16) __attribute__((always_inline)) {
+        const unsigned off = ((unsigned)(fb * g.Cin + c16 * CH) + (unsigned)(lane & 3) * 4u) * 4u;
+        cA = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 0, 0));
+        cB = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_c, off + (unsigned)(g.B * g.Cin) * 4u, 0, 0));
+    };
+    auto gna_mask = [&](int r) __attribute__((always_inline)) -> bool {                // r static: is this lane's piece r inside the volume?
+        const unsigned p = posH[r];
+        const int iz = bz + (int)(p & 255u), iy = by + (int)((p >> 8) & 255u), ix = bxx + (int)((p >> 16) & 255u);
+        const unsigned m = (unsigned)(iz | iy | ix) | (unsigned)((Dm1 - iz) | (Hm1 - iy) | (Wm1 - ix)) | (p << 7) | deadX;
+        return !(m & OOB);
+    };
+    auto gna_ptr = [&](int r, int himg) __attribute__((always_inline)) -> f32x4v* {
+        return reinterpret_cast<f32x4v*>(smem9 + himg * HB + (wave + 4 * r) * 1024 + lane * 16);
+    };
+    // one element of a piece: hardware reciprocal (1 ulp) instead of act_fwd's IEEE division (~10 instructions) -- this arithmetic
+    // shares the issue slots between the MFMAs of a wave that has the SIMD to itself
+    auto gna_elem = [&](float xv, float a, float b, bool live) __attribute__((always_inline)) -> float {
+        const float z = a * xv + b;
+        float r;
+        if constexpr (GNA == DIQT_ACT_MISH) {
+            const float n = __expf(fminf(z, 20.f));
+            const float mm = n * (n + 2.f);
+            r = z > 20.f ? z : z * (mm * __builtin_amdgcn_rcpf(mm + 2.f));
+        } else {
+            r = z * __builtin_amdgcn_rcpf(1.f + __expf(-z));
+        }
+        return live ? r : 0.f;
+    };
+    auto gna_xform = [&](int r, int himg) __attribute__((always_inline)) {           // whole piece at once (prologue); r static
+        f32x4v* q = gna_ptr(r, himg);
+        f32x4v v = *q;
+        const bool live = gna_mask(r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gna_elem(v[e], cA[e], cB[e], live);
+        *q = v;
+    };
+    // Inside the main loop the rewrite of a step's pieces (those issued two steps before) is cut into SLICES that the step's tap
+    // loops place between their MFMA groups (F9_MMX): slice 0 reads the pieces back, the elements follow one or a few per slice, a
+    // piece is stored with its last element.  (In one block in front of the step's MFMAs the same instructions left the matrix pipe
+    // idle for ~1k cycles per step: +7 % on the dominant launch, more than the elementwise pass they replace.)
+    constexpr int GNA_MAXP = (NPH + NSPREAD - 1) / NSPREAD + 1;                      // pieces rewritten per step, at most
+    auto gna_np = [](int s_) constexpr { int n_ = 0; for (int r = 0; r < C::NPH; ++r) n_ += (s_ >= 2 && r * NSPREAD / C::NPH == s_ - 2) ? 1 : 0; return n_; };
+    auto gna_piece = [](int s_, int p_) constexpr { int c_ = 0; for (int r = 0; r < C::NPH; ++r) if (s_ >= 2 && r * NSPREAD / C::NPH == s_ - 2) { if (c_ == p_) return r; ++c_; } return 0; };
+    f32x4v gxv[GNA ? GNA_MAXP : 1];
+    bool glive[GNA ? GNA_MAXP : 1];
+    auto gna_slice = [&](int s_, int k, int ns, int himg) __attribute__((always_inline)) {   // s_, k, ns static
+        const int np = gna_np(s_);
+        if (np == 0) return;
+        if (k == 0) {
+#pragma unroll
+            for (int p_ = 0; p_ < GNA_MAXP; ++p_)
+                if (p_ < np) { gxv[p_] = *gna_ptr(gna_piece(s_, p_), himg); glive[p_] = gna_mask(gna_piece(s_, p_)); }
+            return;
+        }
+        // element j (piece j / 4, component j % 4) goes to slice 1 + j (ns - 1) / (4 np)
+#pragma unroll
+        for (int j = 0; j < 4 * GNA_MAXP; ++j) {
+            if (j < 4 * np && 1 + j * (ns - 1) / (4 * np) == k) {
+                const int p_ = j / 4, e = j % 4;
+                gxv[p_][e] = gna_elem(gxv[p_][e], cA[e], cB[e], glive[p_]);
+                if (e == 3) *gna_ptr(gna_piece(s_, p_), himg) = gxv[p_];
+            }
+        }
     };
 
     f32x16 acc[NVB][2];
@@ -179,7 +259,12 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
     dma_w(cBeg, 0, wringBase, 0); dma_w(cBeg, 1, wringBase, 1);
     dma_w(cBeg, 2, wringBase + WSLOT, 0);
     if (3 < T) dma_w(cBeg, 3, wringBase + WSLOT, 1);
+    if constexpr (GNA != 0) gna_coef(cBeg);
     __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0)
+    if constexpr (GNA != 0) {
+#pragma unroll
+        for (int r = 0; r < NPH; ++r) gna_xform(r, 0);
+    }
     __syncthreads();
 
     int wcur = 0, hcur = 0;
@@ -190,6 +275,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
             const bool wrap = c + 1 == cEnd;
             const int cNext = wrap ? cBeg : c + 1;
             if (wrap) set_fetch(L + Gn, !lastTile);        // from here on the fetches are the next tile's first chunk (or dead)
+            if constexpr (GNA != 0) gna_coef(cNext);       // in front of the chunk's DMAs: landed with the first step's counted wait
             const unsigned hbufN = ldsBase + (unsigned)(hcur ^ 1) * HB;
             const char* hb[NVB];
 #pragma unroll
@@ -219,6 +305,27 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
         }                                                                                                            \
         __builtin_amdgcn_sched_group_barrier(0x008, 16 * NVB - (2 * NVB + 4) * (NVB == 4 ? 5 : 3), 0);              \
     } while (0)
+// GroupNorm-apply instantiations: the MFMAs of tap (Av, Bv) in groups of GS; behind group u the u-th fragment read of the NEXT tap
+// (k-group 0 of every block first: needed first) and slice SL0 + u of the rewrite; sched_barrier(0) keeps the groups apart
+#define F9_MMX(Av, Bv, An, Bn, DORD, TAPN, WSN, TISN, SL0)                                                           \
+    do {                                                                                                             \
+        const char* wb_ = smem9 + 2 * HB + (WSN) * WSLOT + (TISN) * WTAP + bLane;                                    \
+        _Pragma("unroll") for (int u = 0; u <= NG; ++u) {                                                            \
+            _Pragma("unroll") for (int m = u * GS; m < (u == NG ? 16 * NVB : (u + 1) * GS); ++m) {                   \
+                const int ch = m % 2, vb = (m / 2) % NVB, e = (m / (2 * NVB)) % 4, q = m / (8 * NVB);                \
+                acc[vb][ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(Av[vb][q][e], Bv[ch][q][e], acc[vb][ch], 0, 0, 0);   \
+            }                                                                                                        \
+            if (u < NG) {                                                                                            \
+                if (DORD) {                                                                                          \
+                    const int q = u / (NVB + 2), j = u % (NVB + 2);                                                  \
+                    if (j < NVB) An[j][q] = *reinterpret_cast<const f32x4v*>(hb[j] + C::tapoff(TAPN) * ROWB + q * 32);   \
+                    else Bn[j - NVB][q] = *reinterpret_cast<const f32x4v*>(wb_ + (j - NVB) * 32 * ROWB + q * 32);    \
+                }                                                                                                    \
+                gna_slice(s, (SL0) + u, ns, hcur ^ 1);                                                               \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+    } while (0)
             F9_RD(A0, B0, 0, wcur, 0);                     // cold read of the chunk's first tap (prefetched across chunks would be the next step)
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
@@ -236,7 +343,18 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
                         if (r * NSPREAD / NPH == s) dma_h(r, hbufN, cNext);         // but the last (whose end is the chunk's end)
                 }
                 // ---- taps 2s, 2s + 1 ----
-                if (2 * s + 1 < T) {
+                if constexpr (GNA != 0) {
+                    // the same taps with the interleave written out: per group of MFMAs one fragment read of the next tap and one
+                    // slice of the rewrite of the pieces issued two steps ago (landed: the previous step's counted wait), fenced
+                    constexpr int NG = 2 * NVB + 4, GS = NVB == 4 ? 5 : 3;
+                    const int two = 2 * s + 1 < T ? 1 : 0, ns = NG * (1 + two);
+                    if (two) {
+                        F9_MMX(A0, B0, A1, B1, true, 2 * s + 1, wcur, 1, 0);
+                        F9_MMX(A1, B1, A0, B0, s + 1 < NSTEP, 2 * s + 2, wnext, 0, NG);
+                    } else {
+                        F9_MMX(A0, B0, A1, B1, false, 0, wcur, 0, 0);
+                    }
+                } else if (2 * s + 1 < T) {
                     F9_RD(A1, B1, 2 * s + 1, wcur, 1);
                     F9_MM(A0, B0);
                     if (s + 1 < NSTEP) F9_RD(A0, B0, 2 * s + 2, wnext, 0);
@@ -249,11 +367,13 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
                 // weights in program order: loads retire in order) may stay in flight for another step -- `vmcnt(0)` here made every
                 // piece's HBM latency (~3 us under load) the step's problem.  Raw s_barrier: __syncthreads() would bring its own
                 // vmcnt(0) lgkmcnt(0), which also drains the fragment reads prefetched for the next step.
-                f9_step_end(s + 1 == NSTEP ? 0 : nh_in_step(s));
+                if (GNA != 0 && s + 1 == NSTEP) f9_chunk_end_gna();
+                else f9_step_end(s + 1 == NSTEP ? 0 : nh_in_step(s));
                 wcur = wnext;
             }
 #undef F9_RD
 #undef F9_MM
+#undef F9_MMX
             hcur ^= 1;
         }
         // ---- epilogue of the tile: D[row = voxel][col = co]; voxel of (block vb, register i, lane half): plane bd, row bh4 + (i >> 2),
@@ -346,9 +466,9 @@ __global__ __launch_bounds__(256, 1) void conv_fwd9_kernel(const float* __restri
     }
 }
 
-template <class C, bool GNB = false> static int f9_launch(const float* x, const float* packed, const float* bias, const float* residual, float* y,
+template <class C, bool GNB = false, int GNA = 0> static int f9_launch(const float* x, const float* packed, const float* bias, const float* residual, float* y,
                                         const F9Geom& g, size_t lds, unsigned grid, void* stream) {
-    auto kern = conv_fwd9_kernel<C, GNB>;
+    auto kern = conv_fwd9_kernel<C, GNB, GNA>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd(v9): hipFuncSetAttribute: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(grid, g.ksplit), dim3(256), lds, (hipStream_t)stream, x, packed, bias, residual, y, g);
@@ -374,6 +494,15 @@ int fwd9_launch_c(const float* x, const float* packed, const float* bias, const 
 int fwd9_launch_d(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
                   unsigned grid, void* stream);
 int fwd9_launch_e(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
+                  unsigned grid, void* stream);
+// ... and with the GroupNorm-apply prologue (g.gcoef set): Mish on the 3x3x3 variants (Family A), SiLU on the (1,3,3) ones (Family B)
+int fwd9_launch_f(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
+                  unsigned grid, void* stream);
+int fwd9_launch_g(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
+                  unsigned grid, void* stream);
+int fwd9_launch_h(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
+                  unsigned grid, void* stream);
+int fwd9_launch_i(const float* x, const float* packed, const float* bias, const float* residual, float* y, const F9Geom& g, size_t lds,
                   unsigned grid, void* stream);
 
 }  // namespace diqt

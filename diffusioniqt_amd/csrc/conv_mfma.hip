@@ -1852,6 +1852,64 @@ static int conv3d_fwd_one(const float* x, const float* packed, const float* bias
                           int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream, float* stats,
                           int subF = 0);
 
+// Block.forward on the sampling path (GroupNorm -> (scale + 1) x + shift -> Mish / SiLU -> conv; imagen_pytorch3D.py:546-566,
+// imagen_video.py:680-697) as ONE launch: x is the RAW GroupNorm input and conv_fwd9_kernel's GroupNorm-apply instantiation rewrites
+// every halo piece in the LDS as act(A x + Bc) right after its DMA landed -- the elementwise pass over the activation (a read and a
+// write of the whole tensor per conv) is gone.  coef[2][B][Cin] = (A, Bc) from diqt_gn_coef_from_partials / diqt_gn_coef.
+// diqt_conv3d_fwd_gn_supported: 1 when conv_fwd9_kernel takes the launch (given the workspace diqt_conv3d_fwd_workspace_bytes asks
+// for) and has the instantiation for this filter and activation; otherwise run diqt_gn_act_fwd + diqt_conv3d_fwd_ex.
+extern "C" int diqt_conv3d_fwd_gn_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                            int epd, int eph, int epw, int act) {
+    static const bool off = [] { const char* e = getenv("DIQT_CONV_NOGNA"); return e && e[0] == '1'; }();       // A/B switch
+    F9Geom g9;
+    size_t l9;
+    unsigned gr9;
+    if (off || Cin % 4 != 0 || smallcin_pad(Cin, kd * kh * kw)) return 0;
+    if (!fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, diqt_conv_packed_elems(Cout, Cin, kd, kh, kw), true))
+        return 0;
+    if (!fwd9_gna_available(g9.variant, act)) return 0;
+    // Every 64-channel output block of a tile rewrites its own copy of the halo, so the rewrite grows with Cout / 64 while the pass it
+    // replaces does not.  Measured on MI355X (tools/conv_bench.py gn, us saved per launch): 3x3x3 64->64 @ 8x32^3 +7, 128->64 +12,
+    // 128->128 @ 8x16^3 +2, 192->128 +3, split-K 256->256 @ 8x8^3 +4 (the saved launch is latency-bound there), but 256->128 @ 8x16^3
+    // -6, 256->256 @ 32^3 -23, 512->512 @ 16^3 -6; (1,3,3): 64->64 @ 32x32 frames +19, 128->128 +10, 256->256 @ 8x8 +5.
+    if (kd == 1) return g9.nNt <= 4 ? 1 : 0;
+    return (g9.nNt == 1 || (g9.nNt == 2 && Cin <= 192) || g9.ksplit > 1) ? 1 : 0;
+}
+extern "C" int diqt_conv3d_fwd_gn(const float* x, const float* packed, const float* bias, const float* residual, float* y, float* stats,
+                                  void* workspace, size_t workspace_bytes, const float* coef, int act, int B, int D, int H, int W, int Cin,
+                                  int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream) {
+    DIQT_REQUIRE(x && packed && y && coef, DIQT_E_ALIGN, "conv3d_fwd_gn: null pointer");
+    DIQT_REQUIRE(aligned16(x) && aligned16(packed) && aligned16(coef), DIQT_E_ALIGN, "conv3d_fwd_gn: x, packed weights and coef must be 16-byte aligned");
+    DIQT_REQUIRE(diqt_conv3d_fwd_gn_supported(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, act), DIQT_E_UNSUPPORTED,
+                 "conv3d_fwd_gn: shape / activation not taken (diqt_conv3d_fwd_gn_supported == 0)");
+    F9Geom g9;
+    size_t l9;
+    unsigned gr9;
+    const bool maySplit = workspace && aligned16(workspace);
+    const bool ok = fwd9_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw,
+                              diqt_conv_packed_elems(Cout, Cin, kd, kh, kw), maySplit);
+    DIQT_REQUIRE(ok && fwd9_gna_available(g9.variant, act), DIQT_E_WORKSPACE,
+                 "conv3d_fwd_gn: this launch needs the split-K workspace of diqt_conv3d_fwd_workspace_bytes");
+    g9.gcoef = coef;
+    g9.gnaAct = act;
+    if (g9.ksplit == 1) {
+        DIQT_REQUIRE(!stats || diqt_conv3d_fwd_stats_blocks(B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw) > 0, DIQT_E_UNSUPPORTED,
+                     "conv3d_fwd_gn: this shape does not produce output statistics");
+        g9.stats = stats;
+        return fwd9_launch(x, packed, bias, residual, y, g9, l9, gr9, stream);
+    }
+    const size_t n = (size_t)B * g9.Do * g9.Ho * g9.Wo * Cout;
+    DIQT_REQUIRE(!stats && workspace_bytes >= (size_t)g9.ksplit * n * sizeof(float), DIQT_E_WORKSPACE,
+                 "conv3d_fwd_gn: split-K launch: no statistics, workspace of %zu bytes", (size_t)g9.ksplit * n * sizeof(float));
+    float* slabs = static_cast<float*>(workspace);
+    g9.stats = nullptr;
+    int rc = fwd9_launch(x, packed, nullptr, nullptr, slabs, g9, l9, gr9, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, slabs, bias, residual, y, n,
+                       Cout, g9.ksplit);
+    return check_launch("conv3d_fwd_gn(split-K reduce)");
+}
+
 // 'same' convolution (odd cubic filter k, padding k / 2) over the f^3 sub-volume batch x[f^3][A][A][A][Cin] of ONE merged volume, the
 // halo of a sub-volume read in place from its neighbours (conv_src_voxel): what the reference computes as
 // boundary_pad(x) -> unpadded Conv3d (imagen_pytorch3D.py:37-46, 550-566 with boundary=True).  Same kernels, same bits per output

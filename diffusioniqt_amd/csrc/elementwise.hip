@@ -111,9 +111,14 @@ struct MomentsF {
     }
 };
 
+struct GnCoefOut {          // optional second result of the statistics finalisation: y = act(A x + Bc) coefficients per (b, c)
+    float* coef;            // [2][B][C]: A, then Bc (nullptr: none)
+    const float *gamma, *beta, *scale, *shift;
+    int cs;
+};
 __global__ __launch_bounds__(512) void gn_stats_final_kernel(const float* __restrict__ partial, float* __restrict__ mean,
                                                              float* __restrict__ rstd, int B, int C, int G, int nblk,
-                                                             double count, float eps) {
+                                                             double count, float eps, GnCoefOut co) {
     // one 512-thread workgroup per (b,g): threads stride over the nblk x Cg partial sums (a 64^3 volume has 2048 tiles: one wave
     // per (b,g) took 58 us per launch on C4), fp64 combine in a fixed order: lanes by butterfly, then the 8 waves through LDS
     __shared__ double sh[16];
@@ -138,6 +143,18 @@ __global__ __launch_bounds__(512) void gn_stats_final_kernel(const float* __rest
         if (var < 0) var = 0;
         mean[i] = (float)m;
         rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+        if (co.coef) { sh[0] = (double)mean[i]; sh[1] = (double)rstd[i]; }
+    }
+    if (co.coef) {          // kernel-uniform: the group's channels get their coefficients here (same expressions as GnCoef::get)
+        __syncthreads();
+        const float m = (float)sh[0], r = (float)sh[1];
+        for (int e = threadIdx.x; e < Cg; e += 512) {
+            const int c = g * Cg + e;
+            const float ga = co.gamma ? co.gamma[c] : 1.f, be = co.beta ? co.beta[c] : 0.f;
+            const float sc = co.scale ? co.scale[b * co.cs + c] + 1.f : 1.f, sf = co.shift ? co.shift[b * co.cs + c] : 0.f;
+            co.coef[(size_t)b * C + c] = r * ga * sc;
+            co.coef[(size_t)(B + b) * C + c] = (be - m * r * ga) * sc + sf;
+        }
     }
 }
 
@@ -156,6 +173,15 @@ struct GnCoef {   // y = act(A*x + Bc) per (b,c)
         Bc = (be - m * r * ga) * sc + sf;
     }
 };
+
+__global__ __launch_bounds__(256) void gn_coef_kernel(GnCoef k, float* __restrict__ coef, int B) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * k.C) return;
+    float A, Bc;
+    k.get(i / k.C, i % k.C, A, Bc);
+    coef[i] = A;
+    coef[(size_t)B * k.C + i] = Bc;
+}
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -1446,7 +1472,7 @@ extern "C" int diqt_groupnorm_stats(const float* x, float* mean, float* rstd, vo
     int rc = check_launch("groupnorm_stats/reduce");
     if (rc) return rc;
     hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B * G), dim3(512), 0, STREAM, partial, mean, rstd, B, C, G,
-                       nblk, (double)rows * (C / G), eps);
+                       nblk, (double)rows * (C / G), eps, GnCoefOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
     return check_launch("groupnorm_stats/final");
 }
 
@@ -1457,8 +1483,31 @@ extern "C" int diqt_groupnorm_stats_from_partials(const float* partials, float* 
     DIQT_REQUIRE(partials && mean && rstd, DIQT_E_ALIGN, "groupnorm_stats_from_partials: null pointer");
     DIQT_REQUIRE(B > 0 && nblk > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "groupnorm_stats_from_partials: bad shape");
     hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B * G), dim3(512), 0, STREAM, partials, mean, rstd, B, C, G, nblk,
-                       (double)rows * (C / G), eps);
+                       (double)rows * (C / G), eps, GnCoefOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
     return check_launch("groupnorm_stats_from_partials");
+}
+// GroupNorm statistics from a producer's per-tile column sums AND, in the same launch, the coefficients of the fused
+// GroupNorm -> (scale + 1) x + shift -> activation as y = act(A x + Bc): coef[2][B][C] (A, then Bc), what diqt_conv3d_fwd_gn applies to its
+// input while staging it (Block.forward, imagen_pytorch3D.py:546-566 / imagen_video.py:680-697; sampling path).
+extern "C" int diqt_gn_coef_from_partials(const float* partials, int nblk, int rows, const float* gamma, const float* beta,
+                                          const float* scale, const float* shift, int cond_stride, float* mean, float* rstd, float* coef,
+                                          int B, int C, int G, float eps, void* stream) {
+    DIQT_REQUIRE(partials && mean && rstd && coef, DIQT_E_ALIGN, "gn_coef_from_partials: null pointer");
+    DIQT_REQUIRE(B > 0 && nblk > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_coef_from_partials: bad shape");
+    DIQT_REQUIRE((scale == nullptr) == (shift == nullptr) && (!scale || cond_stride >= C), DIQT_E_SHAPE, "gn_coef_from_partials: scale / shift");
+    hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B * G), dim3(512), 0, STREAM, partials, mean, rstd, B, C, G, nblk,
+                       (double)rows * (C / G), eps, GnCoefOut{coef, gamma, beta, scale, shift, cond_stride});
+    return check_launch("gn_coef_from_partials");
+}
+// ... and from statistics that exist already (diqt_groupnorm_stats)
+extern "C" int diqt_gn_coef(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale,
+                            const float* shift, int cond_stride, float* coef, int B, int C, int G, void* stream) {
+    DIQT_REQUIRE(mean && rstd && coef, DIQT_E_ALIGN, "gn_coef: null pointer");
+    DIQT_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_coef: bad shape");
+    DIQT_REQUIRE((scale == nullptr) == (shift == nullptr) && (!scale || cond_stride >= C), DIQT_E_SHAPE, "gn_coef: scale / shift");
+    GnCoef k{mean, rstd, gamma, beta, scale, shift, C, G, cond_stride};
+    hipLaunchKernelGGL(gn_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, STREAM, k, coef, B);
+    return check_launch("gn_coef");
 }
 __global__ __launch_bounds__(256) void mean_from_stat_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                                       int nblk, int C, int total, float alpha) {

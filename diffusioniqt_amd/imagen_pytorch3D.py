@@ -313,6 +313,13 @@ class Block(nn.Module):
         ``tap``: also returns an alias of the input for its other consumer (ops.groupnorm_act): ``(y, x_alias)``."""
         gn = self.groupnorm
         x_in = x
+        if isinstance(gn, nn.GroupNorm) and not self.boundary and not torch.is_grad_enabled():
+            # sampling: GroupNorm-apply + Mish inside the conv's input staging (one launch, no elementwise pass); None: shape not taken
+            pr = self.project
+            y = ops.gn_conv3d(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps, pr.weight, pr.bias, pr.padding,
+                              residual, want_stats=emit_stats) if pr.groups == 1 and tuple(pr.stride) == (1, 1, 1) else None
+            if y is not None:
+                return (y, x_in) if tap else y
         if isinstance(gn, nn.GroupNorm):
             x = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps, tap=tap)
             if tap:

@@ -134,14 +134,22 @@ class Conv3d(nn.Module):
             nn.init.dirac_(self.temporal_conv.weight.data)
             nn.init.zeros_(self.temporal_conv.bias.data)
 
-    def forward(self, x, ignore_time=False, residual=None, want_stats=False):
+    def forward(self, x, ignore_time=False, residual=None, want_stats=False, gn=None):
         """``residual`` is added in the epilogue of the LAST conv of the pair (the caller's ``h + res``), whose per-tile column sums
-        (``want_stats``) feed the consumer's GroupNorm."""
+        (``want_stats``) feed the consumer's GroupNorm.  ``gn`` = (GroupNorm module, scale_shift): x is the RAW GroupNorm input and the
+        per-frame conv applies GroupNorm + SiLU while staging it (sampling path, ops.gn_conv3d); returns None when that is not taken."""
         sc = self.spatial_conv
         k = self.kernel_size
         last = ignore_time or not exists(self.temporal_conv)
-        x = ops.conv3d(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), residual=residual if last else None,
-                       want_stats=want_stats and last)
+        if gn is not None:
+            norm, ss = gn
+            x = ops.gn_conv3d(x, norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps, sc.weight.unsqueeze(2), sc.bias,
+                              (0, k // 2, k // 2), residual if last else None, want_stats=want_stats and last)
+            if x is None:
+                return None
+        else:
+            x = ops.conv3d(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), residual=residual if last else None,
+                           want_stats=want_stats and last)
         if last:
             return x
         tc = self.temporal_conv
@@ -298,6 +306,11 @@ class Block(nn.Module):
     def forward(self, x, scale_shift=None, ignore_time=False, residual=None, emit_stats=False, tap=False):
         """``tap``: also returns an alias of x for its other consumer (the ResnetBlock's residual branch; ops.groupnorm_act)."""
         gn = self.groupnorm
+        if not torch.is_grad_enabled():
+            # sampling: GroupNorm-apply + SiLU inside the per-frame conv's input staging (no elementwise pass); None: shape not taken
+            y = self.project(x, ignore_time=ignore_time, residual=residual, want_stats=emit_stats, gn=(gn, scale_shift))
+            if y is not None:
+                return (y, x) if tap else y
         if tap:
             x, alias = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_SILU, gn.eps, tap=True)
             return self.project(x, ignore_time=ignore_time, residual=residual, want_stats=emit_stats), alias

@@ -704,6 +704,64 @@ def groupnorm_act(x, gamma, beta, scale_shift=None, groups=8, act=ACT_MISH, eps=
     return (y, alias) if tap else y
 
 
+def gn_conv3d(x, gamma, beta, scale_shift, groups, act, eps, weight, bias, padding, residual=None, extra_pad=(0, 0, 0), want_stats=False):
+    """Sampling path (no autograd, fp32): conv3d(act(GN(x) * (scale + 1) + shift)) as ONE conv launch -- the GroupNorm statistics
+    (from the producer's column sums when x carries them) are folded into per-(batch, channel) coefficients by one tiny launch and
+    ``conv_fwd9_kernel`` applies them to its input tiles while staging them (``diqt_conv3d_fwd_gn``).  Returns None when the shape is
+    not taken (the caller then runs ``groupnorm_act`` + ``conv3d``)."""
+    if torch.is_grad_enabled() or lp_mode() is not None or x.dim() != 5:
+        return None
+    B, D, H, W, C = x.shape
+    Cout, Cin, kd, kh, kw = weight.shape
+    padding = tuple(int(p) for p in ((padding,) * 3 if isinstance(padding, int) else padding))
+    extra_pad = tuple(int(p) for p in extra_pad)
+    geo = (B, D, H, W, C, Cout, kd, kh, kw, *padding, *extra_pad)
+    if Cin != C or C % groups != 0 or not _lib.query("diqt_conv3d_fwd_gn_supported", *geo, act):
+        return None
+    _chk(x, gamma, beta, weight, bias, residual, scale_shift.base if isinstance(scale_shift, SSView) else None)
+    rows = D * H * W
+    dev = x.device
+    s = _stream()
+    mean = torch.empty(B * groups, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    coef = torch.empty(2 * B * C, dtype=torch.float32, device=dev)
+    scale = shift = None
+    cs = 0
+    if isinstance(scale_shift, SSView):
+        assert scale_shift.width == 2 * C and scale_shift.base.shape[0] == B
+        scale, cs = scale_shift.base.data_ptr() + 4 * scale_shift.off, scale_shift.base.shape[1]
+        shift = scale + 4 * C
+    elif scale_shift is not None:
+        assert scale_shift.shape == (B, 2 * C) and scale_shift.stride(1) == 1 and scale_shift.is_cuda and scale_shift.dtype == torch.float32
+        scale, shift, cs = scale_shift.data_ptr(), scale_shift.data_ptr() + 4 * C, scale_shift.stride(0)
+    pre = getattr(x, "_diqt_stats", None)
+    if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
+        _lib.call("diqt_gn_coef_from_partials", pre.partials, pre.nblk, rows, gamma, beta, scale, shift, cs, mean, rstd, coef, B, C, groups,
+                  float(eps), s)
+    else:
+        ws, n = _reduce_ws(B, C, dev)
+        _lib.call("diqt_groupnorm_stats", x, mean, rstd, ws, n, B, rows, C, groups, float(eps), s)
+        _lib.call("diqt_gn_coef", mean, rstd, gamma, beta, scale, shift, cs, coef, B, C, groups, s)
+    Do, Ho, Wo = D + 2 * padding[0] + extra_pad[0] - kd + 1, H + 2 * padding[1] + extra_pad[1] - kh + 1, W + 2 * padding[2] + extra_pad[2] - kw + 1
+    y = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+    if TIMER.enabled:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    n = _lib.query("diqt_conv3d_fwd_workspace_bytes", *geo)
+    ws = _workspace(n, dev) if n else None
+    stats = None
+    if want_stats:
+        nblk = _lib.query("diqt_conv3d_fwd_stats_blocks", *geo)
+        if nblk > 0:
+            stats = torch.empty((B, nblk, 2, Cout), dtype=torch.float32, device=dev)
+            y._diqt_stats = ColStats(stats, nblk, Do * Ho * Wo)
+    _lib.call("diqt_conv3d_fwd_gn", x, _packed(weight, 0), bias, residual, y, stats, ws, n, coef, act, *geo, s)
+    if TIMER.enabled:
+        ev1.record()
+        TIMER.records.append((ev0, ev1, 2.0 * B * Do * Ho * Wo * Cout * C * kd * kh * kw, "conv_fwd9_kernel", geo[:9]))
+    return y
+
+
 class _ActFn(Function):
     @staticmethod
     def forward(ctx, x, act):

@@ -205,6 +205,23 @@ int diqt_gn_act_bwd(const float* x, const float* dy, const float* mean, const fl
  * Replaces autograd of Block.forward (imagen_pytorch3D.py:535-566, imagen_video.py:671-697).                                       */
 int diqt_conv3d_fwd_gnbwd_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd,
                                  int eph, int epw);
+/* Block.forward on the sampling path as one launch (GroupNorm -> (scale + 1) x + shift -> Mish / SiLU -> conv;
+ * imagen_pytorch3D.py:546-566, imagen_video.py:680-697): diqt_gn_coef_from_partials (statistics from the producer's column sums) or
+ * diqt_gn_coef (from existing statistics) fold the normalisation into y = act(A x + Bc), coef[2][B][C] = (A, Bc); diqt_conv3d_fwd_gn
+ * takes the RAW GroupNorm input x and applies the coefficients while it stages its input tiles (arguments otherwise as
+ * diqt_conv3d_fwd_ex).  diqt_conv3d_fwd_gn_supported = 0: use diqt_gn_act_fwd + diqt_conv3d_fwd_ex.  act: DIQT_ACT_MISH on 3x3x3
+ * filters, DIQT_ACT_SILU on (1,3,3) filters.                                                                                       */
+int diqt_gn_coef_from_partials(const float* partials, int nblk, int rows, const float* gamma, const float* beta, const float* scale,
+                               const float* shift, int cond_stride, float* mean, float* rstd, float* coef, int B, int C, int G,
+                               float eps, void* stream);
+int diqt_gn_coef(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
+                 int cond_stride, float* coef, int B, int C, int G, void* stream);
+int diqt_conv3d_fwd_gn_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd,
+                                 int eph, int epw, int act);
+int diqt_conv3d_fwd_gn(const float* x, const float* packed, const float* bias, const float* residual, float* y, float* stats,
+                       void* workspace, size_t workspace_bytes, const float* coef, int act, int B, int D, int H, int W, int Cin, int Cout,
+                       int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
+
 /* Process-wide switch of that fusion (default: off unless DIQT_GNBWD_FUSE=1 in the environment at the first query).  The setter
  * returns the previous value; with the switch off diqt_conv3d_fwd_gnbwd_blocks answers 0 for every shape.  Host-side state only
  * (no reference counterpart: both settings compute autograd of Block.forward, imagen_pytorch3D.py:535-566).                        */

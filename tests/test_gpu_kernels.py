@@ -862,3 +862,52 @@ def test_multi_accumulate_matches_per_tensor_adds(ops):
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(RuntimeError):
         ops.mish(torch.randn(4))
+
+
+@pytest.mark.parametrize("B,sp,Cin,Cout,k,act,with_ss,with_res", [
+    (8, (32, 32, 32), 64, 64, (3, 3, 3), "mish", True, True),     # the headline shape: 512-voxel tiles, persistent walk (2 tiles per workgroup)
+    (2, (32, 32, 32), 32, 64, (3, 3, 3), "mish", False, False),   # 256-voxel tiles, one round, two 16-channel chunks
+    (8, (16, 16, 16), 128, 128, (3, 3, 3), "mish", True, False),  # 16^3 level: two 64-channel output blocks per tile
+    (8, (8, 8, 8), 256, 256, (3, 3, 3), "mish", True, True),      # 8^3 level: split-K slabs + reduce (bias / residual in the reduce)
+    (8, (32, 32, 32), 64, 64, (1, 3, 3), "silu", True, True),     # pseudo-3D per-frame conv, 1x16x32 tiles
+    (8, (32, 16, 16), 128, 128, (1, 3, 3), "silu", False, True),  # 2x16x16 tiles
+    (8, (32, 8, 8), 256, 64, (1, 3, 3), "silu", True, False)])    # 4x8x8 tiles
+def test_groupnorm_apply_inside_the_conv_staging_matches_the_two_kernel_path(ops, B, sp, Cin, Cout, k, act, with_ss, with_res):
+    """Sampling path: Block.forward (GroupNorm -> (scale + 1) x + shift -> Mish / SiLU -> conv, imagen_pytorch3D.py:546-566,
+    imagen_video.py:680-697) as one conv launch whose input tiles are rewritten act(A x + Bc) in the LDS (``ops.gn_conv3d`` ->
+    ``diqt_conv3d_fwd_gn``), against float64 and against the two-kernel path (``groupnorm_act`` + ``conv3d``); statistics of the
+    producer (``_diqt_stats``) and of the output ride along in both."""
+    D, H, W = sp
+    pads = tuple(kk // 2 for kk in k)
+    A = ops.ACT_MISH if act == "mish" else ops.ACT_SILU
+    g = torch.Generator().manual_seed(Cin + 3 * Cout + k[0])
+    x = torch.randn(B, Cin, D, H, W, generator=g) * 1.7 + 0.4
+    x[:, :, :, :2] += 25.0 if act == "mish" else 0.0        # a few activations beyond Mish's x > 20 branch
+    gamma, beta = torch.randn(Cin, generator=g), torch.randn(Cin, generator=g) * 0.3
+    ss = torch.randn(B, 2 * Cin, generator=g) * 0.3 if with_ss else None
+    w = torch.randn(Cout, Cin, *k, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
+    bias = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, D, H, W, generator=g) if with_res else None
+    h = F.group_norm(x.double(), 8, gamma.double(), beta.double(), eps=1e-5)
+    if with_ss:
+        h = h * (ss.double()[:, :Cin, None, None, None] + 1) + ss.double()[:, Cin:, None, None, None]
+    h = F.mish(h) if act == "mish" else F.silu(h)
+    ref = F.conv3d(h, w.double(), bias.double(), padding=pads)
+    if with_res:
+        ref = ref + res.double()
+    xd, gd, bd, wd, cd = cl(x), gamma.to(DEV), beta.to(DEV), w.to(DEV), bias.to(DEV)
+    sd = ss.to(DEV) if with_ss else None
+    rd = cl(res) if with_res else None
+    with torch.no_grad():
+        y = ops.gn_conv3d(xd, gd, bd, sd, 8, A, 1e-5, wd, cd, pads, rd, want_stats=True)
+        assert y is not None, "shape not taken by the GroupNorm-apply instantiation of conv_fwd9_kernel"
+        y2 = ops.conv3d(ops.groupnorm_act(xd, gd, bd, sd, 8, A), wd, cd, pads, rd, want_stats=True)
+    close(cf(y), ref, tol=3e-5, what="fused GroupNorm + act + conv vs float64")
+    close(cf(y), cf(y2).double(), tol=1e-5, what="fused vs two-kernel path")
+    st, st2 = getattr(y, "_diqt_stats", None), getattr(y2, "_diqt_stats", None)
+    assert (st is None) == (st2 is None)
+    if st is not None:
+        close(st.partials, st2.partials.double(), tol=1e-5, what="output column sums")
+    with torch.no_grad():
+        y3 = ops.gn_conv3d(xd, gd, bd, sd, 8, A, 1e-5, wd, cd, pads, rd)
+    assert torch.equal(y3, y), "the result must not depend on whether output statistics are requested"

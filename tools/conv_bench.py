@@ -39,6 +39,17 @@ if mode in ("fwd", "both"):
     with torch.no_grad():
         ms = timeit(lambda: ops.conv3d(x, w, bias, PADS), iters)
     print(f"conv fwd  B={B} {SP} k={KS} {Cin}->{Cout}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
+if mode == "gn":                # Block on the sampling path: GroupNorm-apply inside the conv staging vs groupnorm_act + conv3d
+    gamma, beta = torch.randn(Cin, device=dev), torch.randn(Cin, device=dev)
+    ss = torch.randn(B, 2 * Cin, device=dev) * 0.3
+    act = ops.ACT_SILU if KS[0] == 1 else ops.ACT_MISH
+    with torch.no_grad():
+        assert ops.gn_conv3d(x, gamma, beta, ss, 8, act, 1e-5, w, bias, PADS) is not None, "shape not taken"
+        ms_f = timeit(lambda: ops.gn_conv3d(x, gamma, beta, ss, 8, act, 1e-5, w, bias, PADS), iters)
+        ms_c = timeit(lambda: ops.conv3d(x, w, bias, PADS), iters)
+        ms_u = timeit(lambda: ops.conv3d(ops.groupnorm_act(x, gamma, beta, ss, 8, act), w, bias, PADS), iters)
+    print(f"GN+act+conv B={B} {SP} k={KS} {Cin}->{Cout}: fused {ms_f*1e3:.1f} us (incl. statistics pass + coefficient launch), "
+          f"two-kernel path {ms_u*1e3:.1f} us, conv alone {ms_c*1e3:.1f} us = {flops/ms_c/1e9:.1f} TFLOP/s")
 if mode in ("fwdh",):           # fp16 / bf16 operand kernel (LP=fp16|bf16)
     with torch.no_grad(), ops.low_precision(os.environ.get("LP", "fp16")):
         ms = timeit(lambda: ops.conv3d(x, w, bias, PADS), iters)

@@ -57,7 +57,11 @@ template <int ND>           // dim_head = 32 * ND
 __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                                const float* __restrict__ rel, const float* __restrict__ null_bias,
                                                                float* __restrict__ out, float* __restrict__ lse, int n, int h, int E,
-                                                               int ns, int causal, float scale) {
+                                                               int ns, int causal, float scale, int P, const float* __restrict__ nullkv) {
+    // P > 0: the sequences are the FRAME axis of channels-last tensors q[B][n][P][h D], kv[B][n][P][2 D], out like q (sequence
+    // g = (b, pixel p), token i = frame: row (b n + i) P + p), read and written in place -- no transposed copies around the temporal
+    // attentions -- and the lone extra key / value (E == 1, the learned null row) comes from nullkv[2 D] instead of a concatenated copy
+    // of kv.  P == 0: q[G][n][h D], kv[G][E + ns][2 D] as documented above.
     constexpr int D = 32 * ND, ROW = D + 4, NPF = AKT * (2 * D / 4) / 256;    // float4 pieces of a K|V tile per thread
     __shared__ __attribute__((aligned(16))) float KVs[2][2][AKT * ROW];       // [buffer][K | V][key][ROW]
     const int g = blockIdx.y;
@@ -68,8 +72,12 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
     const bool rvalid = r < R;
     const int rc = rvalid ? r : R - 1;
     const int qi = rc / h, qh = rc % h;                    // token index, head
-    const float* qg = q + ((size_t)g * R + rc) * D;
-    const float* kvg = kv + (size_t)g * M * 2 * D;
+    const size_t tokStride = P > 0 ? (size_t)P : 1;        // rows between consecutive tokens of a sequence
+    const size_t seqRow0 = P > 0 ? (size_t)(g / P) * n * P + (size_t)(g % P) : (size_t)g * n;      // row of token 0 in q / out
+    const float* qg = q + ((seqRow0 + (size_t)qi * tokStride) * h + qh) * D;
+    // kv rows: key j of the sequence (P == 0: row j of its [E + ns] block; P > 0: the null row for j == 0, frame j - 1 otherwise)
+    const float* kvg = P > 0 ? nullkv : kv + (size_t)g * M * 2 * D;
+    const float* kvSelf = P > 0 ? kv + ((size_t)(g / P) * ns * P + (size_t)(g % P)) * 2 * D : nullptr;
 
     // Q^T operand: MFMA step (group gq, element e) of a key tile uses k-index dd = 8*gq + 4*hf + e  (same order as the K fragments)
     float qreg[D / 2];
@@ -115,7 +123,9 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
             const int e = u * 256 + tid;
             const int key = e / (2 * D / 4), c4 = (e % (2 * D / 4)) * 4;
             const int j = kbase + t * AKT + key;
-            const float4 v = *reinterpret_cast<const float4*>(kvg + (size_t)min(j, M - 1) * 2 * D + c4);
+            const int jc = min(j, M - 1);
+            const float* krow = P > 0 ? kvSelf + (size_t)(jc - 1) * tokStride * 2 * D : kvg + (size_t)jc * 2 * D;     // P > 0: kbase == 1, jc >= 1
+            const float4 v = *reinterpret_cast<const float4*>(krow + c4);
             pre[u] = j < M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
     if (rvalid) {
         const float inv = 1.f / lrun;
         if (lse && hf == 0) lse[(size_t)g * R + r] = mrun + __logf(lrun);      // log-sum-exp of the row: what the backward recomputes P from
-        float* og = out + ((size_t)g * R + r) * D;
+        float* og = out + ((seqRow0 + (size_t)qi * tokStride) * h + qh) * D;
 #pragma unroll
         for (int c = 0; c < ND; ++c)
 #pragma unroll
@@ -465,11 +475,32 @@ extern "C" int diqt_mqa_attention_fwd(const float* q, const float* kv, const flo
     const dim3 grid((unsigned)(((long long)n * h + AQ - 1) / AQ), G);
     if (d == 64)
         hipLaunchKernelGGL(mqa_flash_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, (float*)nullptr, n, h,
-                           n_extra, n_self, causal, scale);
+                           n_extra, n_self, causal, scale, 0, (const float*)nullptr);
     else
         hipLaunchKernelGGL(mqa_flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, (float*)nullptr, n, h,
-                           n_extra, n_self, causal, scale);
+                           n_extra, n_self, causal, scale, 0, (const float*)nullptr);
     return check_launch("mqa_attention_fwd");
+}
+
+// The temporal attentions of the pseudo-3D U-Net (EinopsToAndFrom('b c f h w', '(b h w) f c', Attention), imagen_video.py:1351-1354)
+// on the channels-last tensors as they stand: q[B][F][P][h d], kv[B][F][P][2 d] (k | v of frame f at pixel p), out like q; sequence =
+// (b, p), tokens = the F frames, one extra key / value nullkv[2 d] in front (the learned null row, with null_bias[h] when rel is
+// given).  Same kernel and arithmetic as diqt_mqa_attention_fwd on transposed copies + a concatenated kv (bit-identical results).
+extern "C" int diqt_mqa_attention_fwd_frames(const float* q, const float* kv, const float* nullkv, const float* rel, const float* null_bias,
+                                             float* out, int B, int F, int P, int h, int d, int causal, float scale, void* stream) {
+    DIQT_REQUIRE(q && kv && nullkv && out, DIQT_E_ALIGN, "mqa_attention_fwd_frames: null pointer");
+    DIQT_REQUIRE(B > 0 && F > 0 && P > 0 && h > 0, DIQT_E_SHAPE, "mqa_attention_fwd_frames: bad shape");
+    DIQT_REQUIRE(d == 32 || d == 64, DIQT_E_UNSUPPORTED, "mqa_attention_fwd_frames: dim_head %d (32 or 64 are built)", d);
+    DIQT_REQUIRE(aligned16(q) && aligned16(kv) && aligned16(out) && aligned16(nullkv), DIQT_E_ALIGN, "mqa_attention_fwd_frames: pointers must be 16-byte aligned");
+    DIQT_REQUIRE((long long)B * P <= 65535, DIQT_E_SHAPE, "mqa_attention_fwd_frames: B * P > 65535");
+    const dim3 grid((unsigned)(((long long)F * h + AQ - 1) / AQ), (unsigned)(B * P));
+    if (d == 64)
+        hipLaunchKernelGGL(mqa_flash_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, (float*)nullptr, F, h,
+                           1, F, causal, scale, P, nullkv);
+    else
+        hipLaunchKernelGGL(mqa_flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, (float*)nullptr, F, h,
+                           1, F, causal, scale, P, nullkv);
+    return check_launch("mqa_attention_fwd_frames");
 }
 
 extern "C" int diqt_mqa_attention_fwd_lse(const float* q, const float* kv, const float* rel, const float* null_bias, float* out, float* lse,
@@ -484,10 +515,10 @@ extern "C" int diqt_mqa_attention_fwd_lse(const float* q, const float* kv, const
     const dim3 grid((unsigned)(((long long)n * h + AQ - 1) / AQ), G);
     if (d == 64)
         hipLaunchKernelGGL(mqa_flash_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, lse, n, h, n_extra,
-                           n_self, causal, scale);
+                           n_self, causal, scale, 0, (const float*)nullptr);
     else
         hipLaunchKernelGGL(mqa_flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, lse, n, h, n_extra,
-                           n_self, causal, scale);
+                           n_self, causal, scale, 0, (const float*)nullptr);
     return check_launch("mqa_attention_fwd_lse");
 }
 

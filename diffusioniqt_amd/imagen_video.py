@@ -115,6 +115,10 @@ class TokensOverTime(nn.Module):
 
     def forward(self, x, **kwargs):
         B, F, H, W, C = x.shape
+        fn = self.fn.fn if isinstance(self.fn, Residual) else None
+        if isinstance(fn, Attention) and not kwargs and fn.frames_ok(B * H * W):
+            # sampling: LayerNorm and the projections are per-row, and the attention kernel walks the frame axis in place
+            return fn.forward_frames(x.reshape(B, F, H * W, C)).reshape(B, F, H, W, C)
         t = ops.transpose_mid(x.reshape(B, F, H * W, C)).reshape(B * H * W, F, C)
         t = self.fn(t, **kwargs)
         return ops.transpose_mid(t.reshape(B, H * W, F, C)).reshape(B, F, H, W, C)
@@ -213,6 +217,26 @@ class Attention(nn.Module):
 
     def _out(self, out, residual):
         return self.to_out[1](self.to_out[0](out), residual=residual)              # Linear -> LayerNorm (+ residual)
+
+    def frames_ok(self, G):
+        return (not torch.is_grad_enabled() and ops.lp_mode() is None and self.dim_head in (32, 64) and G <= 65535
+                and self.to_context is None)
+
+    def forward_frames(self, x):
+        """``Residual(Attention)`` over the FRAME axis of x[B, F, P, C] without leaving that layout (sampling path): what
+        EinopsToAndFrom('b c f h w', '(b h w) f c', ...) computes through two transposes (imagen_video.py:1351-1354)."""
+        B, F, P, _ = x.shape
+        h, d = self.heads, self.dim_head
+        xn = self.norm(x)
+        q = self.to_q(xn)                                                         # [B, F, P, h*d]
+        kv = self.to_kv(xn)                                                       # [B, F, P, 2d]
+        rel = null_bias = None
+        if exists(self.rel_pos_bias):
+            rel = self.rel_pos_bias(F, x.device).contiguous()
+            null_bias = self.null_attn_bias.contiguous()
+        out = ops.mqa_attention_frames_nograd(q.contiguous(), kv.contiguous(), self.null_kv.reshape(-1).contiguous(), rel, null_bias,
+                                              h, d, self.causal, self.scale)
+        return self._out(out, x)
 
     def forward(self, x, context=None, mask=None, attn_bias=None, residual=None):
         assert mask is None and attn_bias is None

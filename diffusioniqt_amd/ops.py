@@ -1373,6 +1373,17 @@ def mqa_attention_nograd(q, kv_ext, rel, null_bias, n, h, d, n_extra, n_self, ca
     return out
 
 
+def mqa_attention_frames_nograd(q, kv, null_kv, rel, null_bias, h, d, causal, scale):
+    """The temporal attention of the pseudo-3D U-Net in place (sampling path, fp32): q[B, F, P, h*d], kv[B, F, P, 2d] channels-last,
+    sequences = (b, pixel), tokens = frames, ``null_kv``[2d] the extra key / value.  Returns out[B, F, P, h*d] -- no transposes, no
+    concatenated copy of kv."""
+    _chk(q, kv, null_kv, rel, null_bias)
+    B, F, P, _ = q.shape
+    out = torch.empty_like(q)
+    _lib.call("diqt_mqa_attention_fwd_frames", q, kv, null_kv, rel, null_bias, out, B, F, P, h, d, int(causal), float(scale), _stream())
+    return out
+
+
 class _MqaAttentionFn(Function):
     """Fused multi-query attention with autograd (training path): scores and probabilities never reach HBM, the backward
     recomputes them from the row log-sum-exp (diqt_mqa_attention_fwd_lse / diqt_mqa_attention_bwd)."""

@@ -486,6 +486,13 @@ int diqt_mqa_attention_fwd(const float* q, const float* kv, const float* rel, co
  *   dq[G][n*h][d], dkv[G][n_extra + n_self][2d] (every row written: the extra rows carry the gradient of the null / context
  *   keys), drel[2 n_self - 1][h] and dnull[h] (required iff rel / null_bias are given).
  * Deterministic (no atomics; bias tables are summed per wave, then in a fixed order).  workspace: ..._bwd_workspace_bytes. */
+/* The temporal attentions of the pseudo-3D U-Net -- EinopsToAndFrom('b c f h w', '(b h w) f c', Attention), imagen_video.py:1351-1354,
+ * 410-525 -- on the channels-last tensors as they stand: q[B][F][P][h d], kv[B][F][P][2 d] (k | v of frame f at pixel p), out like q.
+ * A sequence is (b, p), its tokens the F frames; one extra key / value nullkv[2 d] in front (the learned null row; null_bias[h] is
+ * added to its score when rel is given).  Replaces the two mid-axis transposes and the null-row concatenation around
+ * diqt_mqa_attention_fwd; same kernel, bit-identical results.                                                                      */
+int diqt_mqa_attention_fwd_frames(const float* q, const float* kv, const float* nullkv, const float* rel, const float* null_bias,
+                                  float* out, int B, int F, int P, int h, int d, int causal, float scale, void* stream);
 int diqt_mqa_attention_fwd_lse(const float* q, const float* kv, const float* rel, const float* null_bias, float* out, float* lse,
                                int G, int n, int h, int d, int n_extra, int n_self, int causal, float scale, void* stream);
 size_t diqt_mqa_attention_bwd_workspace_bytes(int G, int n, int h, int d, int n_extra, int n_self, int has_rel);

@@ -289,3 +289,26 @@ def test_c5_cascade_layouts_match_reference_golden():
                      use_tqdm=False, noise=list(T(g['draws3'])))
     mx, frac = sample_err(img, T(g['img_from2']))
     assert mx <= 5e-3 and frac < 0.03, ("from2", mx, frac)
+
+
+@pytest.mark.parametrize("B,F,H,W,C,heads,dh,causal", [(2, 32, 16, 16, 64, 8, 64, True), (1, 7, 5, 3, 32, 2, 32, True),
+                                                       (2, 40, 4, 4, 128, 4, 64, False)])
+def test_temporal_attention_walks_the_frame_axis_in_place(B, F, H, W, C, heads, dh, causal):
+    """Sampling path of EinopsToAndFrom('b c f h w', '(b h w) f c', Residual(Attention)) (imagen_video.py:1351-1354, 410-525): the
+    attention kernel reads q / k|v and writes its output along the frame axis of the channels-last tensors (no transposed copies, the
+    null key / value from its own pointer instead of a concatenated kv): bit-identical to the transposed path, which the golden
+    fixtures pin against the reference."""
+    from diffusioniqt_amd.imagen_video import Attention, Residual, TokensOverTime
+    torch.manual_seed(F + C)
+    attn = Attention(C, heads=heads, dim_head=dh, causal=causal, rel_pos_bias=True, rel_pos_bias_mlp_depth=2, init_zero=True)
+    with torch.no_grad():
+        attn.to_out[1].g.normal_()                 # init_zero would make the block the identity
+    mod = TokensOverTime(Residual(attn)).to(DEV)
+    x = torch.randn(B, F, H, W, C, device=DEV)
+    with torch.no_grad():
+        assert attn.frames_ok(B * H * W)
+        y_new = mod(x)
+        attn.frames_ok = lambda G: False
+        y_old = mod(x)
+    assert torch.isfinite(y_new).all() and (y_new - x).abs().max().item() > 1e-3
+    assert torch.equal(y_new, y_old), f"max diff {(y_new - y_old).abs().max().item():.3e}"

@@ -81,6 +81,12 @@ PROTOTYPES = {
     "diqt_q_sample": (I, [P, P, P, P, P, I, Z, P]),
     "diqt_ddpm_step": (I, [P, P, P, P, P, P, F, F, I, P, P, I, Z, P]),
     "diqt_axpby3": (I, [P, P, P, P, P, P, F, F, I, P, I, Z, P]),
+    "diqt_loss_clamp_fwd": (I, [P, P, P, P, F, I, I, P, P, I, Z, P]),
+    "diqt_loss_clamp_bwd": (I, [P, P, P, F, I, I, F, P, I, Z, P]),
+    "diqt_nearest_resize_bwd": (I, [P, P] + [I] * 8 + [P]),
+    "diqt_l2norm_rows_fwd": (I, [P, P, P, Z, I, I, I, P]),
+    "diqt_l2norm_rows_bwd": (I, [P, P, P, P, Z, I, I, I, P]),
+    "diqt_groupnorm_stats_coef": (I, [P, P, P, P, P, I, P, P, P, P, Z, I, I, I, I, F, P]),
     "diqt_mse_clamp_fwd": (I, [P, P, P, P, F, I, P, P, I, Z, P]),
     "diqt_mse_clamp_bwd": (I, [P, P, P, F, I, F, P, I, Z, P]),
     "diqt_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, F, F, I, P]),

@@ -884,9 +884,21 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
     }
 }
 
+// kind: 0 = squared error (F.mse_loss), 1 = absolute error (F.l1_loss), 2 = Huber with beta 1 (F.smooth_l1_loss): the three
+// `loss_type`s of Imagen.__init__ (imagen_pytorch3D.py:1785-1790)
+__device__ __forceinline__ float loss_term(float d, int kind) {
+    if (kind == 1) return fabsf(d);
+    if (kind == 2) { const float a = fabsf(d); return a < 1.f ? 0.5f * d * d : a - 0.5f; }
+    return d * d;
+}
+__device__ __forceinline__ float loss_term_grad(float d, int kind) {      // d loss_term / d d
+    if (kind == 1) return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (kind == 2) return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+    return 2.f * d;
+}
 __global__ __launch_bounds__(256) void mse_clamp_fwd_kernel(const float* pred, float* pred_out, const float* __restrict__ target,
                                                             const float* __restrict__ w, float lo, int do_clamp,
-                                                            float* __restrict__ partials, int B, size_t per) {
+                                                            float* __restrict__ partials, int B, size_t per, int kind) {
     __shared__ float sh[4];
     const size_t total = (size_t)B * per;
     float s = 0.f;
@@ -895,7 +907,7 @@ __global__ __launch_bounds__(256) void mse_clamp_fwd_kernel(const float* pred, f
         if (do_clamp) p = fmaxf(p, lo);
         if (pred_out) pred_out[i] = p;
         const float d = p - target[i];
-        s += (w ? w[i / per] : 1.f) * d * d;
+        s += (w ? w[i / per] : 1.f) * loss_term(d, kind);
     }
     s = block_sum256(s, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -910,12 +922,13 @@ __global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict_
 }
 __global__ __launch_bounds__(256) void mse_clamp_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                             const float* __restrict__ w, float lo, int do_clamp,
-                                                            float coef, float* __restrict__ dpred, int B, size_t per) {
+                                                            float coef, float* __restrict__ dpred, int B, size_t per, int kind) {
     const size_t total = (size_t)B * per;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const float p = pred[i];
         // the reference clamps in place (imagen_pytorch3D.py:2362): no gradient where pred was floored
-        float gq = coef * (w ? w[i / per] : 1.f) * (p - target[i]);
+        // (kind 0: coef carries the 2 of d(d^2), and 2 * (0.5 d) is exact, so this is the old expression bit for bit)
+        float gq = coef * (w ? w[i / per] : 1.f) * (0.5f * loss_term_grad(p - target[i], kind));
         if (do_clamp && !(p > lo)) gq = 0.f;
         dpred[i] = gq;
     }
@@ -1135,6 +1148,65 @@ __global__ __launch_bounds__(256) void nearest_resize_kernel(const float* __rest
         const int b = (int)(r / Do);
         const int id = min((int)floorf(od * fd), D - 1), ih = min((int)floorf(oh * fh), H - 1), iw = min((int)floorf(ow * fw), W - 1);
         y[i] = x[((((size_t)b * D + id) * H + ih) * W + iw) * C + c];
+    }
+}
+
+// gradient of the nearest-neighbour resize for whole-number up-scaling factors (each source voxel sums its fd x fh x fw copies)
+__global__ __launch_bounds__(256) void nearest_resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int D,
+                                                                 int H, int W, int C, int fd, int fh, int fw) {
+    const size_t total = (size_t)B * D * H * W * C;
+    const int Ho = H * fh, Wo = W * fw, Do = D * fd;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int iw = (int)(r % W); r /= W;
+        const int ih = (int)(r % H); r /= H;
+        const int id = (int)(r % D);
+        const int b = (int)(r / D);
+        float s = 0.f;
+        for (int a = 0; a < fd; ++a)
+            for (int e = 0; e < fh; ++e)
+                for (int f = 0; f < fw; ++f)
+                    s += dy[((((size_t)b * Do + id * fd + a) * Ho + ih * fh + e) * Wo + iw * fw + f) * C + c];
+        dx[i] = s;
+    }
+}
+
+// y = x / max(||x||, eps) over rows of d floats that start `stride` floats apart (F.normalize(dim = -1): l2norm of the cosine-sim
+// attention, imagen_video.py:118-119, 484-486): 16 lanes per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv,
+                                                          size_t rows, int d, int xs, int ys) {
+    const int sub = threadIdx.x & 15;
+    for (size_t r = (blockIdx.x * (size_t)256 + threadIdx.x) >> 4; r < ((rows + 15) >> 4 << 4); r += ((size_t)gridDim.x * 256) >> 4) {
+        const bool ok = r < rows;
+        const float* xr = x + (ok ? r : 0) * (size_t)xs;
+        float s = 0.f;
+        for (int e = sub; e < d; e += 16) { const float v = ok ? xr[e] : 0.f; s += v * v; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        const float iv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+        if (ok) {
+            for (int e = sub; e < d; e += 16) y[r * (size_t)ys + e] = xr[e] * iv;
+            if (inv && sub == 0) inv[r] = iv;
+        }
+    }
+}
+// dx = (dy - y (y . dy)) * inv
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                              const float* __restrict__ inv, float* __restrict__ dx, size_t rows, int d,
+                                                              int ys, int dxs) {
+    const int sub = threadIdx.x & 15;
+    for (size_t r = (blockIdx.x * (size_t)256 + threadIdx.x) >> 4; r < ((rows + 15) >> 4 << 4); r += ((size_t)gridDim.x * 256) >> 4) {
+        const bool ok = r < rows;
+        const size_t ro = (ok ? r : 0) * (size_t)ys;
+        float s = 0.f;
+        for (int e = sub; e < d; e += 16) s += ok ? y[ro + e] * dy[ro + e] : 0.f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        if (ok) {
+            const float iv = inv[r];
+            for (int e = sub; e < d; e += 16) dx[r * (size_t)dxs + e] = (dy[ro + e] - y[ro + e] * s) * iv;
+        }
     }
 }
 
@@ -1474,6 +1546,26 @@ extern "C" int diqt_groupnorm_stats(const float* x, float* mean, float* rstd, vo
     hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B * G), dim3(512), 0, STREAM, partial, mean, rstd, B, C, G,
                        nblk, (double)rows * (C / G), eps, GnCoefOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
     return check_launch("groupnorm_stats/final");
+}
+
+// diqt_groupnorm_stats that also writes the coefficients of diqt_conv3d_fwd_gn (see diqt_gn_coef_from_partials) from its finalisation
+extern "C" int diqt_groupnorm_stats_coef(const float* x, const float* gamma, const float* beta, const float* scale, const float* shift,
+                                         int cond_stride, float* mean, float* rstd, float* coef, void* workspace, size_t workspace_bytes,
+                                         int B, int rows, int C, int G, float eps, void* stream) {
+    DIQT_REQUIRE(x && mean && rstd && coef && workspace, DIQT_E_ALIGN, "groupnorm_stats_coef: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "groupnorm_stats_coef: bad shape (C=%d,G=%d)", C, G);
+    DIQT_REQUIRE(workspace_bytes >= diqt_reduce_workspace_bytes(B, C), DIQT_E_WORKSPACE, "groupnorm_stats_coef: workspace too small");
+    DIQT_REQUIRE(aligned16(workspace) && (C % 4 != 0 || aligned16(x)), DIQT_E_ALIGN, "groupnorm_stats_coef: misaligned pointer");
+    DIQT_REQUIRE((scale == nullptr) == (shift == nullptr) && (!scale || cond_stride >= C), DIQT_E_SHAPE, "groupnorm_stats_coef: scale / shift");
+    const int nblk = red_nblk(rows);
+    float* partial = static_cast<float*>(workspace);
+    MomentsF f{x};
+    hipLaunchKernelGGL((colreduce_kernel<2, MomentsF>), dim3(nblk, B), dim3(256), 0, STREAM, f, partial, rows, C);
+    int rc = check_launch("groupnorm_stats_coef/reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_stats_final_kernel, dim3(B * G), dim3(512), 0, STREAM, partial, mean, rstd, B, C, G,
+                       nblk, (double)rows * (C / G), eps, GnCoefOut{coef, gamma, beta, scale, shift, cond_stride});
+    return check_launch("groupnorm_stats_coef/final");
 }
 
 // GroupNorm statistics / channel means from per-tile column sums that a producer kernel (the conv epilogue) already wrote:
@@ -2025,26 +2117,34 @@ extern "C" int diqt_ddpm_step(const float* x_t, const float* pred, const float* 
                        lo, hi, clamp_mode, x_next, x0_out, per);
     return check_launch("ddpm_step");
 }
-extern "C" int diqt_mse_clamp_fwd(const float* pred, float* pred_clamped, const float* target, const float* w, float lo,
-                                  int do_clamp, float* partials, float* loss_out, int B, size_t per, void* stream) {
-    DIQT_REQUIRE(pred && target && partials && loss_out, DIQT_E_ALIGN, "mse_clamp_fwd: null pointer");
-    DIQT_REQUIRE(B > 0 && per > 0, DIQT_E_SHAPE, "mse_clamp_fwd: bad shape");
+extern "C" int diqt_loss_clamp_fwd(const float* pred, float* pred_clamped, const float* target, const float* w, float lo,
+                                   int do_clamp, int kind, float* partials, float* loss_out, int B, size_t per, void* stream) {
+    DIQT_REQUIRE(pred && target && partials && loss_out, DIQT_E_ALIGN, "loss_clamp_fwd: null pointer");
+    DIQT_REQUIRE(B > 0 && per > 0 && kind >= 0 && kind <= 2, DIQT_E_SHAPE, "loss_clamp_fwd: bad shape / kind");
     const unsigned nblk = grid_for((size_t)B * per, 256, 1024);
-    hipLaunchKernelGGL(mse_clamp_fwd_kernel, dim3(nblk), dim3(256), 0, STREAM, pred, pred_clamped, target, w, lo, do_clamp, partials, B, per);
-    int rc = check_launch("mse_clamp_fwd");
+    hipLaunchKernelGGL(mse_clamp_fwd_kernel, dim3(nblk), dim3(256), 0, STREAM, pred, pred_clamped, target, w, lo, do_clamp, partials, B, per, kind);
+    int rc = check_launch("loss_clamp_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, STREAM, partials, (int)nblk, 1.f / ((float)B * (float)per),
                        loss_out);
-    return check_launch("mse_final");
+    return check_launch("loss_final");
+}
+extern "C" int diqt_loss_clamp_bwd(const float* pred, const float* target, const float* w, float lo, int do_clamp, int kind,
+                                   float gscale, float* dpred, int B, size_t per, void* stream) {
+    DIQT_REQUIRE(pred && target && dpred, DIQT_E_ALIGN, "loss_clamp_bwd: null pointer");
+    DIQT_REQUIRE(B > 0 && per > 0 && kind >= 0 && kind <= 2, DIQT_E_SHAPE, "loss_clamp_bwd: bad shape / kind");
+    const float coef = gscale * 2.f / ((float)B * (float)per);
+    hipLaunchKernelGGL(mse_clamp_bwd_kernel, dim3(grid_for((size_t)B * per, 256, 2048)), dim3(256), 0, STREAM, pred, target, w,
+                       lo, do_clamp, coef, dpred, B, per, kind);
+    return check_launch("loss_clamp_bwd");
+}
+extern "C" int diqt_mse_clamp_fwd(const float* pred, float* pred_clamped, const float* target, const float* w, float lo,
+                                  int do_clamp, float* partials, float* loss_out, int B, size_t per, void* stream) {
+    return diqt_loss_clamp_fwd(pred, pred_clamped, target, w, lo, do_clamp, 0, partials, loss_out, B, per, stream);
 }
 extern "C" int diqt_mse_clamp_bwd(const float* pred, const float* target, const float* w, float lo, int do_clamp,
                                   float gscale, float* dpred, int B, size_t per, void* stream) {
-    DIQT_REQUIRE(pred && target && dpred, DIQT_E_ALIGN, "mse_clamp_bwd: null pointer");
-    DIQT_REQUIRE(B > 0 && per > 0, DIQT_E_SHAPE, "mse_clamp_bwd: bad shape");
-    const float coef = gscale * 2.f / ((float)B * (float)per);
-    hipLaunchKernelGGL(mse_clamp_bwd_kernel, dim3(grid_for((size_t)B * per, 256, 2048)), dim3(256), 0, STREAM, pred, target, w,
-                       lo, do_clamp, coef, dpred, B, per);
-    return check_launch("mse_clamp_bwd");
+    return diqt_loss_clamp_bwd(pred, target, w, lo, do_clamp, 0, gscale, dpred, B, per, stream);
 }
 
 extern "C" int diqt_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
@@ -2130,7 +2230,7 @@ static int shuffle_nd(const float* x, float* y, int B, int D, int H, int W, int 
                       void* stream, const char* what) {
     DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "%s: null pointer", what);
     DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, DIQT_E_SHAPE, "%s: bad shape", what);
-    DIQT_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), DIQT_E_UNSUPPORTED, "%s: factors must be 1 or 2", what);
+    DIQT_REQUIRE(sd >= 1 && sd <= 8 && sh >= 1 && sh <= 8 && sw >= 1 && sw <= 8, DIQT_E_UNSUPPORTED, "%s: factors must be 1 .. 8", what);
     const size_t total = (size_t)B * sd * sh * sw * D * H * W * C;
     hipLaunchKernelGGL(shuffle_nd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, STREAM, x, y, B, D, H, W, C, sd, sh, sw, toSpace);
     return check_launch(what);
@@ -2156,6 +2256,35 @@ extern "C" int diqt_nearest_resize(const float* x, float* y, int B, int D, int H
     hipLaunchKernelGGL(nearest_resize_kernel, dim3(grid_for((size_t)B * Do * Ho * Wo * C, 256)), dim3(256), 0, STREAM, x, y, B,
                        D, H, W, C, Do, Ho, Wo);
     return check_launch("nearest_resize");
+}
+extern "C" int diqt_nearest_resize_bwd(const float* dy, float* dx, int B, int D, int H, int W, int C, int Do, int Ho, int Wo,
+                                       void* stream) {
+    DIQT_REQUIRE(dy && dx, DIQT_E_ALIGN, "nearest_resize_bwd: null pointer");
+    DIQT_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && Do > 0 && Ho > 0 && Wo > 0, DIQT_E_SHAPE, "nearest_resize_bwd: bad shape");
+    DIQT_REQUIRE(Do % D == 0 && Ho % H == 0 && Wo % W == 0, DIQT_E_UNSUPPORTED,
+                 "nearest_resize_bwd: whole-number up-scaling factors only (%dx%dx%d -> %dx%dx%d)", D, H, W, Do, Ho, Wo);
+    hipLaunchKernelGGL(nearest_resize_bwd_kernel, dim3(grid_for((size_t)B * D * H * W * C, 256)), dim3(256), 0, STREAM, dy, dx, B, D, H, W,
+                       C, Do / D, Ho / H, Wo / W);
+    return check_launch("nearest_resize_bwd");
+}
+// rows of d floats, x rows `x_stride` floats apart, y (and dy / dx of the backward) rows `y_stride` apart; inv[rows] (optional in the
+// forward) keeps 1 / max(||x||, 1e-12) for the backward
+extern "C" int diqt_l2norm_rows_fwd(const float* x, float* y, float* inv, size_t rows, int d, int x_stride, int y_stride, void* stream) {
+    DIQT_REQUIRE(x && y, DIQT_E_ALIGN, "l2norm_rows_fwd: null pointer");
+    DIQT_REQUIRE(d > 0 && x_stride >= d && y_stride >= d, DIQT_E_SHAPE, "l2norm_rows_fwd: bad shape");
+    if (rows == 0) return DIQT_OK;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(grid_for((rows + 15) / 16 * 16 * 16, 256)), dim3(256), 0, STREAM, x, y, inv, rows, d,
+                       x_stride, y_stride);
+    return check_launch("l2norm_rows_fwd");
+}
+extern "C" int diqt_l2norm_rows_bwd(const float* y, const float* dy, const float* inv, float* dx, size_t rows, int d, int y_stride,
+                                    int dx_stride, void* stream) {
+    DIQT_REQUIRE(y && dy && inv && dx, DIQT_E_ALIGN, "l2norm_rows_bwd: null pointer");
+    DIQT_REQUIRE(d > 0 && y_stride >= d && dx_stride >= d, DIQT_E_SHAPE, "l2norm_rows_bwd: bad shape");
+    if (rows == 0) return DIQT_OK;
+    hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3(grid_for((rows + 15) / 16 * 16 * 16, 256)), dim3(256), 0, STREAM, y, dy, inv, dx, rows,
+                       d, y_stride, dx_stride);
+    return check_launch("l2norm_rows_bwd");
 }
 extern "C" int diqt_attn_softmax_fwd(const float* sim, const float* rel, const float* null_bias, float* p, int G, int n,
                                      int h, int n_extra, int n_self, int causal, void* stream) {

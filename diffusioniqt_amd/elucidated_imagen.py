@@ -205,19 +205,24 @@ class ElucidatedImagen(nn.Module):
             images = ops.add(images, init_images.to(dev).float())
         fwd = partial(self.preconditioned_network_forward, unet.forward_with_cond_scale, sigma_data=hp.sigma_data, clamp=clamp,
                       dynamic_threshold=dynamic_threshold, cond_scale=cond_scale, **kwargs)
+        self_cond_on = bool(getattr(unet, 'self_cond', False))                   # self-conditioning (:483, 505, 524): the last x0 estimate
+        sc = (lambda x0: dict(self_cond=x0)) if self_cond_on else (lambda x0: {})
+        x_start = None
         for sigma, sigma_next, gamma in sched:
             eps = draw()
             sigma_hat = sigma + gamma * sigma
             images_hat = ops.axpby3(images, eps, None, vec(1.), vec(hp.S_noise * sqrt(max(sigma_hat ** 2 - sigma ** 2, 0.))), None)
-            out = fwd(images_hat, float(sigma_hat))
+            out = fwd(images_hat, float(sigma_hat), **sc(x_start))
             r = (sigma_next - sigma_hat) / sigma_hat
             # x_next = x_hat + (s_next - s_hat) * (x_hat - D)/s_hat
             images_next = ops.axpby3(images_hat, out, None, vec(1. + r), vec(-r), None)
+            x_start = out
             if sigma_next != 0:                                                   # 2nd-order correction (:502-516)
-                out2 = fwd(images_next, float(sigma_next))
+                out2 = fwd(images_next, float(sigma_next), **sc(out))
                 r2 = 0.5 * (sigma_next - sigma_hat) / sigma_next
                 tmp = ops.axpby3(images_hat, out, images_next, vec(1. + 0.5 * r), vec(-0.5 * r), vec(r2))
                 images_next = ops.axpby3(tmp, out2, None, vec(1.), vec(-r2), None)
+                x_start = out2
             images = images_next
         images = ops.axpby3(images, None, None, vec(1.), None, None, -1., 1., 2)    # clamp(-1, 1)   (:527)
         return self.unnormalize_img(images)
@@ -243,7 +248,7 @@ class ElucidatedImagen(nn.Module):
                stop_at_unet_number=None, return_all_unet_outputs=False, return_pil_images=False, use_tqdm=True, device=None,
                noise=None):
         """:536-702.  ``noise``: optional injected list [lowres_noise, init, step_0, ...] per sampled unet (tests)."""
-        assert texts is None and text_embeds is None and cond_images is None and not return_pil_images
+        assert texts is None and text_embeds is None and not return_pil_images
         device = default(device, self.device)
         self.reset_unets_all_one_device(device=device)
         lowres_sample_noise_level = default(lowres_sample_noise_level, self.lowres_sample_noise_level)
@@ -281,6 +286,7 @@ class ElucidatedImagen(nn.Module):
             img = self.one_unet_sample(unet, shape, unet_number=unet_number, init_images=unet_init, skip_steps=unet_skip,
                                        sigma_min=smin, sigma_max=smax, cond_scale=unet_cond_scale, dynamic_threshold=dynamic_threshold,
                                        use_tqdm=use_tqdm, noise=unet_noise,
+                                       **({'cond_images': cond_images.to(device).float()} if exists(cond_images) else {}),
                                        **self._unet_kwargs(unet, lowres_cond_img, lowres_noise_times))
             outputs.append(img)
             if exists(stop_at_unet_number) and stop_at_unet_number == unet_number:
@@ -292,7 +298,7 @@ class ElucidatedImagen(nn.Module):
                 noise=None, sigmas=None, lowres_aug_times=None, lowres_noise=None, lowres_img=None, **kwargs):
         """:712-882 -> scalar loss.  ``noise`` / ``sigmas`` / ``lowres_aug_times`` / ``lowres_noise`` are optional injection
         hooks for parity tests (the reference draws them internally)."""
-        assert texts is None and text_embeds is None and cond_images is None
+        assert texts is None and text_embeds is None
         assert images.shape[-1] == images.shape[-2], \
             f'the images you pass in must be a square, but received dimensions of {images.shape[2]}, {images.shape[-1]}'
         assert not (len(self.unets) > 1 and not exists(unet_number)), \
@@ -343,8 +349,15 @@ class ElucidatedImagen(nn.Module):
         #   w*(c_skip x + c_out F - y)^2 = (w c_out^2) * (F - (y - c_skip x)/c_out)^2
         cin, cskip, cout = (f(hp.sigma_data, sig) for f in (self.c_in, self.c_skip, self.c_out))
         x_in = ops.axpby3(noised, None, None, cin.to(device), None, None)
-        net_out = unet.forward(x_in, self.c_noise(sig).to(device), **self._unet_kwargs(unet, lowres_cond_img, lowres_noise_cond),
-                               **kwargs)
+        ukw = {**self._unet_kwargs(unet, lowres_cond_img, lowres_noise_cond), **kwargs}
+        if exists(cond_images):                                                   # image conditioning of the U-Net (:718, 844)
+            ukw['cond_images'] = cond_images.to(device).float()
+        if getattr(inner, 'self_cond', False) and random() < 0.5:
+            # self-conditioning (:847-860): half of the steps first estimate x0 without gradients and feed it back
+            with torch.no_grad():
+                pred_x0 = self.preconditioned_network_forward(unet.forward, noised, sig, sigma_data=hp.sigma_data, **ukw).detach()
+            ukw['self_cond'] = pred_x0
+        net_out = unet.forward(x_in, self.c_noise(sig).to(device), **ukw)
         target = ops.axpby3(images, noised, None, (1. / cout).to(device), (-cskip / cout).to(device), None)
         weight = (self.loss_weight(hp.sigma_data, sig) * cout ** 2).to(device)
         loss, _ = ops.mse_clamp(net_out, target, do_clamp=False, weight=weight)

@@ -1064,8 +1064,8 @@ class Imagen(nn.Module):
         self.boundary = boundary
         assert not lpips and not medlpips, 'perceptual losses are dead code in the reference (SURVEY.md §2 #10)'
         self.lpips = None
-        if loss_type != 'l2':
-            raise NotImplementedError("only the reference's live loss_type='l2' is built")
+        if loss_type not in ops.LOSS_KINDS:                    # 'l1' F.l1_loss, 'l2' F.mse_loss, 'huber' F.smooth_l1_loss (:1785-1792)
+            raise NotImplementedError()
         self.loss_type = loss_type
         self.min_bound = min_bound
         self.condition_on_text = False
@@ -1316,13 +1316,13 @@ class Imagen(nn.Module):
             weight = ((self.p2_loss_weight_k + log_snr.exp()) ** -p2_loss_weight_gamma).to(device)
         if pred_objective == 'x_start':
             # in-place clamp_(min_bound) + MSE mean in one kernel; returns the clamped pred like the reference (:2361-2364)
-            loss, pred = ops.mse_clamp(pred, x_start, lo=float(self.min_bound), do_clamp=True, weight=weight)
+            loss, pred = ops.mse_clamp(pred, x_start, lo=float(self.min_bound), do_clamp=True, weight=weight, kind=self.loss_type)
         else:
             if pred_objective == 'noise':                                                  # (:2344-2345)
                 target = noise
             else:                                                                          # v = alpha*eps - sigma*x0 (:2348-2352)
                 target = ops.axpby3(noise, x_start, None, alpha.to(device), (-sigma).to(device), None, 0.0, 0.0, 0)
-            loss, pred = ops.mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=weight)
+            loss, pred = ops.mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=weight, kind=self.loss_type)
         return loss, pred, x_noisy, lowres_cond_img
 
     def forward(self, images, lowres_img=None, unet=None, text_embeds=None, text_masks=None, unet_number=None,

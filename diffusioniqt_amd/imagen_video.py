@@ -200,8 +200,9 @@ class Attention(nn.Module):
     def __init__(self, dim, *, dim_head=64, heads=8, causal=False, context_dim=None, cosine_sim_attn=False,
                  rel_pos_bias=False, rel_pos_bias_mlp_depth=2, init_zero=False):
         super().__init__()
-        assert not cosine_sim_attn, 'cosine-sim attention is outside the IQT path'
-        self.scale = dim_head ** -0.5
+        # cosine-sim attention (:427-431, 484-490): unit scale, l2-normalised queries and keys, similarities times 16
+        self.cosine_sim_attn = cosine_sim_attn
+        self.scale = dim_head ** -0.5 if not cosine_sim_attn else 16.
         self.causal, self.heads, self.dim_head = causal, heads, dim_head
         self.rel_pos_bias = DynamicPositionBias(dim=dim, heads=heads, depth=rel_pos_bias_mlp_depth) if rel_pos_bias else None
         inner_dim = dim_head * heads
@@ -220,7 +221,7 @@ class Attention(nn.Module):
 
     def frames_ok(self, G):
         return (not torch.is_grad_enabled() and ops.lp_mode() is None and self.dim_head in (32, 64) and G <= 65535
-                and self.to_context is None)
+                and self.to_context is None and not self.cosine_sim_attn)
 
     def forward_frames(self, x):
         """``Residual(Attention)`` over the FRAME axis of x[B, F, P, C] without leaving that layout (sampling path): what
@@ -257,6 +258,11 @@ class Attention(nn.Module):
             extra = ops.concat_channels(ckv.reshape(G, -1), extra)                # [context..., null]   (:471-481)
         kv_ext = ops.concat_channels(extra, kv.reshape(G, n * 2 * d))             # [G, (E+n)*2d]
         M = E + n
+        if self.cosine_sim_attn:                                                  # l2norm of q and of EVERY key (null, context, self)
+            q = ops.l2norm_rows(q.reshape(G, n * h, d)).reshape(G, n, h * d)
+            kn = ops.l2norm_rows(kv_ext.reshape(G * M, 2 * d), 0, d)              # the k half of the k|v rows
+            _, vv = ops.split_channels(kv_ext.reshape(G * M, 2 * d), d)
+            kv_ext = ops.concat_channels(kn, vv).reshape(G, M * 2 * d)
         rel = null_bias = None
         if exists(self.rel_pos_bias):
             rel = self.rel_pos_bias(n, x.device)                                  # [2n-1, h]
@@ -284,8 +290,9 @@ class CrossAttention(nn.Module):
 
     def __init__(self, dim, *, context_dim=None, dim_head=64, heads=8, norm_context=False, cosine_sim_attn=False):
         super().__init__()
-        assert not cosine_sim_attn and not norm_context
-        self.scale = dim_head ** -0.5
+        assert not norm_context
+        self.cosine_sim_attn = cosine_sim_attn                                    # (:784-786, 826-833)
+        self.scale = dim_head ** -0.5 if not cosine_sim_attn else 16.
         self.heads, self.dim_head = heads, dim_head
         inner_dim = dim_head * heads
         context_dim = default(context_dim, dim)
@@ -306,6 +313,11 @@ class CrossAttention(nn.Module):
         kv = self.to_kv(context)                                                  # [B, m, 2*h*d]  (k heads | v heads)
         null_row = torch.cat((self.null_kv[0].repeat(h), self.null_kv[1].repeat(h))).reshape(1, 2 * h * d).expand(B, -1)
         kv_ext = ops.concat_channels(null_row, kv.reshape(B, m * 2 * h * d)).reshape(B, M, 2 * h * d)   # null first (:817-820)
+        if self.cosine_sim_attn:
+            q = ops.l2norm_rows(q.reshape(B, n * h, d)).reshape(B, n, h * d)
+            kk, vv = ops.split_channels(kv_ext.reshape(B * M, 2 * h * d), h * d)  # (k heads | v heads) per key
+            kk = ops.l2norm_rows(kk.reshape(B * M * h, d)).reshape(B * M, h * d)
+            kv_ext = ops.concat_channels(kk, vv).reshape(B, M, 2 * h * d)
         outs = []
         for b in range(B):
             sim = ops.bmm_strided(q[b], kv_ext[b], (h, n, M, d, False, True, d, h * d, d, 2 * h * d, M, h * M, self.scale,
@@ -474,6 +486,66 @@ class PixelShuffleUpsample(nn.Module):
         return ops.depth_to_space_nd(self.net(x), (1, 2, 2))
 
 
+class TemporalDownsample(nn.Sequential):
+    """nn.Sequential(Rearrange('b c (f p) h w -> b (c p) f h w'), Conv2d(dim * p, dim_out, 1)) (imagen_video.py:636-641); the conv keeps
+    index 1 for the state-dict key."""
+
+    def __init__(self, dim, dim_out=None, stride=2):
+        super().__init__(Identity(), Conv2d(dim * stride, default(dim_out, dim), 1))
+        self.stride = stride
+
+    def forward(self, x):
+        return self[1](ops.space_to_depth_nd(x, (self.stride, 1, 1)))
+
+
+class TemporalPixelShuffleUpsample(nn.Module):
+    """Conv1d(dim, dim_out * r, 1) over the frame axis -> SiLU -> 'b (c r) n -> b c (n r)' (imagen_video.py:604-634)."""
+
+    def __init__(self, dim, dim_out=None, stride=2):
+        super().__init__()
+        self.stride = stride
+        dim_out = default(dim_out, dim)
+        conv = nn.Conv1d(dim, dim_out * stride, 1)
+        self.net = nn.Sequential(conv, SiLU())
+        o, i, f = conv.weight.shape
+        w0 = torch.empty(o // stride, i, f)
+        nn.init.kaiming_uniform_(w0)
+        conv.weight.data.copy_(w0.repeat_interleave(stride, dim=0))
+        nn.init.zeros_(conv.bias.data)
+
+    def forward(self, x):
+        conv = self.net[0]
+        y = self.net[1](ops.linear(x, conv.weight.squeeze(-1), conv.bias))        # per-position linear == the 1-wide conv1d
+        return ops.depth_to_space_nd(y, (self.stride, 1, 1))
+
+
+class UpsampleCombiner(nn.Module):
+    """imagen_video.py:1085-1117: every up-path feature map, resized (nearest) to the output size and passed through a Block, is
+    concatenated to the final feature map."""
+
+    def __init__(self, dim, *, enabled=False, dim_ins=tuple(), dim_outs=tuple()):
+        super().__init__()
+        dim_outs = cast_tuple(dim_outs, len(dim_ins))
+        assert len(dim_ins) == len(dim_outs)
+        self.enabled = enabled
+        if not enabled:
+            self.dim_out = dim
+            return
+        self.fmap_convs = nn.ModuleList([Block(di, do) for di, do in zip(dim_ins, dim_outs)])
+        self.dim_out = dim + (sum(dim_outs) if len(dim_outs) > 0 else 0)
+
+    def forward(self, x, fmaps=None):
+        fmaps = default(fmaps, tuple())
+        if not self.enabled or len(fmaps) == 0 or len(self.fmap_convs) == 0:
+            return x
+        size = x.shape[3]
+        for fmap, conv in zip(fmaps, self.fmap_convs):
+            if fmap.shape[3] != size:                                             # resize_video_to: frames kept, H = W = size
+                fmap = ops.nearest_resize(fmap, (fmap.shape[1], size, size))
+            x = ops.concat_channels(x, conv(fmap))
+        return x
+
+
 class CausalPad(nn.Module):
     """Pad((0,0,0,0,2,0)) of the temporal PEG (imagen_video.py:1351) — folded into the conv's one-sided padding."""
 
@@ -515,13 +587,16 @@ class Unet3D(nn.Module):
         assert attn_heads > 1, 'you need to have more than 1 attention head, ideally at least 4 or 8'
         if cond_on_text or attn_pool_text and cond_on_text:
             raise NotImplementedError('text conditioning (T5) is not part of the IQT hot path (SURVEY.md §2 #13): use cond_on_text=False')
-        unsupported = dict(memory_efficient=memory_efficient, use_linear_attn=use_linear_attn, use_linear_cross_attn=use_linear_cross_attn,
-                           cross_embed_downsample=cross_embed_downsample, cosine_sim_attn=cosine_sim_attn, self_cond=self_cond,
-                           combine_upsample_fmaps=combine_upsample_fmaps, init_conv_to_final_conv_residual=init_conv_to_final_conv_residual,
-                           cond_images=cond_images_channels > 0, nearest_upsample=not pixel_shuffle_upsample)
-        bad = [k for k, v in unsupported.items() if v]
-        if bad or cast_tuple(temporal_strides, len(dim_mults)) != (1,) * len(dim_mults):
-            raise NotImplementedError(f'Unet3D options outside the IQT hot path (SURVEY.md §8): {bad or "temporal_strides"}')
+        # options the REFERENCE itself cannot run (probed against /root/reference): the nearest Upsample doubles the frame
+        # axis too and its output no longer concatenates with the skip tensors (imagen_video.py:556-562 -> RuntimeError in forward),
+        # cross_embed_downsample passes kernel_sizes twice (:1381 -> TypeError in __init__), use_linear_attn's 2-D rearrange meets a 5-D
+        # tensor (:888-955 -> EinopsError in forward).  use_linear_cross_attn works there and is not built.
+        broken = dict(nearest_upsample=not pixel_shuffle_upsample, cross_embed_downsample=cross_embed_downsample, use_linear_attn=use_linear_attn)
+        bad = [k for k, v in broken.items() if v]
+        if bad:
+            raise NotImplementedError(f'Unet3D options that raise in the reference as well: {bad}')
+        if use_linear_cross_attn:
+            raise NotImplementedError('use_linear_cross_attn is outside the IQT hot path (SURVEY.md §8)')
         if dim < 128:
             print_once('The base dimension of your u-net should ideally be no smaller than 128, as recommended by a '
                        'professional DDPM trainer https://nonint.com/2022/05/04/friends-dont-let-friends-train-small-diffusion-models/')
@@ -530,8 +605,9 @@ class Unet3D(nn.Module):
         self.channels_out = default(channels_out, channels)
         init_channels = channels * (1 + int(lowres_cond) + int(self_cond))
         init_dim = default(init_dim, dim)
-        self.has_cond_image = False
-        self.cond_images_channels = 0
+        self.has_cond_image = cond_images_channels > 0
+        self.cond_images_channels = cond_images_channels
+        init_channels += cond_images_channels
 
         self.init_conv = CrossEmbedLayer(init_channels, dim_out=init_dim, kernel_sizes=init_cross_embed_kernel_sizes, stride=1) \
             if init_cross_embed else Conv2d(init_channels, init_dim, init_conv_kernel_size, padding=init_conv_kernel_size // 2)
@@ -577,8 +653,12 @@ class Unet3D(nn.Module):
         layer_attns_depth = cast_tuple(layer_attns_depth, num_layers)
         layer_cross_attns = cast_tuple(layer_cross_attns, num_layers)
         assert all(len(t) == num_layers for t in (resnet_groups, layer_attns, layer_cross_attns))
+        temporal_strides = cast_tuple(temporal_strides, num_layers)
         self.total_temporal_divisor = 1
-        self.init_resnet_block = None
+        for ts in temporal_strides:
+            self.total_temporal_divisor *= ts
+        self.init_resnet_block = resnet_klass(init_dim, init_dim, time_cond_dim=time_cond_dim, groups=resnet_groups[0],
+                                              use_gca=use_global_context_attn) if memory_efficient else None
         self.init_temporal_peg = temporal_peg(init_dim)
         self.init_temporal_attn = temporal_attn(init_dim)
         self.skip_connect_scale = 1. if not scale_skip_connection else (2 ** -0.5)
@@ -586,22 +666,29 @@ class Unet3D(nn.Module):
         self.downs = nn.ModuleList([])
         self.ups = nn.ModuleList([])
         skip_connect_dims = []
-        params = list(zip(num_resnet_blocks, resnet_groups, layer_attns, layer_attns_depth, layer_cross_attns))
-        for ind, ((dim_in, dim_out), (n_blocks, groups, layer_attn, layer_attn_depth, layer_cross_attn)) in enumerate(zip(in_out, params)):
+        params = list(zip(num_resnet_blocks, resnet_groups, layer_attns, layer_attns_depth, layer_cross_attns, temporal_strides))
+        for ind, ((dim_in, dim_out), (n_blocks, groups, layer_attn, layer_attn_depth, layer_cross_attn, temporal_stride)) in enumerate(zip(in_out, params)):
             is_last = ind >= (num_layers - 1)
             layer_cond_dim = cond_dim if layer_cross_attn else None
             current_dim = dim_in
+            pre_downsample = None
+            if memory_efficient:                      # memory-efficient U-Net: down-sample in front of the level's blocks (:1400-1404)
+                pre_downsample = Downsample(dim_in, dim_out)
+                current_dim = dim_out
             skip_connect_dims.append(current_dim)
-            post_downsample = Downsample(current_dim, dim_out) if not is_last else \
-                Parallel(Conv2d(dim_in, dim_out, 3, padding=1), Conv2d(dim_in, dim_out, 1))
+            post_downsample = None
+            if not memory_efficient:
+                post_downsample = Downsample(current_dim, dim_out) if not is_last else \
+                    Parallel(Conv2d(dim_in, dim_out, 3, padding=1), Conv2d(dim_in, dim_out, 1))
             transformer = TransformerBlock(dim=current_dim, depth=layer_attn_depth, ff_mult=ff_mult, context_dim=cond_dim,
                                            **attn_kwargs) if layer_attn else Identity()
             self.downs.append(nn.ModuleList([
-                None,
+                pre_downsample,
                 resnet_klass(current_dim, current_dim, cond_dim=layer_cond_dim, time_cond_dim=time_cond_dim, groups=groups),
                 nn.ModuleList([ResnetBlock(current_dim, current_dim, time_cond_dim=time_cond_dim, groups=groups,
                                            use_gca=use_global_context_attn) for _ in range(n_blocks)]),
-                transformer, temporal_peg(current_dim), temporal_attn(current_dim), None, post_downsample]))
+                transformer, temporal_peg(current_dim), temporal_attn(current_dim),
+                TemporalDownsample(current_dim, stride=temporal_stride) if temporal_stride > 1 else None, post_downsample]))
 
         mid_dim = dims[-1]
         self.mid_block1 = ResnetBlock(mid_dim, mid_dim, cond_dim=cond_dim, time_cond_dim=time_cond_dim, groups=resnet_groups[-1])
@@ -610,24 +697,30 @@ class Unet3D(nn.Module):
         self.mid_temporal_attn = temporal_attn(mid_dim)
         self.mid_block2 = ResnetBlock(mid_dim, mid_dim, cond_dim=cond_dim, time_cond_dim=time_cond_dim, groups=resnet_groups[-1])
 
-        for ind, ((dim_in, dim_out), (n_blocks, groups, layer_attn, layer_attn_depth, layer_cross_attn)) in enumerate(
+        upsample_fmap_dims = []
+        for ind, ((dim_in, dim_out), (n_blocks, groups, layer_attn, layer_attn_depth, layer_cross_attn, temporal_stride)) in enumerate(
                 zip(reversed(in_out), reversed(params))):
             is_last = ind == (len(in_out) - 1)
             layer_cond_dim = cond_dim if layer_cross_attn else None
             skip_connect_dim = skip_connect_dims.pop()
+            upsample_fmap_dims.append(dim_out)
             transformer = TransformerBlock(dim=dim_out, depth=layer_attn_depth, ff_mult=ff_mult, context_dim=cond_dim,
                                            **attn_kwargs) if layer_attn else Identity()
             self.ups.append(nn.ModuleList([
                 resnet_klass(dim_out + skip_connect_dim, dim_out, cond_dim=layer_cond_dim, time_cond_dim=time_cond_dim, groups=groups),
                 nn.ModuleList([ResnetBlock(dim_out + skip_connect_dim, dim_out, time_cond_dim=time_cond_dim, groups=groups,
                                            use_gca=use_global_context_attn) for _ in range(n_blocks)]),
-                transformer, temporal_peg(dim_out), temporal_attn(dim_out), None,
-                PixelShuffleUpsample(dim_out, dim_in) if not is_last else Identity()]))
+                transformer, temporal_peg(dim_out), temporal_attn(dim_out),
+                TemporalPixelShuffleUpsample(dim_out, stride=temporal_stride) if temporal_stride > 1 else None,
+                PixelShuffleUpsample(dim_out, dim_in) if not is_last or memory_efficient else Identity()]))
 
-        self.init_conv_to_final_conv_residual = False
-        self.final_res_block = ResnetBlock(dim, dim, time_cond_dim=time_cond_dim, groups=resnet_groups[0], use_gca=True) \
+        # feature maps of every up level joined to the output (:1471-1478); residual from the initial conv (:1480-1483)
+        self.upsample_combiner = UpsampleCombiner(dim=dim, enabled=combine_upsample_fmaps, dim_ins=upsample_fmap_dims, dim_outs=dim)
+        self.init_conv_to_final_conv_residual = init_conv_to_final_conv_residual
+        final_conv_dim = self.upsample_combiner.dim_out + (dim if init_conv_to_final_conv_residual else 0)
+        self.final_res_block = ResnetBlock(final_conv_dim, dim, time_cond_dim=time_cond_dim, groups=resnet_groups[0], use_gca=True) \
             if final_resnet_block else None
-        final_conv_dim_in = dim + (channels if lowres_cond else 0)
+        final_conv_dim_in = (dim if final_resnet_block else final_conv_dim) + (channels if lowres_cond else 0)
         self.final_conv = Conv2d(final_conv_dim_in, self.channels_out, final_conv_kernel_size, padding=final_conv_kernel_size // 2)
         nn.init.zeros_(self.final_conv.weight)
         nn.init.zeros_(self.final_conv.bias)
@@ -664,18 +757,34 @@ class Unet3D(nn.Module):
                 cond_images=None, self_cond=None, cond_drop_prob=0., ignore_time=False):
         """(x[B,C,F,H,W], time[B]) -> [B,C_out,F,H,W]  (imagen_video.py:1585-1822)."""
         assert x.ndim == 5, 'input to 3d unet must have 5 dimensions (batch, channels, time, height, width)'
-        assert text_embeds is None and cond_images is None
+        assert text_embeds is None
+        frames = x.shape[2]
+        assert ignore_time or frames % self.total_temporal_divisor == 0, \
+            f'number of input frames {frames} must be divisible by {self.total_temporal_divisor}'
         assert not (self.lowres_cond and not exists(lowres_cond_img)), 'low resolution conditioning image must be present'
         assert not (self.lowres_cond and not exists(lowres_noise_times)), 'low resolution conditioning noise time must be present'
         x = to_channels_last(x.float())
+        if self.self_cond:                                                        # (:1605-1609) the previous x0 estimate, or zeros
+            sc = to_channels_last(self_cond.float()) if exists(self_cond) else torch.zeros_like(x)
+            x = ops.concat_channels(x, sc)
         lowres_cl = None
         if exists(lowres_cond_img):
             lowres_cl = to_channels_last(lowres_cond_img.float())
             x = ops.concat_channels(x, lowres_cl)
+        assert not (self.has_cond_image ^ exists(cond_images)), \
+            'you either requested to condition on an image on the unet, but the conditioning image is not supplied, or vice versa'
+        if exists(cond_images):                                                   # (:1621-1627) resized (nearest) and put IN FRONT
+            assert cond_images.shape[1] == self.cond_images_channels, \
+                'the number of channels on the conditioning image you are passing in does not match what you specified on initialiation of the unet'
+            ci = to_channels_last(cond_images.float())
+            if ci.shape[3] != x.shape[3]:
+                ci = ops.nearest_resize(ci, (ci.shape[1], x.shape[3], x.shape[3]))
+            x = ops.concat_channels(ci, x)
         x = self.init_conv(x)
         if not ignore_time:
             x = self.init_temporal_peg(x)
             x = self.init_temporal_attn(x)
+        init_conv_residual = x if self.init_conv_to_final_conv_residual else None
 
         B = x.shape[0]
         _, tok, t = self._time_tokens(self.to_time_hiddens, self.to_time_tokens, self.to_time_cond, time)
@@ -693,8 +802,12 @@ class Unet3D(nn.Module):
             self._time_mlps = BatchedTimeMLPs(m.time_mlp[1] for m in self.modules() if isinstance(m, ResnetBlock) and m.time_mlp is not None)
         t.batched = self._time_mlps(t)
 
+        if exists(self.init_resnet_block):
+            x = self.init_resnet_block(x, t, ignore_time=ignore_time)
         hiddens = []
-        for _, init_block, resnet_blocks, attn_block, temporal_peg, temporal_attn, _, post_downsample in self.downs:
+        for pre_downsample, init_block, resnet_blocks, attn_block, temporal_peg, temporal_attn, temporal_downsample, post_downsample in self.downs:
+            if exists(pre_downsample):
+                x = pre_downsample(x)
             x = init_block(x, t, c, ignore_time=ignore_time)
             for resnet_block in resnet_blocks:
                 x = resnet_block(x, t, ignore_time=ignore_time)
@@ -705,7 +818,10 @@ class Unet3D(nn.Module):
                 x = temporal_peg(x)
                 x = temporal_attn(x)
             hiddens.append(x)
-            x = post_downsample(x)
+            if exists(temporal_downsample) and not ignore_time:
+                x = temporal_downsample(x)
+            if exists(post_downsample):
+                x = post_downsample(x)
 
         x = self.mid_block1(x, t, c, ignore_time=ignore_time)
         if exists(self.mid_attn):
@@ -718,7 +834,10 @@ class Unet3D(nn.Module):
         def add_skip_connection(x):
             return ops.concat_channels(x, ops.scale(hiddens.pop(), self.skip_connect_scale))
 
-        for init_block, resnet_blocks, attn_block, temporal_peg, temporal_attn, _, upsample in self.ups:
+        up_hiddens = []
+        for init_block, resnet_blocks, attn_block, temporal_peg, temporal_attn, temporal_upsample, upsample in self.ups:
+            if exists(temporal_upsample) and not ignore_time:
+                x = temporal_upsample(x)
             x = add_skip_connection(x)
             x = init_block(x, t, c, ignore_time=ignore_time)
             for resnet_block in resnet_blocks:
@@ -729,8 +848,12 @@ class Unet3D(nn.Module):
             if not ignore_time:
                 x = temporal_peg(x)
                 x = temporal_attn(x)
+            up_hiddens.append(x)
             x = upsample(x)
 
+        x = self.upsample_combiner(x, up_hiddens)
+        if exists(init_conv_residual):
+            x = ops.concat_channels(x, init_conv_residual)
         if exists(self.final_res_block):
             x = self.final_res_block(x, t, ignore_time=ignore_time)
         if exists(lowres_cl):

@@ -740,8 +740,7 @@ def gn_conv3d(x, gamma, beta, scale_shift, groups, act, eps, weight, bias, paddi
                   float(eps), s)
     else:
         ws, n = _reduce_ws(B, C, dev)
-        _lib.call("diqt_groupnorm_stats", x, mean, rstd, ws, n, B, rows, C, groups, float(eps), s)
-        _lib.call("diqt_gn_coef", mean, rstd, gamma, beta, scale, shift, cs, coef, B, C, groups, s)
+        _lib.call("diqt_groupnorm_stats_coef", x, gamma, beta, scale, shift, cs, mean, rstd, coef, ws, n, B, rows, C, groups, float(eps), s)
     Do, Ho, Wo = D + 2 * padding[0] + extra_pad[0] - kd + 1, H + 2 * padding[1] + extra_pad[1] - kh + 1, W + 2 * padding[2] + extra_pad[2] - kw + 1
     y = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=dev)
     if TIMER.enabled:
@@ -1037,6 +1036,37 @@ def concat_channels(a, b):
     return _ConcatFn.apply(a.contiguous(), b.contiguous())
 
 
+class _SplitFn(Function):
+    @staticmethod
+    def forward(ctx, x, ca):
+        _chk(x)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        a = torch.empty((*x.shape[:-1], ca), dtype=torch.float32, device=x.device)
+        b = torch.empty((*x.shape[:-1], C - ca), dtype=torch.float32, device=x.device)
+        _lib.call("diqt_split_channels", x, a, ca, b, C - ca, rows, _stream())
+        ctx.set_materialize_grads(False)
+        ctx.cfg = (ca, C - ca, a.shape, b.shape)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, da, db):
+        ca, cb, sa, sb = ctx.cfg
+        ref = da if da is not None else db
+        if ref is None:
+            return None, None
+        da = da.contiguous() if da is not None else torch.zeros(sa, dtype=torch.float32, device=ref.device)
+        db = db.contiguous() if db is not None else torch.zeros(sb, dtype=torch.float32, device=ref.device)
+        dx = torch.empty((*sa[:-1], ca + cb), dtype=torch.float32, device=ref.device)
+        _lib.call("diqt_concat_channels", da, ca, db, cb, dx, da.numel() // ca, _stream())
+        return dx, None
+
+
+def split_channels(x, ca):
+    """(x[..., :ca], x[..., ca:]) as two contiguous tensors (the inverse of ``concat_channels``)."""
+    return _SplitFn.apply(x.contiguous(), int(ca))
+
+
 class _SubvolumeFn(Function):
     """merged volume [1,S,S,S,C] -> sub-volume batch [f^3,A',A',A',C] (halo>0: zero-padded overlap)."""
     @staticmethod
@@ -1320,14 +1350,58 @@ def transpose_mid(x):
     return _TransposeMidFn.apply(x.contiguous())
 
 
+class _NearestResizeFn(Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        _chk(x)
+        B, D, H, W, C = x.shape
+        Do, Ho, Wo = size
+        y = torch.empty((B, Do, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        _lib.call("diqt_nearest_resize", x, y, B, D, H, W, C, Do, Ho, Wo, _stream())
+        ctx.cfg = (B, D, H, W, C, Do, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, D, H, W, C, Do, Ho, Wo = ctx.cfg
+        dx = torch.empty((B, D, H, W, C), dtype=torch.float32, device=dy.device)
+        _lib.call("diqt_nearest_resize_bwd", dy.contiguous(), dx, B, D, H, W, C, Do, Ho, Wo, _stream())       # whole-number up-scaling only
+        return dx, None
+
+
 def nearest_resize(x, size):
-    """F.interpolate(mode='nearest') of a channels-last volume to (Do, Ho, Wo); data preparation, no autograd."""
-    _chk(x)
-    B, D, H, W, C = x.shape
-    Do, Ho, Wo = size
-    y = torch.empty((B, Do, Ho, Wo, C), dtype=torch.float32, device=x.device)
-    _lib.call("diqt_nearest_resize", x, y, B, D, H, W, C, Do, Ho, Wo, _stream())
-    return y
+    """F.interpolate(mode='nearest') of a channels-last volume to (Do, Ho, Wo).  Differentiable for whole-number up-scaling factors
+    (the feature maps of UpsampleCombiner); other sizes are data preparation only."""
+    return _NearestResizeFn.apply(x.contiguous(), tuple(int(v) for v in size))
+
+
+class _L2NormRowsFn(Function):
+    """F.normalize(dim=-1) of the d-wide rows of x[..., stride] taken at column offset ``off`` (rows ``stride`` floats apart)."""
+    @staticmethod
+    def forward(ctx, x, off, d):
+        _chk(x)
+        stride = x.shape[-1]
+        rows = x.numel() // stride
+        y = torch.empty(x.shape[:-1] + (d,), dtype=torch.float32, device=x.device)
+        inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.call("diqt_l2norm_rows_fwd", x.data_ptr() + 4 * off, y, inv, rows, d, stride, d, _stream())
+        ctx.save_for_backward(y, inv)
+        ctx.cfg = (off, d, stride, rows, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        off, d, stride, rows, shape = ctx.cfg
+        dx = torch.zeros(shape, dtype=torch.float32, device=dy.device) if d != stride else torch.empty(shape, dtype=torch.float32, device=dy.device)
+        _lib.call("diqt_l2norm_rows_bwd", y, dy.contiguous(), inv, dx.data_ptr() + 4 * off, rows, d, d, stride, _stream())
+        return dx, None, None
+
+
+def l2norm_rows(x, off=0, d=None):
+    """l2-normalised copy of columns [off, off + d) of every row of x[..., C] (cosine-sim attention: q heads, the k half of k|v rows)."""
+    d = x.shape[-1] if d is None else d
+    return _L2NormRowsFn.apply(x.contiguous(), int(off), int(d))
 
 
 class _AttnSoftmaxFn(Function):
@@ -1548,27 +1622,27 @@ def axpby3(a, b, c, c0, c1, c2, lo=0.0, hi=0.0, clamp_mode=0):
 
 class _MseClampFn(Function):
     @staticmethod
-    def forward(ctx, pred, target, weight, lo, do_clamp):
+    def forward(ctx, pred, target, weight, lo, do_clamp, kind=0):
         _chk(pred, target, weight)
         B = pred.shape[0]
         per = pred.numel() // B
         partials = torch.empty(1024, dtype=torch.float32, device=pred.device)
         loss = torch.empty((), dtype=torch.float32, device=pred.device)
         clamped = torch.empty_like(pred)
-        _lib.call("diqt_mse_clamp_fwd", pred, clamped, target, weight, float(lo), int(do_clamp), partials, loss, B, per,
+        _lib.call("diqt_loss_clamp_fwd", pred, clamped, target, weight, float(lo), int(do_clamp), int(kind), partials, loss, B, per,
                   _stream())
         ctx.mark_non_differentiable(clamped)
         ctx.save_for_backward(clamped, target, weight)
-        ctx.cfg = (float(lo), int(do_clamp), B, per)
+        ctx.cfg = (float(lo), int(do_clamp), B, per, int(kind))
         return loss, clamped
 
     @staticmethod
     def backward(ctx, dloss, _dclamped):
         clamped, target, weight = ctx.saved_tensors
-        lo, do_clamp, B, per = ctx.cfg
+        lo, do_clamp, B, per, kind = ctx.cfg
         dpred = torch.empty_like(clamped)
-        _lib.call("diqt_mse_clamp_bwd", clamped, target, weight, lo, do_clamp, 1.0, dpred, B, per, _stream())
-        return _ScaleByScalar.apply_raw(dpred, dloss), None, None, None, None
+        _lib.call("diqt_loss_clamp_bwd", clamped, target, weight, lo, do_clamp, kind, 1.0, dpred, B, per, _stream())
+        return _ScaleByScalar.apply_raw(dpred, dloss), None, None, None, None, None
 
 
 class _ScaleByScalar:
@@ -1581,11 +1655,14 @@ class _ScaleByScalar:
         return out
 
 
-def mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=None):
-    """mean((clamp_min(pred, lo) - target)^2 * weight[b]); returns (loss, clamped_pred).  The reference clamps
-    ``pred`` in place and returns it (imagen_pytorch3D.py:2361-2364); here the clamped values come back as a
-    separate (non-differentiable) tensor — same numbers, no aliasing of an autograd view."""
-    return _MseClampFn.apply(pred.contiguous(), target.contiguous(), weight, lo, do_clamp)
+LOSS_KINDS = {'l2': 0, 'l1': 1, 'huber': 2}      # F.mse_loss / F.l1_loss / F.smooth_l1_loss (imagen_pytorch3D.py:1785-1790)
+
+
+def mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=None, kind='l2'):
+    """mean(loss(clamp_min(pred, lo) - target) * weight[b]) with loss = square ('l2'), absolute value ('l1') or Huber with beta 1
+    ('huber'); returns (loss, clamped_pred).  The reference clamps ``pred`` in place and returns it (imagen_pytorch3D.py:2361-2364);
+    here the clamped values come back as a separate (non-differentiable) tensor — same numbers, no aliasing of an autograd view."""
+    return _MseClampFn.apply(pred.contiguous(), target.contiguous(), weight, lo, do_clamp, LOSS_KINDS[kind])
 
 
 # --------------------------------------------------------------------------------------------

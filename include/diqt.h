@@ -214,6 +214,9 @@ int diqt_conv3d_fwd_gnbwd_blocks(int B, int D, int H, int W, int Cin, int Cout, 
 int diqt_gn_coef_from_partials(const float* partials, int nblk, int rows, const float* gamma, const float* beta, const float* scale,
                                const float* shift, int cond_stride, float* mean, float* rstd, float* coef, int B, int C, int G,
                                float eps, void* stream);
+int diqt_groupnorm_stats_coef(const float* x, const float* gamma, const float* beta, const float* scale, const float* shift,
+                              int cond_stride, float* mean, float* rstd, float* coef, void* workspace, size_t workspace_bytes, int B,
+                              int rows, int C, int G, float eps, void* stream);      /* diqt_groupnorm_stats + the coefficients */
 int diqt_gn_coef(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
                  int cond_stride, float* coef, int B, int C, int G, void* stream);
 int diqt_conv3d_fwd_gn_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd,
@@ -350,6 +353,15 @@ int diqt_depth_to_space_nd(const float* x, float* y, int B, int D, int H, int W,
 int diqt_transpose_mid(const float* x, float* y, int A, int M, int N, int C, void* stream);
 /* F.interpolate(mode='nearest') on channels-last volumes (resize_video_to imagen_video.py:137-158) */
 int diqt_nearest_resize(const float* x, float* y, int B, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream);
+/* its gradient for whole-number up-scaling factors (UpsampleCombiner's resize_video_to of the up-path feature maps,
+ * imagen_video.py:1085-1117): dx[b][d][h][w][c] = sum of the Do/D x Ho/H x Wo/W copies in dy                                       */
+int diqt_nearest_resize_bwd(const float* dy, float* dx, int B, int D, int H, int W, int C, int Do, int Ho, int Wo, void* stream);
+/* F.normalize(dim = -1) over rows of d floats (the l2norm of cosine-sim attention, imagen_video.py:118-119, 484-486, 828-829): rows of
+ * x are x_stride floats apart (so the k half of a [.., 2d] k|v row can be normalised in place of a copy), rows of y / dy / dx
+ * y_stride / dx_stride apart; inv[rows] = 1 / max(||x||, 1e-12) is kept for the backward dx = (dy - y (y . dy)) inv.               */
+int diqt_l2norm_rows_fwd(const float* x, float* y, float* inv, size_t rows, int d, int x_stride, int y_stride, void* stream);
+int diqt_l2norm_rows_bwd(const float* y, const float* dy, const float* inv, float* dx, size_t rows, int d, int y_stride, int dx_stride,
+                         void* stream);
 /* y[rows][Ca+Cb] = cat(a[rows][Ca], b[rows][Cb]) ; and the inverse split */
 int diqt_concat_channels(const float* a, int Ca, const float* b, int Cb, float* y, size_t rows, void* stream);
 int diqt_split_channels(const float* y, float* a, int Ca, float* b, int Cb, size_t rows, void* stream);
@@ -384,6 +396,12 @@ int diqt_axpby3(const float* a, const float* b_, const float* c_, const float* c
  * — p_losses imagen_pytorch3D.py:2361-2364; the clamped prediction the reference returns is written to
  * pred_clamped (may alias pred for the reference's in-place form, or be NULL).
  * loss_out: single float (atomic-free two-stage reduce through `partials`, >= 1024 floats).          */
+/* diqt_mse_clamp_fwd / _bwd with the per-element loss selected by `kind`: 0 squared error (F.mse_loss), 1 absolute error (F.l1_loss),
+ * 2 Huber with beta 1 (F.smooth_l1_loss) -- Imagen(loss_type = 'l2' | 'l1' | 'huber'), imagen_pytorch3D.py:1785-1790, 2370.        */
+int diqt_loss_clamp_fwd(const float* pred, float* pred_clamped, const float* target, const float* w, float lo, int do_clamp, int kind,
+                        float* partials, float* loss_out, int B, size_t per, void* stream);
+int diqt_loss_clamp_bwd(const float* pred, const float* target, const float* w, float lo, int do_clamp, int kind, float gscale,
+                        float* dpred, int B, size_t per, void* stream);
 int diqt_mse_clamp_fwd(const float* pred, float* pred_clamped, const float* target, const float* w, float lo,
                        int do_clamp, float* partials, float* loss_out, int B, size_t per_batch, void* stream);
 /* dpred = gscale * 2*(pred-target)*w[b]/(B*per_batch), zero where pred was clamped (pred <= lo)      */

@@ -15,9 +15,10 @@ def _q_sample(x0, noise, alpha, sigma):
     return alpha.view(sh) * x0 + sigma.view(sh) * noise
 
 
-def _mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=None):
+def _mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=None, kind='l2'):
     p = pred.clamp(min=lo) if do_clamp else pred
-    losses = ((p - target) ** 2).flatten(1).mean(1)
+    fn = {'l2': torch.nn.functional.mse_loss, 'l1': torch.nn.functional.l1_loss, 'huber': torch.nn.functional.smooth_l1_loss}[kind]
+    losses = fn(p, target, reduction='none').flatten(1).mean(1)
     if weight is not None:
         losses = losses * weight
     return losses.mean(), p.detach()

@@ -312,3 +312,95 @@ def test_temporal_attention_walks_the_frame_axis_in_place(B, F, H, W, C, heads, 
         y_old = mod(x)
     assert torch.isfinite(y_new).all() and (y_new - x).abs().max().item() > 1e-3
     assert torch.equal(y_new, y_old), f"max diff {(y_new - y_old).abs().max().item():.3e}"
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# constructor options beyond the IQT defaults (fixtures of the real reference: oracle/make_golden_opts.py)
+# ------------------------------------------------------------------------------------------------------------------------------------
+OPTION_CASES = ['memeff', 'tstride_a', 'tstride_b', 'cosine', 'selfcond', 'combine', 'initres', 'condimg']
+
+
+def _kw(g):
+    return {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(str(g['kwargs'])).items()}
+
+
+@pytest.mark.parametrize('case', OPTION_CASES)
+def test_unet3d_constructor_option_matches_reference_golden(case):
+    """Unet3D(memory_efficient / temporal_strides / cosine_sim_attn / self_cond / combine_upsample_fmaps /
+    init_conv_to_final_conv_residual / cond_images_channels) on the HIP path: state-dict keys and shapes in the reference's order,
+    forward, (y^2).mean() gradients and the set of parameters without gradient (imagen_video.py:1176-1213, 1371-1492, 1585-1822)."""
+    from diffusioniqt_amd.imagen_video import Unet3D
+    g = load_golden(f'unet3d_opt_{case}')
+    unet = Unet3D(**_kw(g))
+    sd0 = unet.state_dict()
+    assert list(sd0.keys()) == [str(k) for k in g['keys']], "state_dict keys / order differ from the reference"
+    assert [list(v.shape) for v in sd0.values()] == [json.loads(str(s)) for s in g['shapes']]
+    unet.load_state_dict(O.hash_fill_state_dict(sd0, 21))
+    unet = unet.to(DEV).train()
+    extra = {k: T(g[k]).to(DEV) for k in ('cond_images', 'self_cond') if k in g}
+    args = (T(g['x']).to(DEV), T(g['time']).to(DEV))
+    kw = dict(lowres_cond_img=T(g['lowres']).to(DEV), lowres_noise_times=T(g['lowres_times']).to(DEV))
+    y = unet(*args, **kw, **extra)
+    close(y, T(g['y']), 4e-4, f"unet3d {case} fwd")
+    (y ** 2).mean().backward()
+    named = dict(unet.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith('grad:'):
+            assert named[k[5:]].grad is not None, k
+            close(named[k[5:]].grad, T(g[k]), 3e-3, k)
+            n += 1
+    assert n >= 10
+    unused = set(str(u) for u in g['unused'])
+    for k, p in named.items():
+        assert (p.grad is None) == (k in unused), k
+    with torch.no_grad():                                                         # the sampling path (fused kernels) agrees
+        unet.eval()
+        close(unet(*args, **kw, **extra), T(g['y']), 4e-4, f"unet3d {case} fwd (no grad)")
+        if 'y_no_self_cond' in g:
+            close(unet(*args, **kw), T(g['y_no_self_cond']), 4e-4, "self_cond input omitted: zeros")
+
+
+def test_unet3d_options_the_reference_cannot_run_raise():
+    from diffusioniqt_amd.imagen_video import Unet3D
+    g = load_golden('unet3d_opt_memeff')
+    broken = json.loads(str(g['unrunnable']))
+    assert broken == {'nearest_upsample': 'RuntimeError', 'cross_embed_downsample': 'TypeError', 'use_linear_attn': 'EinopsError'}
+    base = {k: v for k, v in _kw(g).items() if k != 'memory_efficient'}
+    for over in (dict(pixel_shuffle_upsample=False), dict(cross_embed_downsample=True), dict(use_linear_attn=True)):
+        with pytest.raises(NotImplementedError):
+            Unet3D(**{**base, **over})
+
+
+def test_edm_self_conditioning_sample_and_loss_match_reference_golden(monkeypatch):
+    """ElucidatedImagen over a self-conditioning Unet3D: the x0 estimate is fed back at every evaluation of the Heun sampler
+    (elucidated_imagen.py:483-524), and training runs a gradient-free estimate first on half of the steps (:847-860)."""
+    from diffusioniqt_amd.imagen_video import Unet3D
+    from diffusioniqt_amd import elucidated_imagen as EI
+    g = load_golden('edm_selfcond')
+    kw = _kw(g)
+    base = Unet3D(**{**kw, 'lowres_cond': False, 'layer_attns': False, 'self_cond': False})
+    sr = Unet3D(**kw)
+    elu = EI.ElucidatedImagen(unets=(base, sr), image_sizes=(8, 8), channels=1, condition_on_text=False, auto_normalize_img=False,
+                              cond_drop_prob=0.0, num_sample_steps=3, dynamic_thresholding=False)
+    u = elu.unets[1]
+    u.load_state_dict(O.hash_fill_state_dict(u.state_dict(), 23))
+    elu = elu.to(DEV)
+    noise = [T(g['lr_noise']), T(g['init_noise'])] + list(T(g['step_noise']))
+    img = elu.sample(batch_size=1, video_frames=4, start_image_or_video=T(g['lowres']).to(DEV), start_at_unet_number=2, use_tqdm=False,
+                     noise=noise)
+    err = (img.cpu() - T(g['img'])).abs()
+    assert err.max().item() <= 5e-3 and (err > 2e-4).float().mean().item() < 0.03, (err.max().item(), (err > 2e-4).float().mean().item())
+    elu.unets[1].train()
+    for tag, draw in (('on', 0.0), ('off', 0.9)):
+        monkeypatch.setattr(EI, 'random', lambda d=draw: d)
+        elu.unets[1].zero_grad(set_to_none=True)
+        loss = elu(T(g['images']).to(DEV), unet_number=2, noise=T(g['loss_noise']), sigmas=T(g['sigmas']),
+                   lowres_aug_times=T(g['aug_t']).repeat(2), lowres_noise=T(g['loss_lr_noise']))
+        ref = float(g[f'loss_{tag}'])
+        assert abs(loss.item() - ref) <= 2e-4 * abs(ref), (tag, loss.item(), ref)
+        loss.backward()
+        named = dict(elu.unets[1].named_parameters())
+        for k in g:
+            if k.startswith(f'grad_{tag}:'):
+                close(named[k.split(':', 1)[1]].grad, T(g[k]), 3e-3, k)

@@ -377,3 +377,35 @@ def test_abs_quantile_matches_torch_quantile():
         ref = torch.quantile(x.flatten(1).abs(), q, dim=-1)
         got = ops.abs_quantile(x.to(DEV), q).cpu()
         assert torch.allclose(got, ref, atol=0, rtol=1e-6), (shape, q, got, ref)
+
+
+@pytest.mark.parametrize("loss_type", ["l1", "huber"])
+def test_imagen_loss_types_match_reference_golden(loss_type):
+    """Imagen(loss_type='l1' | 'huber') -> F.l1_loss / F.smooth_l1_loss (imagen_pytorch3D.py:1785-1790, 2370) through the fused
+    clamp + loss kernel: loss, clamped prediction and gradients against the real reference."""
+    from diffusioniqt_amd.imagen_pytorch3D import Imagen, NullUnet
+    g = load_golden('imagenA_loss_types')
+    gu = load_golden('unetA_tiny')
+    unet, sd, cfg = build(gu, 0)
+    configs = {'Data': {'norm': 'z-score'}, 'Train': {'batch_sample': False}}
+    imagen = Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=float(gu['min_bound']), image_sizes=(8, 8), channels=1,
+                    pred_objectives='x_start', timesteps=4, dynamic_thresholding=False, p2_loss_weight_gamma=0.0, cond_drop_prob=0.0,
+                    loss_type=loss_type).to(DEV)
+    times = T(gu['times'])
+    imagen.noise_schedulers[1].sample_random_times = lambda b, device: times.clone()
+    u = imagen.unets[1].train()
+    loss, pred, _, _ = imagen((T(gu['hr']) * float(g['hr_scale'])).to(DEV), lowres_img=T(gu['lowres']).to(DEV), unet_number=2,
+                              noise=T(gu['noise']).to(DEV))
+    ref = float(g[f'loss_{loss_type}'])
+    assert abs(loss.item() - ref) <= 2e-5 * abs(ref), (loss.item(), ref)
+    close(pred, T(g[f'pred_{loss_type}']), 2e-4, "pred")
+    loss.backward()
+    named = dict(u.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith(f'grad_{loss_type}:'):
+            close(named[k.split(':', 1)[1]].grad, T(g[k]), 1e-3, k)
+            n += 1
+    assert n == 3
+    with pytest.raises(NotImplementedError):
+        Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=0.0, image_sizes=(8, 8), channels=1, loss_type='l3')

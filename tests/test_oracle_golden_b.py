@@ -138,3 +138,88 @@ def test_c5_cascade_layouts():
     up = F.interpolate(T(g['lowres']), (16, 16, 16), mode='nearest')
     s3 = oracle_stage(sd2, cfg2, (1, 1, 16, 16, 16), list(T(g['draws3'])), 3, lowres=up)
     assert (s3 - T(g['img_from2'])).abs().max().item() <= 2e-3, (s3 - T(g['img_from2'])).abs().max()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# constructor options beyond the IQT defaults (oracle/make_golden_opts.py; imagen_video.py:1176-1213, 1371-1492)
+# ------------------------------------------------------------------------------------------------------------------------------------
+import pytest  # noqa: E402
+
+OPTION_CASES = ['memeff', 'tstride_a', 'tstride_b', 'cosine', 'selfcond', 'combine', 'initres', 'condimg']
+
+
+def _kw(g):
+    return {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(str(g['kwargs'])).items()}
+
+
+@pytest.mark.parametrize('case', OPTION_CASES)
+def test_oracle_unet3d_option_matches_reference(case):
+    g = load_golden(f'unet3d_opt_{case}')
+    keys = [str(k) for k in g['keys']]
+    shapes = [tuple(json.loads(str(s))) for s in g['shapes']]
+    sd = O.hash_fill_state_dict({k: torch.zeros(s) for k, s in zip(keys, shapes)}, 21)
+    cfg = OB.unet3d_config(**_kw(g))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    extra = {k: T(g[k]) for k in ('cond_images', 'self_cond') if k in g}
+    y = OB.unet3d_forward(sdg, cfg, T(g['x']), T(g['time']), lowres_cond_img=T(g['lowres']), lowres_noise_times=T(g['lowres_times']), **extra)
+    assert torch.allclose(y, T(g['y']), atol=5e-5, rtol=2e-4), (y - T(g['y'])).abs().max()
+    (y ** 2).mean().backward()
+    n = 0
+    for k in g:
+        if k.startswith('grad:'):
+            ref, got = T(g[k]), sdg[k[5:]].grad
+            assert got is not None, k
+            assert (got - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-7, k
+            n += 1
+    assert n >= 10
+    for k in (str(u) for u in g['unused']):
+        assert sdg[k].grad is None, k
+    if 'y_no_self_cond' in g:
+        with torch.no_grad():
+            y0 = OB.unet3d_forward(sd, cfg, T(g['x']), T(g['time']), lowres_cond_img=T(g['lowres']), lowres_noise_times=T(g['lowres_times']))
+        assert torch.allclose(y0, T(g['y_no_self_cond']), atol=5e-5, rtol=2e-4)
+
+
+def test_oracle_edm_self_conditioning_sample_and_loss():
+    g = load_golden('edm_selfcond')
+    kw = _kw(g)
+    cfg = OB.unet3d_config(**kw)
+    from diffusioniqt_amd.imagen_video import Unet3D          # host-side mirror: only for the parameter names / shapes
+    sd = O.hash_fill_state_dict(Unet3D(**kw).state_dict(), 23)
+    hp = dict(OB.EDM_DEFAULTS, num_sample_steps=3)
+    lt = torch.full((1,), 0.2)                                 # lowres_sample_noise_level default
+    lowres = OB.lowres_q_sample(T(g['lowres']), lt, T(g['lr_noise']))
+    fn = lambda x, cn, **k: OB.unet3d_forward(sd, cfg, x, cn, lowres_cond_img=lowres, lowres_noise_times=lt, **k)
+    with torch.no_grad():
+        img = OB.edm_sample(fn, (1, 1, 4, 8, 8), T(g['init_noise']), list(T(g['step_noise'])), hp, self_cond=True)
+    assert torch.allclose(img, T(g['img']), atol=2e-3, rtol=0), (img - T(g['img'])).abs().max()
+    images, sig = T(g['images']), T(g['sigmas'])
+    aug = T(g['aug_t']).repeat(2)
+    lr_noisy = OB.lowres_q_sample(images, aug, T(g['loss_lr_noise']))
+    cond = OB.beta_linear_log_snr(aug)                          # the log-SNR is the training-time condition (:838)
+    fn2 = lambda x, cn, **k: OB.unet3d_forward(sd, cfg, x, cn, lowres_cond_img=lr_noisy, lowres_noise_times=cond, **k)
+    for tag, draw in (('on', True), ('off', False)):
+        loss = OB.edm_loss(fn2, images, sig, T(g['loss_noise']), hp['sigma_data'], self_cond_draw=draw)
+        ref = float(g[f'loss_{tag}'])
+        assert abs(loss.item() - ref) <= 2e-4 * abs(ref), (tag, loss.item(), ref)
+    assert abs(float(g['loss_on']) - float(g['loss_off'])) > 1e-6
+
+
+def test_oracle_family_a_loss_types():
+    g = load_golden('imagenA_loss_types')
+    gu = load_golden('unetA_tiny')
+    keys = [str(k) for k in gu['keys']]
+    shapes = [tuple(json.loads(str(s))) for s in gu['shapes']]
+    sd = O.hash_fill_state_dict({k: torch.zeros(s) for k, s in zip(keys, shapes)}, 0)
+    cfg = O.unet_config(**json.loads(str(gu['kwargs'])))
+    for lt in ('l1', 'huber'):
+        sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        loss, pred, _, _ = O.p_losses(sdg, cfg, T(gu['hr']) * float(g['hr_scale']), T(gu['lowres']), T(gu['times']), T(gu['noise']),
+                                      min_bound=float(gu['min_bound']), loss_type=lt)
+        ref = float(g[f'loss_{lt}'])
+        assert abs(loss.item() - ref) <= 2e-5 * abs(ref), (lt, loss.item(), ref)
+        loss.backward()
+        for k in g:
+            if k.startswith(f'grad_{lt}:'):
+                r, got = T(g[k]), sdg[k.split(':', 1)[1]].grad
+                assert (got - r).abs().max().item() <= 1e-3 * r.abs().max().item() + 1e-8, k

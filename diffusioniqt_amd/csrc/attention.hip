@@ -1122,6 +1122,340 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward of the SHORT-sequence attentions in ONE kernel (round 3): the temporal attentions of the pseudo-3D U-Net -- thousands of
+// sequences of <= 32 frames, one learned null key in front (E == 1), 8 heads x 64 -- are bound by HBM bytes, not by their five
+// products: q, dO and the forward's output are 8x wider than x (537 MB each at the 32 x 32 level).  The two-kernel backward above reads
+// q and dO twice and `out` once (2.7 GB + the dQ write); here every WAVE takes whole sequences (persistent), keeps K / V of the
+// sequence in registers (and K once more in LDS for the dQ product) and walks its query tiles ONCE:
+//   rows = queries:   S = Q K^T, dP = dO V^T  ->  P, dS  ->  dV^T += dO^T P, dK^T += Q^T dS          (as mqa_flash_bwd_dkv_kernel)
+//   cols = queries:   S^T = K Q^T, dP^T = V dO^T (the SAME operand registers, A and B swapped)  ->  dS^T  ->  dQ^T = K^T dS^T + null key
+// (the score tile is recomputed in both orientations -- 7 MFMA products instead of 5 -- because the accumulator layout of dS feeds
+// the dK^T product directly and that of dS^T the dQ^T product; a transpose through LDS would cost more than 64 MFMAs per tile).
+// delta = rowsum(dO * out) is computed in the kernel from the tile of `out`, which arrives by LDS-DMA (no registers) while the
+// previous tile computes.  Bias-gradient tables accumulate per wave in LDS over all its sequences; one workspace row per wave, summed
+// in a fixed order by attn_bias_reduce_kernel.  Deterministic.
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_at;
+
+template <int ND>
+__global__ __launch_bounds__(256, 1) void mqa_seq_bwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                             const float* __restrict__ rel, const float* __restrict__ null_bias,
+                                                             const float* __restrict__ out, const float* __restrict__ dout,
+                                                             const float* __restrict__ lse, float* __restrict__ dq, float* __restrict__ dkv,
+                                                             float* __restrict__ tbl_part, float* __restrict__ dnull_part, int n, int h,
+                                                             int causal, float scale, int G, int relLds, unsigned outBytes) {
+    constexpr int D = 32 * ND, ROW = D + 4, NPQ = 32 * D / 4 / 64;
+    constexpr int E = 1;
+    extern __shared__ __attribute__((aligned(1024))) float smem_seq[];
+    const int ns = n, M = E + ns, R = n * h;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int TBL = rel ? (2 * ns - 1) * h : 0;
+    // wave-private region: out tile (LDS-DMA target, unpadded, first: 1-KiB aligned) | Q | dO | K | lse | delta | null k|v | bias table
+    constexpr int PERW = 32 * D + 3 * 32 * ROW + 64 + 2 * D;
+    const int perw = (PERW + TBL + 255) / 256 * 256;                               // floats, keeps every wave's DMA target 1-KiB aligned
+    float* const base = smem_seq + (size_t)wave * perw;
+    float* const Os = base;
+    float* const Qs = Os + 32 * D;
+    float* const dOs = Qs + 32 * ROW;
+    float* const Ks = dOs + 32 * ROW;
+    float* const Ls = Ks + 32 * ROW;
+    float* const Dls = Ls + 32;
+    float* const K0s = Dls + 32;
+    float* const tbl = K0s + 2 * D;
+    float* const Rs = smem_seq + (size_t)4 * perw;                                  // shared: rel table, null bias
+    float* const NBs = Rs + relLds;
+    for (int e = threadIdx.x; e < relLds; e += 256) Rs[e] = rel[e];
+    if (null_bias && threadIdx.x < h) NBs[threadIdx.x] = null_bias[threadIdx.x];
+    for (int e = lane; e < TBL; e += 64) tbl[e] = 0.f;
+    __syncthreads();
+    const bool plain = !rel && !null_bias && !causal;      // kernel-uniform
+    const int hs = (h & (h - 1)) == 0 ? __builtin_ctz(h) : -1;
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(out), 0, (int)outBytes, 0x00020000);
+    const unsigned osLds = (unsigned)(size_t)(lds_void_at*)Os;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const int nqt = (R + 31) / 32;
+    float dnb = 0.f;
+    const int nw = gridDim.x * 4;
+
+    for (int g = blockIdx.x * 4 + wave; g < G; g += nw) {
+        // ---- K, V of the sequence: this lane's key j = 1 + l31 ----
+        const int j = E + l31;
+        const bool jvalid = j < M;
+        const int jc = jvalid ? j : M - 1;
+        const float* kvg = kv + ((size_t)g * M + jc) * 2 * D;
+        const float* kv0 = kv + (size_t)g * M * 2 * D;
+        float kreg[D / 2], vreg[D / 2];
+#pragma unroll
+        for (int gq = 0; gq < D / 8; ++gq) {
+            float4 a = *reinterpret_cast<const float4*>(kvg + 8 * gq + 4 * hf);
+            const float4 b = *reinterpret_cast<const float4*>(kvg + D + 8 * gq + 4 * hf);
+            if (!jvalid) a = make_float4(0.f, 0.f, 0.f, 0.f);                       // K^T dS^T must not pick up a clamped row
+            *reinterpret_cast<float4*>(Ks + l31 * ROW + 8 * gq + 4 * hf) = a;       // unscaled: dQ takes the scale at the store
+            kreg[4 * gq] = a.x * scale; kreg[4 * gq + 1] = a.y * scale; kreg[4 * gq + 2] = a.z * scale; kreg[4 * gq + 3] = a.w * scale;
+            vreg[4 * gq] = b.x; vreg[4 * gq + 1] = b.y; vreg[4 * gq + 2] = b.z; vreg[4 * gq + 3] = b.w;
+        }
+        for (int e = lane; e < 2 * D; e += 64) K0s[e] = kv0[e];
+        f32x16 dkt[ND], dvt[ND];
+#pragma unroll
+        for (int c = 0; c < ND; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dkt[c][i] = 0.f; dvt[c][i] = 0.f; }
+        float dkn = 0.f, dvn = 0.f;
+
+        f32x4v pq[NPQ], pdo[NPQ];
+        float pl = 0.f;
+        auto load_q = [&](int qt) __attribute__((always_inline)) {
+            const int r0 = qt * 32;
+#pragma unroll
+            for (int u = 0; u < NPQ; ++u) {
+                const int e = u * 64 + lane;
+                const int row = e / (D / 4), c4 = (e % (D / 4)) * 4;
+                const int rr = min(r0 + row, R - 1);
+                pq[u] = *reinterpret_cast<const f32x4v*>(q + ((size_t)g * R + rr) * D + c4);
+                pdo[u] = *reinterpret_cast<const f32x4v*>(dout + ((size_t)g * R + rr) * D + c4);
+            }
+            pl = lse[(size_t)g * R + min(r0 + l31, R - 1)];
+            // the tile of `out` (32 rows x D floats = 32 D / 256 one-KiB pieces) straight into the LDS; rows past the end: zeros
+#pragma unroll
+            for (int p = 0; p < 32 * D / 256; ++p) {
+                const int row = p * (256 / D) + lane / (D / 4);
+                const unsigned off = (r0 + row < R) ? (unsigned)((((size_t)g * R + r0 + row) * D + (lane % (D / 4)) * 4) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_o, (lds_void_at*)(size_t)(osLds + (unsigned)p * 1024u), 16, off, 0, 0, 0);
+            }
+        };
+        load_q(0);
+        for (int qt = 0; qt < nqt; ++qt) {
+            const int r0 = qt * 32;
+            // ---- registers -> the wave-private LDS tiles; delta of the 32 rows from dO (registers) and `out` (LDS, landed: vmcnt) ----
+            __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): q, dO, lse and the DMA of `out`
+            float dpart[NPQ];
+#pragma unroll
+            for (int u = 0; u < NPQ; ++u) {
+                const int e = u * 64 + lane;
+                const int row = e / (D / 4), c4 = (e % (D / 4)) * 4;
+                *reinterpret_cast<f32x4v*>(Qs + row * ROW + c4) = pq[u];
+                *reinterpret_cast<f32x4v*>(dOs + row * ROW + c4) = pdo[u];
+                const f32x4v ov = *reinterpret_cast<const f32x4v*>(Os + row * D + c4);
+                dpart[u] = pdo[u][0] * ov[0] + pdo[u][1] * ov[1] + pdo[u][2] * ov[2] + pdo[u][3] * ov[3];
+            }
+#pragma unroll
+            for (int u = 0; u < NPQ; ++u) {                // a row's D / 4 pieces sit in D / 4 consecutive lanes
+#pragma unroll
+                for (int o = 1; o < D / 4; o <<= 1) dpart[u] += __shfl_xor(dpart[u], o, 64);
+                if ((lane & (D / 4 - 1)) == 0) Dls[(u * 64 + lane) / (D / 4)] = dpart[u];
+            }
+            if (lane < 32) Ls[lane] = pl;
+            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the reads of Os are done before the next tile's DMA may overwrite it
+            if (qt + 1 < nqt) load_q(qt + 1);              // in flight during this tile's MFMAs
+            const float* qp = Qs + l31 * ROW + 4 * hf;
+            const float* dop = dOs + l31 * ROW + 4 * hf;
+            const float Lq = Ls[l31], dlq = Dls[l31];      // this lane's query row (the columns of the transposed products)
+            const int rq = r0 + l31;
+            const bool rvalid = rq < R;
+            const int rcq = rvalid ? rq : R - 1;
+            int qiq, qhq;
+            if (hs >= 0) { qiq = rcq >> hs; qhq = rcq & (h - 1); } else { qiq = rcq / h; qhq = rcq - qiq * h; }
+            const float nbq = null_bias ? NBs[qhq] : 0.f;
+            // ---- the null key by VALU: p0, ds0 of the 32 rows; its own gradients; dQ starts from its contribution ----
+            float ds0;
+            {
+                float s0 = 0.f, dp0 = 0.f;
+#pragma unroll
+                for (int gq = 0; gq < D / 8; ++gq) {
+                    const float4 a = *reinterpret_cast<const float4*>(qp + 8 * gq);
+                    const float4 b = *reinterpret_cast<const float4*>(dop + 8 * gq);
+                    const float4 kk = *reinterpret_cast<const float4*>(K0s + 8 * gq + 4 * hf);
+                    const float4 vv = *reinterpret_cast<const float4*>(K0s + D + 8 * gq + 4 * hf);
+                    s0 = fmaf(a.x, kk.x, s0); s0 = fmaf(a.y, kk.y, s0); s0 = fmaf(a.z, kk.z, s0); s0 = fmaf(a.w, kk.w, s0);
+                    dp0 = fmaf(b.x, vv.x, dp0); dp0 = fmaf(b.y, vv.y, dp0); dp0 = fmaf(b.z, vv.z, dp0); dp0 = fmaf(b.w, vv.w, dp0);
+                }
+                s0 += __shfl_xor(s0, 32, 64);
+                dp0 += __shfl_xor(dp0, 32, 64);
+                const float p0 = rvalid ? __expf(s0 * scale + nbq - Lq) : 0.f;
+                ds0 = p0 * (dp0 - dlq);
+                if (hf == 0) dnb += ds0;
+                if (lane < D) {
+#pragma unroll
+                    for (int rr = 0; rr < 32; ++rr) {
+                        const float pb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p0), rr));
+                        const float db = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ds0), rr));
+                        dvn = fmaf(pb, dOs[rr * ROW + lane], dvn);
+                        dkn = fmaf(db, Qs[rr * ROW + lane], dkn);
+                    }
+                }
+            }
+            // ---- the four score products share their operand reads: S = Q K^T, dP = dO V^T (rows = queries), S^T, dP^T (cols = queries) ----
+            f32x16 s, dp, st, dpt;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; st[i] = 0.f; dpt[i] = 0.f; }
+            {
+                f32x4a qa = *reinterpret_cast<const f32x4a*>(qp), da = *reinterpret_cast<const f32x4a*>(dop);
+#pragma unroll
+                for (int gq = 0; gq < D / 8; ++gq) {
+                    f32x4a qn = qa, dn = da;
+                    if (gq + 1 < D / 8) {
+                        qn = *reinterpret_cast<const f32x4a*>(qp + 8 * (gq + 1));
+                        dn = *reinterpret_cast<const f32x4a*>(dop + 8 * (gq + 1));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kreg[4 * gq + e], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da[e], vreg[4 * gq + e], dp, 0, 0, 0);
+                        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[4 * gq + e], qa[e], st, 0, 0, 0);
+                        dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[4 * gq + e], da[e], dpt, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                    qa = qn; da = dn;
+                }
+            }
+            // ---- rows = queries: P = exp(S + bias - L[row]), dS = P (dP - delta[row]) (as mqa_flash_bwd_dkv_kernel) ----
+            f32x16 ds;
+            {
+                float lrow[16], drow[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 lv = *reinterpret_cast<const float4*>(Ls + 8 * q4 + 4 * hf);
+                    const float4 dv = *reinterpret_cast<const float4*>(Dls + 8 * q4 + 4 * hf);
+                    lrow[4 * q4] = lv.x; lrow[4 * q4 + 1] = lv.y; lrow[4 * q4 + 2] = lv.z; lrow[4 * q4 + 3] = lv.w;
+                    drow[4 * q4] = dv.x; drow[4 * q4 + 1] = dv.y; drow[4 * q4 + 2] = dv.z; drow[4 * q4 + 3] = dv.w;
+                }
+                if (plain) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int rr = r0 + acc_row(i, hf);
+                        const float ex = __expf(s[i] - lrow[i]);
+                        const float p = (!jvalid || rr >= R) ? 0.f : ex;
+                        s[i] = p;
+                        ds[i] = p * (dp[i] - drow[i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int rr = r0 + acc_row(i, hf);
+                        const int rcl = min(rr, R - 1);
+                        int qi, qh;
+                        if (hs >= 0) { qi = rcl >> hs; qh = rcl & (h - 1); } else { qi = rcl / h; qh = rcl - qi * h; }
+                        const float rvv = rel ? Rs[attn_rel_index(j, E, ns, h, qi, qh)] : 0.f;
+                        const float sv = attn_bias_apply(s[i], j, M, E, qi, causal, rel != nullptr, rvv, 0.f);
+                        const float ex = __expf(sv - lrow[i]);
+                        const float p = (sv == -INFINITY || rr >= R) ? 0.f : ex;
+                        s[i] = p;
+                        ds[i] = p * (dp[i] - drow[i]);
+                    }
+                }
+            }
+            // ---- dV^T += dO^T P, dK^T += Q^T dS ----
+            {
+                float oc[ND], qc[ND], on[ND], qn2[ND];
+#pragma unroll
+                for (int c = 0; c < ND; ++c) { oc[c] = dOs[acc_row(0, hf) * ROW + l31 + 32 * c]; qc[c] = Qs[acc_row(0, hf) * ROW + l31 + 32 * c]; }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i + 1 < 16) {
+                        const int row = acc_row(i + 1, hf);
+#pragma unroll
+                        for (int c = 0; c < ND; ++c) { on[c] = dOs[row * ROW + l31 + 32 * c]; qn2[c] = Qs[row * ROW + l31 + 32 * c]; }
+                    }
+#pragma unroll
+                    for (int c = 0; c < ND; ++c) {
+                        dvt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(oc[c], s[i], dvt[c], 0, 0, 0);
+                        dkt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[c], ds[i], dkt[c], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * ND, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * ND, 0);
+#pragma unroll
+                    for (int c = 0; c < ND; ++c) { oc[c] = on[c]; qc[c] = qn2[c]; }
+                }
+            }
+            // ---- cols = queries: dS^T = exp(S^T + bias - L) (dP^T - delta) for this lane's query; bias-gradient table; dQ^T ----
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int jj = E + acc_row(i, hf);
+                const float rvv = rel ? Rs[attn_rel_index(jj, E, ns, h, qiq, qhq)] : 0.f;
+                const float sv = attn_bias_apply(st[i], jj, M, E, qiq, causal, rel != nullptr, rvv, 0.f);
+                const float p = (sv == -INFINITY) ? 0.f : __expf(sv - Lq);
+                st[i] = rvalid ? p * (dpt[i] - dlq) : 0.f;
+            }
+            if (rel) {                                     // kernel-uniform; the lane halves (keys 4 apart) update one after the other
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (hf == half && rvalid) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int jj = E + acc_row(i, hf);
+                            if (jj < M) {
+                                const int idx = max(0, min(qiq - (jj - E) + ns - 1, 2 * ns - 2));
+                                tbl[idx * h + qhq] += st[i];
+                            }
+                        }
+                    }
+                }
+            }
+            f32x16 dqt[ND];
+#pragma unroll
+            for (int c = 0; c < ND; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dqt[c][i] = ds0 * K0s[32 * c + acc_row(i, hf)];
+            {
+                float kc[ND], kn2[ND];
+#pragma unroll
+                for (int c = 0; c < ND; ++c) kc[c] = Ks[acc_row(0, hf) * ROW + l31 + 32 * c];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i + 1 < 16) {
+                        const float* kq = Ks + acc_row(i + 1, hf) * ROW + l31;
+#pragma unroll
+                        for (int c = 0; c < ND; ++c) kn2[c] = kq[32 * c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < ND; ++c) dqt[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[c], st[i], dqt[c], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, ND, 0);
+#pragma unroll
+                    for (int c = 0; c < ND; ++c) kc[c] = kn2[c];
+                }
+            }
+            if (rvalid) {
+                float* dqg = dq + ((size_t)g * R + rq) * D;
+#pragma unroll
+                for (int c = 0; c < ND; ++c)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        const int dd = 32 * c + 8 * (i >> 2) + 4 * hf;
+                        *reinterpret_cast<float4*>(dqg + dd) = make_float4(dqt[c][i] * scale, dqt[c][i + 1] * scale, dqt[c][i + 2] * scale, dqt[c][i + 3] * scale);
+                    }
+            }
+        }
+        // ---- dK, dV of the sequence (K carried the scale for S: the gradient takes it once more), the null row ----
+        if (jvalid) {
+            float* og = dkv + ((size_t)g * M + j) * 2 * D;
+#pragma unroll
+            for (int c = 0; c < ND; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    const int dd = 32 * c + 8 * (i >> 2) + 4 * hf;
+                    *reinterpret_cast<float4*>(og + dd) = make_float4(dkt[c][i] * scale, dkt[c][i + 1] * scale, dkt[c][i + 2] * scale, dkt[c][i + 3] * scale);
+                    *reinterpret_cast<float4*>(og + D + dd) = make_float4(dvt[c][i], dvt[c][i + 1], dvt[c][i + 2], dvt[c][i + 3]);
+                }
+        }
+        if (lane < D) {
+            float* og = dkv + (size_t)g * M * 2 * D;
+            og[lane] = dkn * scale;
+            og[D + lane] = dvn;
+        }
+    }
+    // ---- bias-gradient partials of this wave: one row of the workspace each ----
+    const size_t wrow = (size_t)blockIdx.x * 4 + wave;
+    if (TBL) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int e = lane; e < TBL; e += 64) tbl_part[wrow * TBL + e] = tbl[e];
+    }
+    if (dnull_part && hf == 0) dnull_part[wrow * 32 + l31] = dnb;
+}
+
 static int attn_bwd_rows(int G, int n, int h) {
     const int gx = (int)(((long long)n * h + AQ - 1) / AQ), gy = G < 256 ? G : 256;
     return gy * gx * 4;
@@ -1161,6 +1495,35 @@ extern "C" int diqt_mqa_attention_bwd(const float* q, const float* kv, const flo
     float* delta = static_cast<float*>(workspace);
     float* tbl_part = delta + (size_t)G * R;
     float* dnull_part = tbl_part + (size_t)rows * TBL;
+    {
+        // thousands of short sequences with the lone null key (the temporal attentions): everything in one pass, a sequence per wave
+        static const bool noSeq = [] { const char* e = getenv("DIQT_ATTN_NO_SEQ"); return e && e[0] == '1'; }();
+        const unsigned long long ob = (unsigned long long)G * R * d * 4ull;
+        const int relLds = rel ? TBL : 0;
+        const int perw = (32 * d + 3 * 32 * (d + 4) + 64 + 2 * d + TBL + 255) / 256 * 256;
+        const size_t lds = ((size_t)4 * perw + relLds + 64) * sizeof(float);
+        if (!noSeq && n_extra == 1 && n_self == n && n <= 32 && 32 % h == 0 && G >= 2048 && ob < (1ull << 31) && lds <= 160 * 1024) {
+            const int nwg = (G + 3) / 4 < 256 ? (G + 3) / 4 : 256;
+            auto kern = d == 64 ? mqa_seq_bwd_kernel<2> : mqa_seq_bwd_kernel<1>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "mqa_attention_bwd(seq): hipFuncSetAttribute: %s", hipGetErrorString(e));
+            float* dnp = tbl_part + (size_t)nwg * 4 * TBL;                          // (nwg * 4 <= rows: fits the workspace of the two-kernel path)
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, q, kv, rel, null_bias, out, dout, lse, dq, dkv, tbl_part,
+                               null_bias ? dnp : (float*)nullptr, n, h, causal, scale, G, relLds, (unsigned)ob);
+            int rc = check_launch("mqa_attention_bwd(seq)");
+            if (rc) return rc;
+            if (rel || null_bias) {
+                const int ntb = rel ? (TBL + 63) / 64 : 0;
+                const size_t lds_r = (size_t)(256 * h > 256 ? 256 * h : 256) * sizeof(float);
+                // lane l of a wave's row always carries head l % h here (32 % h == 0): gx = 1 and an unbounded R give exactly that mapping
+                hipLaunchKernelGGL(attn_bias_reduce_kernel, dim3((unsigned)(ntb + (null_bias ? 1 : 0))), dim3(256), lds_r, s, tbl_part, dnp,
+                                   rel ? drel : (float*)nullptr, null_bias ? dnull : (float*)nullptr, nwg * 4, TBL, 1, h, 0x7fffffff, ntb);
+                rc = check_launch("mqa_attention_bwd(seq, bias reduce)");
+                if (rc) return rc;
+            }
+            return DIQT_OK;
+        }
+    }
     {
         const dim3 grid(gx, gy);
         const size_t lds = (size_t)4 * TBL * sizeof(float);

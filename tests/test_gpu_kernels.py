@@ -536,6 +536,8 @@ def _mqa_ref(q, kv, rel, nb, n, h, d, E, causal, scale):
     (300, 8, 2, 32, 1, True, True),      # more batch entries than resident workgroups: the persistent walk of the dQ kernel
     (2051, 12, 2, 32, 1, True, True),    # thousands of short sequences: the dK/dV kernel gives every WAVE a sequence (ragged last workgroup)
     (2048, 20, 4, 64, 1, False, False),  # ... dim_head 64, no bias / mask
+    (2100, 32, 8, 64, 1, True, True),    # the temporal attention at its real shape: the one-pass short-sequence kernel (mqa_seq_bwd_kernel)
+    (2300, 7, 2, 32, 1, True, False),    # ... ragged query tile (14 rows), bias without mask, dim_head 32
     (1, 1, 8, 64, 1, True, True)])
 def test_fused_mqa_attention_backward(ops, G, n, h, d, E, use_rel, causal):
     """diqt_mqa_attention_fwd_lse / diqt_mqa_attention_bwd (flash-style: no stored scores) against float64 autograd of the

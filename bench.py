@@ -482,7 +482,7 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
             elu3.sample(batch_size=B, video_frames=S, start_image_or_video=lr.clamp(-1, 1), start_at_unet_number=2, use_tqdm=False)
         dts = timed(u3_edm, 1, 1)
         u3.train()
-        dtt = timed(u3_train, 1, 2) / 2
+        dtt = timed(u3_train, 2, 4) / 4
         result["unet3d_edm"] = dict(eval_ms=1e3 * dte, eval_patches_per_s=world * B / dte,
                                     eval_tflops=GFLOP_U3_EVAL * B / (1e3 * dte), eval_frac_of_f32_mfma_peak=GFLOP_U3_EVAL * B / (1e3 * dte) / PEAK_F32_MFMA_TFLOPS,
                                     heun_steps=n3, unet_evals=2 * n3 - 1, ms_per_heun_step=1e3 * dts / n3, patch_steps_per_s=world * B * n3 / dts,

@@ -115,6 +115,9 @@ PROTOTYPES = {
     "diqt_attn_softmax_bwd_ws": (I, [P, P, P, P, P, P, Z, I, I, I, I, I, I, P]),
     "diqt_mqa_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "diqt_mqa_attention_fwd_frames": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P]),
+    "diqt_set_convh_workgroups": (I, [I]),
+    "diqt_temporal_attention_h_supported": (I, [I, I, I, I, I, I]),
+    "diqt_temporal_attention_h": (I, [P] * 10 + [I, I, I, I, I, I, I, F, I, I, P]),
     "diqt_mqa_attention_fwd_lse": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "diqt_mqa_attention_bwd_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
     "diqt_mqa_attention_bwd": (I, [P] * 11 + [P, Z, I, I, I, I, I, I, I, F, P]),

@@ -16,6 +16,7 @@
 // Packed weights: half/bf16 [chunk = ci/32][tap][co padded to 64][32 ci]  (conv_pack_weight_h_kernel).
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace diqt {
 
@@ -331,9 +332,249 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
     }
 }
 
+// The same kernel, PERSISTENT: a workgroup walks a contiguous range of (tile, channel-block) units, so that the prologue of the
+// one-unit kernel above -- coordinate tables, the first halo chunk and the first weight group, ~25 % of a workgroup's lifetime with
+// nothing else resident on the CU to hide it -- is paid once: the next unit's first halo chunk is prefetched into registers during
+// the last tap group of the current unit, the weight pipeline runs on across units, and the output stores of a unit leave before
+// its closing barrier.  Per-thread halo coordinates are fixed for the whole kernel (the tile geometry is), so a unit's source
+// offsets are a few integer operations per piece instead of an LDS table.  Only for halo tiles that fit the register prefetch.
+template <bool BF, int OCC, int NHR, int TGM>       // workgroups per CU, halo pieces per thread, most taps per weight group
+__global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
+                                                              const float* __restrict__ bias, const float* __restrict__ residual,
+                                                              float* __restrict__ y, HalfGeom g, int nUnits, int perWg) {
+    constexpr int NWR = (TGM * 256 + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const int HV = g.HD * g.HH * g.HWd;
+    unsigned char* halo = hsm;                                         // [HV][80 B]
+    unsigned char* wbuf = hsm + (size_t)HV * HROWB;                    // [2][TG][64][80 B]
+    const int wbufBytes = g.TG * HNT * HROWB;
+    int* out_off = reinterpret_cast<int*>(wbuf + 2 * (size_t)wbufBytes);   // [2][256]: by unit parity
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int T = g.kd * g.kh * g.kw;
+    const int hq = tid & 7;
+    const int nHalo = HV * 8;
+
+    const int uBegin = blockIdx.x * perWg, uEnd = min(uBegin + perWg, nUnits);
+    if (uBegin >= uEnd) return;
+
+    // halo pieces of this thread: coordinates inside the halo tile, fixed for the kernel
+    unsigned pc[NHR];
+#pragma unroll
+    for (int u = 0; u < NHR; ++u) {
+        const int idx = u * 512 + tid, hv = min(idx >> 3, HV - 1);
+        const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
+        pc[u] = (unsigned)hz | ((unsigned)hy << 8) | ((unsigned)hx << 16) | (idx < nHalo ? 0u : 1u << 24);
+    }
+    const int otw = tid % g.TW, oth = (tid / g.TW) % g.TH, otd = tid / (g.TW * g.TH);      // tid < 256: this thread's out_off entry
+
+    struct Unit { int b, d0, h0, w0, n0; };
+    auto decode = [&](int L) {
+        Unit t;
+        t.n0 = (L % g.nNt) * HNT;
+        int mt = L / g.nNt;
+        t.w0 = (mt % g.tilesW) * g.TW; mt /= g.tilesW;
+        t.h0 = (mt % g.tilesH) * g.TH; mt /= g.tilesH;
+        t.d0 = (mt % g.tilesD) * g.TD;
+        t.b = mt / g.tilesD;
+        return t;
+    };
+    auto write_out_table = [&](const Unit& t, int par) {
+        if (tid < HMT) {
+            const int od = t.d0 + otd, oh = t.h0 + oth, ow = t.w0 + otw;
+            int off = (int)HBUF_OOB;
+            if (od < g.Do && oh < g.Ho && ow < g.Wo) off = (((t.b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout * 4;
+            out_off[par * HMT + tid] = off;
+        }
+    };
+    unsigned srcv[NHR];
+    auto unit_sources = [&](const Unit& t) {
+#pragma unroll
+        for (int u = 0; u < NHR; ++u) {
+            const int hz = pc[u] & 255, hy = (pc[u] >> 8) & 255, hx = (pc[u] >> 16) & 255;
+            const int iz = t.d0 + hz - g.pd, iy = t.h0 + hy - g.ph, ix = t.w0 + hx - g.pw;
+            const bool ok = !(pc[u] >> 24) && iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            srcv[u] = ok ? (unsigned)((((t.b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin) * 4u : HBUF_OOB;
+        }
+    };
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
+
+    u32x4 hr[NHR];
+    auto halo_load = [&](int ci0) {
+        const unsigned coff = (ci0 + hq * 4 < g.Cin) ? (unsigned)(ci0 + hq * 4) * 4u : HBUF_OOB_C;
+#pragma unroll
+        for (int u = 0; u < NHR; ++u) hr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, srcv[u] + coff, 0, 0);
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < NHR; ++u) {
+            const int idx = u * 512 + tid;
+            if (idx < nHalo) {
+                u32x2 p;
+                p.x = pack2<BF>(asf(hr[u].x), asf(hr[u].y));
+                p.y = pack2<BF>(asf(hr[u].z), asf(hr[u].w));
+                *reinterpret_cast<u32x2*>(halo + (idx >> 3) * HROWB + hq * 8) = p;
+            }
+        }
+    };
+    u32x4 wr[NWR];
+    auto load_wgroup = [&](int chunk, int t0, int n, int n0) {
+        const unsigned short* src = wp + ((size_t)chunk * T * g.CoutPad + n0) * HCK;
+#pragma unroll
+        for (int u = 0; u < NWR; ++u) {
+            const int idx = u * 512 + tid;
+            const int tap = min(idx >> 8, n - 1), row = (idx >> 2) & 63, q = idx & 3;
+            wr[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(t0 + tap) * g.CoutPad + row) * HCK + q * 8);
+        }
+    };
+    auto store_wgroup = [&](int buf, int n) {
+        unsigned char* dst = wbuf + buf * wbufBytes;
+#pragma unroll
+        for (int u = 0; u < NWR; ++u) {
+            const int idx = u * 512 + tid;
+            const int tap = idx >> 8, row = (idx >> 2) & 63, q = idx & 3;
+            if (tap < n) *reinterpret_cast<u32x4*>(dst + (tap * HNT + row) * HROWB + q * 16) = wr[u];
+        }
+    };
+
+    int a_base;
+    {
+        const int v = wave * 32 + l31;
+        const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
+        a_base = ((td * g.HH + th) * g.HWd + tw) * HROWB + h * 16;
+    }
+    const int b_base = l31 * HROWB + h * 16;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    Unit cur = decode(uBegin);
+    write_out_table(cur, 0);
+    unit_sources(cur);
+    halo_load(0);
+    load_wgroup(0, 0, min(g.TG, T), cur.n0);
+    halo_store();
+    store_wgroup(0, min(g.TG, T));
+    __syncthreads();
+
+    int step = 0;
+    for (int un = uBegin; un < uEnd; ++un) {
+        const bool hasNext = un + 1 < uEnd;
+        Unit nxt = cur;
+        if (hasNext) {
+            nxt = decode(un + 1);
+            write_out_table(nxt, (un + 1 - uBegin) & 1);       // read in the next unit's epilogue: at least this unit's closing barrier between
+        }
+        for (int chunk = 0; chunk < g.nChunks; ++chunk) {
+            for (int grp = 0; grp < g.nGroups; ++grp, ++step) {
+                const int t0 = grp * g.TG, nTap = min(g.TG, T - t0);
+                const bool lastGrp = grp + 1 == g.nGroups, lastStep = lastGrp && chunk + 1 == g.nChunks;
+                const bool more = !lastStep || hasNext;
+                const int nchunk = lastStep ? 0 : (lastGrp ? chunk + 1 : chunk), nt0 = lastGrp ? 0 : t0 + g.TG, nn = min(g.TG, T - nt0);
+                if (more) load_wgroup(nchunk, nt0, nn, lastStep ? nxt.n0 : cur.n0);
+                const bool pref = lastGrp && more;
+                if (pref) {
+                    if (lastStep) unit_sources(nxt);
+                    halo_load(lastStep ? 0 : (chunk + 1) * HCK);
+                }
+                const unsigned char* wcur = wbuf + (step & 1) * wbufBytes + b_base;
+                const unsigned char* ap = halo + a_base;
+                int kx = t0 % g.kw, ky = (t0 / g.kw) % g.kh, kz = t0 / (g.kw * g.kh);
+                int toff = ((kz * g.HH + ky) * g.HWd + kx) * HROWB;
+                auto next_tap = [&]() {
+                    toff += HROWB;
+                    if (++kx == g.kw) {
+                        kx = 0; toff += (g.HWd - g.kw) * HROWB;
+                        if (++ky == g.kh) { ky = 0; toff += (g.HH - g.kh) * g.HWd * HROWB; }
+                    }
+                };
+                if constexpr (OCC == 2) {
+                    // four waves per SIMD: the other waves cover a tap's fragment reads, no register double-buffering (128 registers)
+                    for (int t = 0; t < nTap; ++t) {
+                        const unsigned char* wn = wcur + t * (HNT * HROWB);
+                        const u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + toff), a1 = *reinterpret_cast<const u32x4*>(ap + toff + 32);
+                        const u32x4 b00 = *reinterpret_cast<const u32x4*>(wn), b01 = *reinterpret_cast<const u32x4*>(wn + 32);
+                        const u32x4 b10 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB), b11 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB + 32);
+                        acc0 = mfma16<BF>(a0, b00, acc0);
+                        acc1 = mfma16<BF>(a0, b10, acc1);
+                        acc0 = mfma16<BF>(a1, b01, acc0);
+                        acc1 = mfma16<BF>(a1, b11, acc1);
+                        next_tap();
+                    }
+                } else {
+                u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + toff), a1 = *reinterpret_cast<const u32x4*>(ap + toff + 32);
+                u32x4 b00 = *reinterpret_cast<const u32x4*>(wcur), b01 = *reinterpret_cast<const u32x4*>(wcur + 32);
+                u32x4 b10 = *reinterpret_cast<const u32x4*>(wcur + 32 * HROWB), b11 = *reinterpret_cast<const u32x4*>(wcur + 32 * HROWB + 32);
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): see conv_fwd_h_kernel
+                for (int t = 0; t < nTap; ++t) {
+                    u32x4 na0, na1, nb00, nb01, nb10, nb11;
+                    if (t + 1 < nTap) {
+                        next_tap();
+                        const unsigned char* wn = wcur + (t + 1) * (HNT * HROWB);
+                        na0 = *reinterpret_cast<const u32x4*>(ap + toff); na1 = *reinterpret_cast<const u32x4*>(ap + toff + 32);
+                        nb00 = *reinterpret_cast<const u32x4*>(wn); nb01 = *reinterpret_cast<const u32x4*>(wn + 32);
+                        nb10 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB); nb11 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB + 32);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0 = mfma16<BF>(a0, b00, acc0);
+                    acc1 = mfma16<BF>(a0, b10, acc1);
+                    acc0 = mfma16<BF>(a1, b01, acc0);
+                    acc1 = mfma16<BF>(a1, b11, acc1);
+                    if (t + 1 < nTap) { a0 = na0; a1 = na1; b00 = nb00; b01 = nb01; b10 = nb10; b11 = nb11; }
+                }
+                }
+                if (lastStep) {
+                    // ---- epilogue of this unit (before its closing barrier: the stores drain while the next unit is staged) ----
+                    const int* oo = out_off + ((un - uBegin) & 1) * HMT + wave * 32 + 4 * h;
+                    const int co0 = cur.n0 + l31, co1 = cur.n0 + 32 + l31;
+                    const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
+                    const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
+                    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : HBUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : HBUF_OOB_C;
+                    constexpr int RB = OCC == 2 ? 8 : 16;          // residual rows in flight together
+#pragma unroll
+                    for (int r0 = 0; r0 < 16; r0 += RB) {
+                        float rr0[RB], rr1[RB];
+                        if (residual) {            // kernel-uniform
+#pragma unroll
+                            for (int r = 0; r < RB; ++r) {
+                                const unsigned off = (unsigned)oo[((r0 + r) & 3) + 8 * ((r0 + r) >> 2)];
+                                rr0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
+                                rr1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) {
+                            const unsigned off = (unsigned)oo[((r0 + r) & 3) + 8 * ((r0 + r) >> 2)];
+                            float v0 = acc0[r0 + r] + bias0, v1 = acc1[r0 + r] + bias1;
+                            if (g.roundOut) { v0 = round_through<BF>(v0); v1 = round_through<BF>(v1); }
+                            if (residual) { v0 += rr0[r]; v1 += rr1[r]; }
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+                            acc0[r0 + r] = 0.f; acc1[r0 + r] = 0.f;
+                        }
+                    }
+                }
+                if (more) store_wgroup((step + 1) & 1, nn);
+                if (pref) {
+                    __syncthreads();                     // every wave is done with this chunk's halo image
+                    halo_store();
+                }
+                __syncthreads();
+            }
+        }
+        cur = nxt;
+    }
+}
+
 static size_t half_lds_bytes(const HalfGeom& g) {
     const size_t HV = (size_t)g.HD * g.HH * g.HWd;
-    return HV * HROWB + 2 * (size_t)g.TG * HNT * HROWB + (HMT + HV) * sizeof(int);
+    const size_t tables = (HMT + HV) > 2 * HMT ? (HMT + HV) : 2 * HMT;      // one-unit kernel: out_off + halo_src; persistent: out_off x 2
+    return HV * HROWB + 2 * (size_t)g.TG * HNT * HROWB + tables * sizeof(int);
 }
 
 static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
@@ -427,6 +668,22 @@ extern "C" int diqt_conv3d_fwd_h_supported(int B, int D, int H, int W, int Cin, 
     return half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw) ? 1 : 0;
 }
 
+// workgroups of the persistent low-precision kernel (default 256 = one per CU; DIQT_CONVH_WGS): a launch of fewer than twice as many
+// (tile, channel-block) units stays on the one-unit kernel.  n > 0 sets it (tests force the persistent walk on small shapes), n <= 0
+// only queries; returns the previous value.
+static std::atomic<int> g_convh_wgs{0};
+extern "C" int diqt_set_convh_workgroups(int n) {
+    int cur = g_convh_wgs.load();
+    if (cur == 0) {
+        const char* e = getenv("DIQT_CONVH_WGS");
+        const int v = e && atoi(e) > 0 ? atoi(e) : 256;
+        g_convh_wgs.compare_exchange_strong(cur, v);
+        cur = g_convh_wgs.load();
+    }
+    if (n > 0) g_convh_wgs.store(n);
+    return cur;
+}
+
 extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const float* bias, const float* residual, float* y, int B, int D,
                                  int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph,
                                  int epw, int bf16, int round_out, void* stream) {
@@ -452,6 +709,26 @@ extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const flo
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    static const bool persist = [] { const char* e = getenv("DIQT_CONVH_PERSIST"); return !(e && e[0] == '0'); }();
+    const int pwgs = diqt_set_convh_workgroups(0);
+    if (persist && pref && !g.dbg && nwg >= 2u * (unsigned)pwgs) {
+        // (two workgroups per CU -- 6 halo pieces per thread, weight groups of <= 5 taps, 128 registers per wave -- measured 1.4x SLOWER
+        // on the 64^3 level-0 shapes: the kernel is bound by vector-ALU issue of the staging / epilogue code, not by exposed latency)
+        const bool two = false;
+        void (*kp)(const float*, const unsigned short*, const float*, const float*, float*, HalfGeom, int, int) =
+            bf16 ? conv_fwd_hp_kernel<true, 1, HHREG, HTG> : conv_fwd_hp_kernel<false, 1, HHREG, HTG>;
+        const HalfGeom& g2 = g;
+        const size_t ldsp = lds;
+        if (ldsp > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+            DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        const int wgs = two ? 2 * pwgs : pwgs;
+        const int perWg = (int)((nwg + wgs - 1) / wgs), grid = (int)((nwg + perWg - 1) / perWg);
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, x, static_cast<const unsigned short*>(packed_h), bias,
+                           residual, y, two ? g2 : g, (int)nwg, perWg);
+        return check_launch("conv3d_fwd_h(persistent)");
     }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, (hipStream_t)stream, x, static_cast<const unsigned short*>(packed_h), bias,
                        residual, y, g);

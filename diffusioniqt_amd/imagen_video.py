@@ -116,6 +116,9 @@ class TokensOverTime(nn.Module):
     def forward(self, x, **kwargs):
         B, F, H, W, C = x.shape
         fn = self.fn.fn if isinstance(self.fn, Residual) else None
+        if isinstance(fn, Attention) and not kwargs and fn.block_ok(B, F, H * W, C):
+            # sampling under autocast: the whole block -- both LayerNorms, the projections, the attention, the residual -- in one kernel
+            return fn.forward_block(x.reshape(B, F, H * W, C)).reshape(B, F, H, W, C)
         if isinstance(fn, Attention) and not kwargs and fn.frames_ok(B * H * W):
             # sampling: LayerNorm and the projections are per-row, and the attention kernel walks the frame axis in place
             return fn.forward_frames(x.reshape(B, F, H * W, C)).reshape(B, F, H, W, C)
@@ -222,6 +225,26 @@ class Attention(nn.Module):
     def frames_ok(self, G):
         return (not torch.is_grad_enabled() and ops.lp_mode() is None and self.dim_head in (32, 64) and G <= 65535
                 and self.to_context is None and not self.cosine_sim_attn)
+
+    def block_ok(self, B, F, P, C):
+        return (not torch.is_grad_enabled() and ops.lp_mode() is not None and self.to_context is None and not self.cosine_sim_attn
+                and ops.temporal_attention_h_ok(B, F, P, C, self.heads, self.dim_head))
+
+    def forward_block(self, x):
+        """``Residual(Attention)`` over the frame axis of x[B, F, P, C] as ONE kernel (sampling path under autocast)."""
+        lp = ops.lp_mode()
+        ws = (self.to_q.weight, self.to_kv.weight, self.to_out[0].weight)
+        key = (lp, ops._WEIGHT_EPOCH) + tuple((w.data_ptr(), w._version) for w in ws)
+        hit = getattr(self, '_packed_h', None)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_temporal_attention_h(*ws, self.heads, self.dim_head, self.scale, lp))
+            self._packed_h = hit
+        rel = null_bias = None
+        if exists(self.rel_pos_bias):
+            rel = self.rel_pos_bias(x.shape[1], x.device).contiguous()
+            null_bias = self.null_attn_bias.contiguous()
+        return ops.temporal_attention_h(x, self.norm.g, hit[1], self.to_out[1].g, self.null_kv.reshape(-1).contiguous(), rel, null_bias,
+                                        self.heads, self.dim_head, self.causal, 1e-5, lp)
 
     def forward_frames(self, x):
         """``Residual(Attention)`` over the FRAME axis of x[B, F, P, C] without leaving that layout (sampling path): what

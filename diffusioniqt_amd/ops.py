@@ -198,14 +198,20 @@ def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0):
     kd, kh, kw = weight.shape[2:]
     Cout = weight.shape[0] if mode == 0 else weight.shape[1]
     geo = (B, D, H, W, Cin, Cout, kd, kh, kw, *pad, *epad)
-    if not _lib.query("diqt_conv3d_fwd_h_supported", *geo):
-        return None
+    Bc = B                      # batch entries per launch: the kernel addresses a tensor through one buffer descriptor (< 1 GiB)
+    while not _lib.query("diqt_conv3d_fwd_h_supported", Bc, *geo[1:]):
+        if Bc % 2 or max(x5[:Bc].numel(), Bc * D * H * W * Cout) * 4 < (1 << 30):
+            return None
+        Bc //= 2
     Do, Ho, Wo = D + 2 * pad[0] + epad[0] - kd + 1, H + 2 * pad[1] + epad[1] - kh + 1, W + 2 * pad[2] + epad[2] - kw + 1
     y = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=x5.device)
     if TIMER.enabled:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-    _lib.call("diqt_conv3d_fwd_h", x5, _packed_h(weight, bf16, mode), bias, residual, y, *geo, bf16, 1, _stream())
+    packed = _packed_h(weight, bf16, mode)
+    for b0 in range(0, B, Bc):
+        _lib.call("diqt_conv3d_fwd_h", x5[b0:b0 + Bc], packed, bias, residual[b0:b0 + Bc] if residual is not None else None,
+                  y[b0:b0 + Bc], Bc, *geo[1:], bf16, 1, _stream())
     if TIMER.enabled:
         e.record()
         TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_h_kernel",
@@ -1456,6 +1462,34 @@ def mqa_attention_frames_nograd(q, kv, null_kv, rel, null_bias, h, d, causal, sc
     out = torch.empty_like(q)
     _lib.call("diqt_mqa_attention_fwd_frames", q, kv, null_kv, rel, null_bias, out, B, F, P, h, d, int(causal), float(scale), _stream())
     return out
+
+
+def temporal_attention_h_ok(B, F, P, C, h, d):
+    return bool(_lib.query("diqt_temporal_attention_h_supported", B, F, P, C, h, d))
+
+
+def pack_temporal_attention_h(to_q_w, to_kv_w, to_out_w, h, d, scale, lp):
+    """16-bit operand copies of an Attention block's projections for diqt_temporal_attention_h: scale * to_q.weight [h d, C],
+    to_kv.weight [2 d, C], and to_out.weight [C, h d] as [h][C][d] with a head's channels in the MFMA accumulator order."""
+    dt = torch.bfloat16 if lp == 1 else torch.float16
+    C = to_out_w.shape[0]
+    wq = (to_q_w.detach().float() * scale).to(dt).contiguous()
+    wkv = to_kv_w.detach().to(dt).contiguous()
+    i = torch.arange(d, device=to_out_w.device)
+    pos = 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3)
+    wo = torch.empty((h, C, d), dtype=dt, device=to_out_w.device)
+    wo[:, :, pos] = to_out_w.detach().reshape(C, h, d).permute(1, 0, 2).to(dt)
+    return wq.view(torch.int16), wkv.view(torch.int16), wo.view(torch.int16)
+
+
+def temporal_attention_h(x, norm_g, packed, out_g, null_kv, rel, null_bias, h, d, causal, eps, lp):
+    """y = LayerNorm(Attention(LayerNorm(x)) W_o) + x over the frame axis of x[B, F, P, C], one kernel (sampling path, autocast)."""
+    _chk(x, norm_g, out_g, null_kv, rel, null_bias)
+    B, F, P, C = x.shape
+    y = torch.empty_like(x)
+    _lib.call("diqt_temporal_attention_h", x, norm_g, packed[0], packed[1], packed[2], out_g, null_kv, rel, null_bias, y, B, F, P, C,
+              h, d, int(causal), float(eps), lp, 1, _stream())
+    return y
 
 
 class _MqaAttentionFn(Function):

@@ -86,6 +86,10 @@ int diqt_conv_pack_weight_h(const float* w_oidhw, void* packed_h, int Cout, int 
                             void* stream);   /* mode as in diqt_conv_pack_weight: 1 = flipped / swapped packing for backward-data */
 int diqt_conv3d_fwd_h_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                                 int epd, int eph, int epw);
+/* diqt_conv3d_fwd_h walks (tile, channel-block) units with a persistent kernel of this many workgroups (default 256, one per CU;
+ * env DIQT_CONVH_WGS; DIQT_CONVH_PERSIST=0 disables it) when a launch has at least twice as many units and the halo tile fits the
+ * register prefetch; n > 0 sets the count, n <= 0 only queries; returns the previous value.  Results do not depend on it.      */
+int diqt_set_convh_workgroups(int n);
 int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const float* bias, const float* residual, float* y, int B, int D, int H,
                       int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, int bf16,
                       int round_out, void* stream);
@@ -511,6 +515,19 @@ int diqt_mqa_attention_fwd(const float* q, const float* kv, const float* rel, co
  * diqt_mqa_attention_fwd; same kernel, bit-identical results.                                                                      */
 int diqt_mqa_attention_fwd_frames(const float* q, const float* kv, const float* nullkv, const float* rel, const float* null_bias,
                                   float* out, int B, int F, int P, int h, int d, int causal, float scale, void* stream);
+/* The whole temporal attention block of the pseudo-3D U-Net as one kernel (sampling path under autocast): per sequence (b, p) of F frames
+ *     y = LayerNorm(Attention(LayerNorm(x; norm_g)) W_o; out_g) + x
+ * -- Residual(EinopsToAndFrom('b c f h w', '(b h w) f c', Attention(dim, causal, rel_pos_bias))), imagen_video.py:1351-1354, 410-525 --
+ * on x[B][F][P][C] fp32 as it stands.  16-bit MFMA operands (fp16, or bf16 when `bf16`), fp32 accumulation, soft-max and LayerNorms;
+ * q, k, v, scores and head outputs never leave the CU.  Weights, 16-bit: wq_h[h d][C] = scale * to_q.weight, wkv_h[2 d][C] =
+ * to_kv.weight, wo_h[h][C][d] = to_out.weight[c][head d] with the 64 channels of a head in the accumulator order
+ * pos(d) = 16 (d >> 4) + 8 ((d >> 2) & 1) + 4 ((d >> 3) & 1) + (d & 3).  null_kv[2][d], rel[2F-1][h] / null_bias[h] (both or neither).
+ * round_out: round the to_out product to the operand type before the LayerNorm (what autocast's Linear returns).
+ * Shapes: d = 64, h in {4, 8}, F in {32, 64}, C in {64, 128, 256} (diqt_temporal_attention_h_supported).                              */
+int diqt_temporal_attention_h_supported(int B, int F, int P, int C, int h, int d);
+int diqt_temporal_attention_h(const float* x, const float* norm_g, const void* wq_h, const void* wkv_h, const void* wo_h,
+                              const float* out_g, const float* null_kv, const float* rel, const float* null_bias, float* y,
+                              int B, int F, int P, int C, int h, int d, int causal, float eps, int bf16, int round_out, void* stream);
 int diqt_mqa_attention_fwd_lse(const float* q, const float* kv, const float* rel, const float* null_bias, float* out, float* lse,
                                int G, int n, int h, int d, int n_extra, int n_self, int causal, float scale, void* stream);
 size_t diqt_mqa_attention_bwd_workspace_bytes(int G, int n, int h, int d, int n_extra, int n_self, int has_rel);

@@ -63,6 +63,16 @@ def test_conv_half_is_bit_exact_on_integer_data(shape, mode):
     ref = ref_conv(x, w, bias, pad, epad, LP[mode])
     assert y.shape == ref.shape
     assert torch.equal(y.cpu(), ref), (y.cpu() - ref).abs().max()
+    # the persistent walk of the same kernel (production: launches of >= 512 units): 1 and 3 workgroups over all units, with a residual
+    res = torch.randint(-5, 6, tuple(ref.shape), generator=g).float()
+    for wgs in (1, 3):
+        prev = _lib.query("diqt_set_convh_workgroups", wgs)
+        try:
+            with ops.low_precision(mode), torch.no_grad():
+                yp = ops.conv3d(x.to(DEV), w.to(DEV), bias.to(DEV), pad, residual=res.to(DEV), extra_pad=epad)
+        finally:
+            _lib.query("diqt_set_convh_workgroups", prev)
+        assert torch.equal(yp.cpu(), ref + res), (wgs, (yp.cpu() - ref - res).abs().max())
 
 
 @pytest.mark.parametrize("mode", ["fp16", "bf16"])
@@ -281,3 +291,75 @@ def test_fused_attention_low_precision(G, n, h, d, E, use_rel, causal, mode):
         full = ops.mqa_attention_nograd(q.to(DEV), kv.to(DEV), rel.to(DEV) if use_rel else None, nb.to(DEV) if use_rel else None,
                                         n, h, d, E, n, causal, scale).cpu().double()
     assert not torch.equal(full, got)          # the low-precision kernel really ran
+
+
+def _temporal_block_ref(x, attn, dt, causal):
+    """float64 model of diqt_temporal_attention_h with the kernel's rounding points: LayerNorm output, the projections' weights,
+    q / k / v, the un-normalised probabilities, the head outputs and the to_out product are rounded to the operand type."""
+    r = lambda t: t.to(dt).double()
+    B, Fr, P, C = x.shape
+    h, d = attn.heads, attn.dim_head
+    xd = x.double().permute(0, 2, 1, 3).reshape(B * P, Fr, C)                     # sequences (b, p) of F frames
+    ln = lambda t, g: (t - t.mean(-1, keepdim=True)) * (t.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt() * g.double()
+    xn = r(ln(xd, attn.norm.g.detach().cpu()).float())
+    wq = r((attn.to_q.weight.detach().cpu() * attn.scale))
+    wkv, wo = r(attn.to_kv.weight.detach().cpu()), r(attn.to_out[0].weight.detach().cpu())
+    q = r((xn @ wq.T).float()).reshape(-1, Fr, h, d)
+    kv = r((xn @ wkv.T).float())
+    k, v = kv[..., :d], kv[..., d:]
+    nk, nv = r(attn.null_kv.detach().cpu())
+    sim = torch.einsum('gihd,gjd->gihj', q, k)
+    i = torch.arange(Fr)[:, None]; j = torch.arange(Fr)[None, :]
+    with torch.no_grad():
+        rel = attn.rel_pos_bias(Fr, torch.device(DEV, 0)).detach().cpu().double()
+    sim = sim + rel[(i - j + Fr - 1)].permute(0, 2, 1)[None]
+    if causal:
+        sim = sim.masked_fill((j > i)[None, :, None, :], float('-inf'))
+    snull = torch.einsum('gihd,d->gih', q, nk) + attn.null_attn_bias.detach().cpu().double()
+    m = torch.maximum(sim.amax(-1), snull)
+    p, pn = (sim - m[..., None]).exp(), (snull - m).exp()
+    l = p.sum(-1) + pn
+    o = (torch.einsum('gihj,gjd->gihd', r(p.float()), v) + r(pn.float())[..., None] * nv) / l[..., None]
+    o = r(o.float()).reshape(-1, Fr, h * d)
+    yo = r((o @ wo.T).float())
+    out = ln(yo, attn.to_out[1].g.detach().cpu()) + xd
+    return out.reshape(B, P, Fr, C).permute(0, 2, 1, 3), yo
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,Fr,P,C,h,causal", [(2, 64, 20, 64, 8, False), (1, 32, 37, 64, 8, True), (2, 64, 9, 128, 8, False),
+                                               (1, 32, 300, 128, 4, False), (1, 64, 530, 64, 4, True), (1, 64, 11, 256, 8, False),
+                                               (2, 32, 5, 256, 8, True)])
+def test_temporal_attention_block_one_kernel(B, Fr, P, C, h, causal, mode):
+    """diqt_temporal_attention_h = Residual(Attention) over the frame axis, in place on [B, F, H, W, C]: against the float64 model
+    of its own rounding points, against the unfused autocast chain, and selected by TokensOverTime under autocast only."""
+    from diffusioniqt_amd import ops
+    from diffusioniqt_amd.imagen_video import Attention, Residual, TokensOverTime
+    dt = LP[mode]
+    ulp = 2.0 ** -10 if mode == 'fp16' else 2.0 ** -7
+    torch.manual_seed(B * 1000 + P)
+    attn = Attention(C, heads=h, dim_head=64, causal=causal, rel_pos_bias=True, init_zero=False)
+    with torch.no_grad():
+        attn.norm.g.uniform_(0.5, 1.5)
+        attn.to_out[1].g.uniform_(0.5, 1.5)
+    blk = TokensOverTime(Residual(attn)).to(DEV).eval()
+    Hh = 1
+    x = torch.randn(B, Fr, Hh, P, C)
+    xg = x.to(DEV)
+    with torch.no_grad():
+        y32 = blk(xg).cpu()
+        with torch.autocast('cuda', dtype=dt):
+            assert attn.block_ok(B, Fr, P, C)
+            got = blk(xg).cpu()
+            attn.block_ok = lambda *a: False                     # the unfused autocast chain
+            chain = blk(xg).cpu()
+            del attn.block_ok
+        assert not attn.block_ok(B, Fr, P, C)                    # fp32: never
+    ref, yo = _temporal_block_ref(x.reshape(B, Fr, P, C), attn, dt, causal)
+    ref = ref.reshape(B, Fr, Hh, P, C)
+    # the to_out product carries ~1 ulp of relative error (rounded operands of fp32 sums); the LayerNorm behind it scales rows to unit variance
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 6 * ulp * (ref - x.double()).abs().max().item(), (err, (ref - x.double()).abs().max().item())
+    assert rel(got.double() - x.double(), ref - x.double()) <= 1.5 * ulp
+    assert not torch.equal(got, y32) and not torch.equal(got, chain)
+    assert rel(got - x, y32 - x) <= 6 * ulp and rel(got - x, chain - x) <= 6 * ulp

@@ -9,7 +9,7 @@ dim, S, B = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 32, 8
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 unet = Unet3D(dim=dim, dim_mults=(1, 2, 4), channels=1, cond_on_text=False, text_embed_dim=None, lowres_cond=True,
-              layer_attns=(False, False, True), layer_cross_attns=False, attend_at_middle=True, num_resnet_blocks=2,
+              layer_attns=False if os.environ.get('NO_LAYER_ATTNS') == '1' else (False, False, True), layer_cross_attns=False, attend_at_middle=True, num_resnet_blocks=2,
               attn_pool_text=False).to(dev).eval()
 x = torch.randn(B, 1, S, S, S, device=dev)
 lr = torch.randn(B, 1, S, S, S, device=dev)

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "diqt_depth_to_space2": (I, [P, P, I, I, I, I, I, P]),
     "diqt_concat_channels": (I, [P, I, P, I, P, Z, P]),
     "diqt_split_channels": (I, [P, P, I, P, I, Z, P]),
+    "diqt_concat_channels_scaled": (I, [P, I, P, I, F, F, P, Z, P]),
+    "diqt_split_channels_scaled": (I, [P, P, I, P, I, F, F, Z, P]),
     "diqt_subvolume_gather": (I, [P, P, I, I, I, I, P]),
     "diqt_subvolume_scatter": (I, [P, P, I, I, I, I, I, P]),
     "diqt_q_sample": (I, [P, P, P, P, P, I, Z, P]),
@@ -116,6 +118,8 @@ PROTOTYPES = {
     "diqt_mqa_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "diqt_mqa_attention_fwd_frames": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P]),
     "diqt_set_convh_workgroups": (I, [I]),
+    "diqt_conv3d_fwd_smallcout_supported": (I, [I] * 15),
+    "diqt_conv3d_fwd_smallcout": (I, [P, P, P, P, P] + [I] * 15 + [P]),
     "diqt_temporal_attention_h_supported": (I, [I, I, I, I, I, I]),
     "diqt_temporal_attention_h": (I, [P] * 10 + [I, I, I, I, I, I, I, F, I, I, P]),
     "diqt_mqa_attention_fwd_lse": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, P]),

@@ -408,16 +408,32 @@ __global__ __launch_bounds__(512, 1) void mqa_flash_fwd_h_kernel(const float* __
             for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sacc[kb][i]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);
-        const float corr = (mnew == -INFINITY) ? 1.f : __expf(mrun - mnew);
-        float psum = 0.f;
+        constexpr float LOG2E = 1.4426950408889634f;
+        float corr, psum = 0.f;
+        if (plain) {
+            // every key of the tile is live, so mnew is finite: exp(s - m) = 2^(s log2e - m log2e) is ONE fma + v_exp_f32 per score
+            // and needs no guard (this loop is vector-ALU bound: 2 waves per SIMD spend more issue cycles here than on the 16 MFMAs)
+            const float mneg = -mnew * LOG2E;
+            corr = __builtin_amdgcn_exp2f(fmaf(mrun, LOG2E, mneg));            // mrun = -inf on the first tile: 2^-inf = 0
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pv = (mnew == -INFINITY) ? 0.f : __expf(sacc[kb][i] - mnew);
-                sacc[kb][i] = pv;
-                psum += pv;
-            }
+                for (int i = 0; i < 16; ++i) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], LOG2E, mneg));
+                    sacc[kb][i] = pv;
+                    psum += pv;
+                }
+        } else {
+            corr = (mnew == -INFINITY) ? 1.f : __expf(mrun - mnew);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pv = (mnew == -INFINITY) ? 0.f : __expf(sacc[kb][i] - mnew);
+                    sacc[kb][i] = pv;
+                    psum += pv;
+                }
+        }
         psum += __shfl_xor(psum, 32, 64);
         lrun = lrun * corr + psum;
         mrun = mnew;

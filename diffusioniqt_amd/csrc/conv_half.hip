@@ -17,6 +17,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 
 namespace diqt {
 
@@ -360,25 +361,46 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     const int uBegin = blockIdx.x * perWg, uEnd = min(uBegin + perWg, nUnits);
     if (uBegin >= uEnd) return;
 
-    // halo pieces of this thread: coordinates inside the halo tile, fixed for the kernel
-    unsigned pc[NHR];
+    // halo pieces of this thread, fixed for the kernel: the coordinates inside the halo tile as three 10-bit fields (range tests of a
+    // unit's source voxel are then two subtractions on guarded fields instead of six compares) and the byte offset inside the tile
+    constexpr unsigned GUARD = (1u << 9) | (1u << 19) | (1u << 29), ONES = 16u | (16u << 10) | (16u << 20);      // ONES: PADB in every field
+    unsigned pc[NHR], prel[NHR];
 #pragma unroll
     for (int u = 0; u < NHR; ++u) {
         const int idx = u * 512 + tid, hv = min(idx >> 3, HV - 1);
         const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
-        pc[u] = (unsigned)hz | ((unsigned)hy << 8) | ((unsigned)hx << 16) | (idx < nHalo ? 0u : 1u << 24);
+        pc[u] = idx < nHalo ? ((unsigned)hz | ((unsigned)hy << 10) | ((unsigned)hx << 20)) : 0x3fffffffu;     // past the tile: never in range
+        prel[u] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin) * 4u;
     }
+    constexpr int PADB = 16;
+    const unsigned limits = (unsigned)(g.D + PADB - 1) | ((unsigned)(g.H + PADB - 1) << 10) | ((unsigned)(g.W + PADB - 1) << 20);
+    const bool wide = g.D > 448 || g.H > 448 || g.W > 448 || g.pd > PADB || g.ph > PADB || g.pw > PADB;
     const int otw = tid % g.TW, oth = (tid / g.TW) % g.TH, otd = tid / (g.TW * g.TH);      // tid < 256: this thread's out_off entry
 
-    struct Unit { int b, d0, h0, w0, n0; };
+    struct Unit { int b, d0, h0, w0, n0, nt, tx, ty, tz; };
     auto decode = [&](int L) {
         Unit t;
-        t.n0 = (L % g.nNt) * HNT;
+        t.nt = L % g.nNt;
         int mt = L / g.nNt;
-        t.w0 = (mt % g.tilesW) * g.TW; mt /= g.tilesW;
-        t.h0 = (mt % g.tilesH) * g.TH; mt /= g.tilesH;
-        t.d0 = (mt % g.tilesD) * g.TD;
+        t.tx = mt % g.tilesW; mt /= g.tilesW;
+        t.ty = mt % g.tilesH; mt /= g.tilesH;
+        t.tz = mt % g.tilesD;
         t.b = mt / g.tilesD;
+        t.n0 = t.nt * HNT; t.w0 = t.tx * g.TW; t.h0 = t.ty * g.TH; t.d0 = t.tz * g.TD;
+        return t;
+    };
+    auto successor = [&](Unit t) {          // the next unit of the walk, without the divisions of decode()
+        if (++t.nt == g.nNt) {
+            t.nt = 0;
+            if (++t.tx == g.tilesW) {
+                t.tx = 0;
+                if (++t.ty == g.tilesH) {
+                    t.ty = 0;
+                    if (++t.tz == g.tilesD) { t.tz = 0; ++t.b; }
+                }
+            }
+        }
+        t.n0 = t.nt * HNT; t.w0 = t.tx * g.TW; t.h0 = t.ty * g.TH; t.d0 = t.tz * g.TD;
         return t;
     };
     auto write_out_table = [&](const Unit& t, int par) {
@@ -391,12 +413,25 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     };
     unsigned srcv[NHR];
     auto unit_sources = [&](const Unit& t) {
+        // source voxel of a piece = tile origin - pad + piece coordinates, per axis in [0, extent): with c = coordinate + PADB >= 0 in a
+        // guarded field, (c | guard) - PADB keeps the guard bit iff c >= PADB and (extent + PADB - 1 | guard) - c keeps it iff c <= that
+        const unsigned org = (unsigned)(t.d0 - g.pd + PADB) + ((unsigned)(t.h0 - g.ph + PADB) << 10) + ((unsigned)(t.w0 - g.pw + PADB) << 20);
+        const unsigned base = (unsigned)((((t.b * g.D + t.d0 - g.pd) * g.H + t.h0 - g.ph) * g.W + t.w0 - g.pw) * g.Cin) * 4u;
+        if (!wide) {
 #pragma unroll
-        for (int u = 0; u < NHR; ++u) {
-            const int hz = pc[u] & 255, hy = (pc[u] >> 8) & 255, hx = (pc[u] >> 16) & 255;
-            const int iz = t.d0 + hz - g.pd, iy = t.h0 + hy - g.ph, ix = t.w0 + hx - g.pw;
-            const bool ok = !(pc[u] >> 24) && iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-            srcv[u] = ok ? (unsigned)((((t.b * g.D + iz) * g.H + iy) * g.W + ix) * g.Cin) * 4u : HBUF_OOB;
+            for (int u = 0; u < NHR; ++u) {
+                const unsigned c = pc[u] + org;                   // fields stay below 512 (extents <= 448, PADB, a halo of a few voxels)
+                const unsigned ok = ((c | GUARD) - ONES) & ((limits | GUARD) - c) & GUARD;
+                srcv[u] = (ok == GUARD && pc[u] != 0x3fffffffu) ? base + prel[u] : HBUF_OOB;
+            }
+        } else {                                                  // an extent beyond the fields (1x1x1 convs arrive as one long row axis)
+#pragma unroll
+            for (int u = 0; u < NHR; ++u) {
+                const int hz = pc[u] & 1023, hy = (pc[u] >> 10) & 1023, hx = (pc[u] >> 20) & 1023;
+                const int iz = t.d0 + hz - g.pd, iy = t.h0 + hy - g.ph, ix = t.w0 + hx - g.pw;
+                const bool ok = pc[u] != 0x3fffffffu && iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                srcv[u] = ok ? base + prel[u] : HBUF_OOB;
+            }
         }
     };
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
@@ -467,7 +502,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
         const bool hasNext = un + 1 < uEnd;
         Unit nxt = cur;
         if (hasNext) {
-            nxt = decode(un + 1);
+            nxt = successor(cur);
             write_out_table(nxt, (un + 1 - uBegin) & 1);       // read in the next unit's epilogue: at least this unit's closing barrier between
         }
         for (int chunk = 0; chunk < g.nChunks; ++chunk) {
@@ -535,28 +570,32 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                     const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
                     const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
                     const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : HBUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : HBUF_OOB_C;
-                    constexpr int RB = OCC == 2 ? 8 : 16;          // residual rows in flight together
+                    auto epilogue = [&](auto ROUND, auto RES) {
+                        float rr0[16], rr1[16];
+                        if constexpr (RES.value) {
 #pragma unroll
-                    for (int r0 = 0; r0 < 16; r0 += RB) {
-                        float rr0[RB], rr1[RB];
-                        if (residual) {            // kernel-uniform
-#pragma unroll
-                            for (int r = 0; r < RB; ++r) {
-                                const unsigned off = (unsigned)oo[((r0 + r) & 3) + 8 * ((r0 + r) >> 2)];
+                            for (int r = 0; r < 16; ++r) {
+                                const unsigned off = (unsigned)oo[(r & 3) + 8 * (r >> 2)];
                                 rr0[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c0, 0, 0));
                                 rr1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off + c1, 0, 0));
                             }
                         }
 #pragma unroll
-                        for (int r = 0; r < RB; ++r) {
-                            const unsigned off = (unsigned)oo[((r0 + r) & 3) + 8 * ((r0 + r) >> 2)];
-                            float v0 = acc0[r0 + r] + bias0, v1 = acc1[r0 + r] + bias1;
-                            if (g.roundOut) { v0 = round_through<BF>(v0); v1 = round_through<BF>(v1); }
-                            if (residual) { v0 += rr0[r]; v1 += rr1[r]; }
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned off = (unsigned)oo[(r & 3) + 8 * (r >> 2)];
+                            float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+                            if constexpr (ROUND.value) { v0 = round_through<BF>(v0); v1 = round_through<BF>(v1); }
+                            if constexpr (RES.value) { v0 += rr0[r]; v1 += rr1[r]; }
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
-                            acc0[r0 + r] = 0.f; acc1[r0 + r] = 0.f;
+                            acc0[r] = 0.f; acc1[r] = 0.f;
                         }
+                    };
+                    // kernel-uniform switches as branches (as selects they cost two v_cndmask per output element)
+                    if (g.roundOut) {
+                        if (residual) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::true_type{}, std::false_type{});
+                    } else {
+                        if (residual) epilogue(std::false_type{}, std::true_type{}); else epilogue(std::false_type{}, std::false_type{});
                     }
                 }
                 if (more) store_wgroup((step + 1) & 1, nn);

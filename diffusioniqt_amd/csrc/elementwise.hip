@@ -771,6 +771,56 @@ __global__ __launch_bounds__(256) void concat_kernel(const float* __restrict__ a
         y[i] = c < Ca ? a[r * Ca + c] : b[r * Cb + (c - Ca)];
     }
 }
+// float4 form with a scalar factor per input (the skip connections of the pseudo-3D U-Net: cat(x, skip * 2^-0.5), imagen_video.py:1743)
+__global__ __launch_bounds__(256) void concat4_kernel(const float4* __restrict__ a, int Ca4, const float4* __restrict__ b, int Cb4,
+                                                      float sa, float sb, float4* __restrict__ y, size_t rows) {
+    const int C4 = Ca4 + Cb4;
+    const size_t total = rows * C4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / C4;
+        const int c = (int)(i - r * C4);
+        const bool first = c < Ca4;
+        float4 v = first ? a[r * Ca4 + c] : b[r * Cb4 + (c - Ca4)];
+        const float f = first ? sa : sb;
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        y[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void split4_kernel(const float4* __restrict__ y, float4* __restrict__ a, int Ca4, float4* __restrict__ b,
+                                                     int Cb4, float sa, float sb, size_t rows) {
+    const int C4 = Ca4 + Cb4;
+    const size_t total = rows * C4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / C4;
+        const int c = (int)(i - r * C4);
+        const bool first = c < Ca4;
+        if ((first && !a) || (!first && !b)) continue;
+        float4 v = y[i];
+        const float f = first ? sa : sb;
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        if (first) a[r * Ca4 + c] = v; else b[r * Cb4 + (c - Ca4)] = v;
+    }
+}
+__global__ __launch_bounds__(256) void concat_scaled_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb,
+                                                            float sa, float sb, float* __restrict__ y, size_t rows) {
+    const int C = Ca + Cb;
+    const size_t total = rows * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / C;
+        const int c = (int)(i % C);
+        y[i] = c < Ca ? sa * a[r * Ca + c] : sb * b[r * Cb + (c - Ca)];
+    }
+}
+__global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restrict__ y, float* __restrict__ a, int Ca, float* __restrict__ b,
+                                                           int Cb, float sa, float sb, size_t rows) {
+    const int C = Ca + Cb;
+    const size_t total = rows * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / C;
+        const int c = (int)(i % C);
+        if (c < Ca) { if (a) a[r * Ca + c] = sa * y[i]; } else { if (b) b[r * Cb + (c - Ca)] = sb * y[i]; }
+    }
+}
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ y, float* __restrict__ a, int Ca,
                                                     float* __restrict__ b, int Cb, size_t rows) {
     const int C = Ca + Cb;
@@ -2067,6 +2117,34 @@ extern "C" int diqt_concat_channels(const float* a, int Ca, const float* b, int 
     if (rows == 0) return DIQT_OK;
     hipLaunchKernelGGL(concat_kernel, dim3(grid_for(rows * (Ca + Cb), 256)), dim3(256), 0, STREAM, a, Ca, b, Cb, y, rows);
     return check_launch("concat_channels");
+}
+extern "C" int diqt_concat_channels_scaled(const float* a, int Ca, const float* b, int Cb, float sa, float sb, float* y, size_t rows,
+                                           void* stream) {
+    DIQT_REQUIRE(a && b && y, DIQT_E_ALIGN, "concat_channels_scaled: null pointer");
+    DIQT_REQUIRE(Ca > 0 && Cb > 0, DIQT_E_SHAPE, "concat_channels_scaled: bad shape");
+    if (rows == 0) return DIQT_OK;
+    if (Ca % 4 == 0 && Cb % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(y)) {
+        hipLaunchKernelGGL(concat4_kernel, dim3(grid_for(rows * ((Ca + Cb) / 4), 256)), dim3(256), 0, STREAM,
+                           reinterpret_cast<const float4*>(a), Ca / 4, reinterpret_cast<const float4*>(b), Cb / 4, sa, sb,
+                           reinterpret_cast<float4*>(y), rows);
+    } else {
+        hipLaunchKernelGGL(concat_scaled_kernel, dim3(grid_for(rows * (Ca + Cb), 256)), dim3(256), 0, STREAM, a, Ca, b, Cb, sa, sb, y, rows);
+    }
+    return check_launch("concat_channels_scaled");
+}
+extern "C" int diqt_split_channels_scaled(const float* y, float* a, int Ca, float* b, int Cb, float sa, float sb, size_t rows,
+                                          void* stream) {
+    DIQT_REQUIRE(y && (a || b), DIQT_E_ALIGN, "split_channels_scaled: null pointer");
+    DIQT_REQUIRE(Ca > 0 && Cb > 0, DIQT_E_SHAPE, "split_channels_scaled: bad shape");
+    if (rows == 0) return DIQT_OK;
+    if (Ca % 4 == 0 && Cb % 4 == 0 && aligned16(y) && (!a || aligned16(a)) && (!b || aligned16(b))) {
+        hipLaunchKernelGGL(split4_kernel, dim3(grid_for(rows * ((Ca + Cb) / 4), 256)), dim3(256), 0, STREAM,
+                           reinterpret_cast<const float4*>(y), reinterpret_cast<float4*>(a), Ca / 4, reinterpret_cast<float4*>(b), Cb / 4,
+                           sa, sb, rows);
+    } else {
+        hipLaunchKernelGGL(split_scaled_kernel, dim3(grid_for(rows * (Ca + Cb), 256)), dim3(256), 0, STREAM, y, a, Ca, b, Cb, sa, sb, rows);
+    }
+    return check_launch("split_channels_scaled");
 }
 extern "C" int diqt_split_channels(const float* y, float* a, int Ca, float* b, int Cb, size_t rows, void* stream) {
     DIQT_REQUIRE(y && (a || b), DIQT_E_ALIGN, "split_channels: null pointer");

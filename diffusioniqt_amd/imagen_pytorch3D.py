@@ -1007,10 +1007,7 @@ class Unet(nn.Module):
         for upsample, init_block, resnet_blocks in self.ups:
             if exists(upsample):
                 x = upsample(x)
-                skip = hiddens.pop()
-                if self.skip_connect_scale != 1.:
-                    skip = skip * self.skip_connect_scale
-                x = ops.concat_channels(x, skip)
+                x = ops.concat_channels(x, hiddens.pop(), 1.0, self.skip_connect_scale)      # cat(x, skip * scale) in one pass
             x = init_block(x, t)
             for resnet_block in resnet_blocks:
                 x = resnet_block(x, t)

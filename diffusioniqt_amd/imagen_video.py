@@ -855,7 +855,7 @@ class Unet3D(nn.Module):
         x = self.mid_block2(x, t, c, ignore_time=ignore_time)
 
         def add_skip_connection(x):
-            return ops.concat_channels(x, ops.scale(hiddens.pop(), self.skip_connect_scale))
+            return ops.concat_channels(x, hiddens.pop(), 1.0, self.skip_connect_scale)           # cat(x, skip * scale) in one pass
 
         up_hiddens = []
         for init_block, resnet_blocks, attn_block, temporal_peg, temporal_attn, temporal_upsample, upsample in self.ups:

@@ -219,6 +219,26 @@ def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0):
     return y
 
 
+def _conv_fwd_smallcout(x5, weight, bias, residual, pad, epad):
+    """Forward of a conv with one or two output channels through diqt_conv3d_fwd_smallcout (exact fp32), or None."""
+    B, D, H, W, Cin = x5.shape
+    Cout, _, kd, kh, kw = weight.shape
+    geo = (B, D, H, W, Cin, Cout, kd, kh, kw, *pad, *epad)
+    if not _lib.query("diqt_conv3d_fwd_smallcout_supported", *geo):
+        return None
+    Do, Ho, Wo = D + 2 * pad[0] + epad[0] - kd + 1, H + 2 * pad[1] + epad[1] - kh + 1, W + 2 * pad[2] + epad[2] - kw + 1
+    y = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=x5.device)
+    if TIMER.enabled:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+    _lib.call("diqt_conv3d_fwd_smallcout", x5, weight.detach().contiguous(), bias, residual, y, *geo, _stream())
+    if TIMER.enabled:
+        e.record()
+        TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_smallcout_kernel",
+                              (B, D, H, W, Cin, Cout, kd, kh, kw)))
+    return y
+
+
 class ColStats:
     """Per-tile column sums (sum, sum of squares) of a conv output, written by the conv epilogue: [B, nblk, 2, C].
     Attached to the output tensor as ``_diqt_stats`` for the consumer's GroupNorm statistics / SE pooling."""
@@ -305,7 +325,13 @@ class _Conv3dFn(Function):
         Cout, Cin, kd, kh, kw = weight.shape
         assert x.dim() == 5 and x.shape[-1] == Cin, f"conv3d: x {tuple(x.shape)} vs weight {tuple(weight.shape)}"
         lp = lp_mode()
-        y = _conv_fwd_half(x, weight, bias, residual, pad, epad, lp) if lp is not None else None
+        y = None
+        if Cout <= 2 and stats_out is None:
+            y = _conv_fwd_smallcout(x, weight, bias, residual, pad, epad)      # dim -> image channel: one pass over x on the vector ALU
+            if y is not None:
+                lp = None
+        if y is None and lp is not None:
+            y = _conv_fwd_half(x, weight, bias, residual, pad, epad, lp)
         if y is None:
             y = _conv_fwd_raw(x, _packed(weight, 0), bias, residual, Cout, (kd, kh, kw), pad, epad, stats_out)
         ctx.save_for_backward(x, weight)
@@ -1018,13 +1044,17 @@ def depth_to_space(x):
 
 class _ConcatFn(Function):
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, fa, fb):
         _chk(a, b)
         Ca, Cb = a.shape[-1], b.shape[-1]
         rows = a.numel() // Ca
         y = torch.empty((*a.shape[:-1], Ca + Cb), dtype=torch.float32, device=a.device)
-        _lib.call("diqt_concat_channels", a, Ca, b, Cb, y, rows, _stream())
+        if fa == 1.0 and fb == 1.0 and (Ca % 4 or Cb % 4):
+            _lib.call("diqt_concat_channels", a, Ca, b, Cb, y, rows, _stream())
+        else:
+            _lib.call("diqt_concat_channels_scaled", a, Ca, b, Cb, fa, fb, y, rows, _stream())
         ctx.shapes = (a.shape, b.shape)
+        ctx.f = (fa, fb)
         return y
 
     @staticmethod
@@ -1034,12 +1064,13 @@ class _ConcatFn(Function):
         da = torch.empty(sa, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
         db = torch.empty(sb, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[1] else None
         if da is not None or db is not None:
-            _lib.call("diqt_split_channels", dy, da, sa[-1], db, sb[-1], dy.numel() // dy.shape[-1], _stream())
-        return da, db
+            _lib.call("diqt_split_channels_scaled", dy, da, sa[-1], db, sb[-1], ctx.f[0], ctx.f[1], dy.numel() // dy.shape[-1], _stream())
+        return da, db, None, None
 
 
-def concat_channels(a, b):
-    return _ConcatFn.apply(a.contiguous(), b.contiguous())
+def concat_channels(a, b, scale_a=1.0, scale_b=1.0):
+    """cat(scale_a * a, scale_b * b) over the last axis in one pass (the scaled skip connections)."""
+    return _ConcatFn.apply(a.contiguous(), b.contiguous(), float(scale_a), float(scale_b))
 
 
 class _SplitFn(Function):

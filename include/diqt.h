@@ -154,6 +154,16 @@ int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw_oidhw, flo
                            int B, int D, int H, int W, int Cin, int Cout,
                            int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, void* stream);
 
+/* Stride-1 convolution with one or two output channels (the U-Nets' final convs dim -> channels, imagen_video.py:1560,
+ * imagen_pytorch3D.py:1485; GlobalContext.to_k, imagen_video.py:585-601) on the vector ALU: per halo voxel the responses of all taps
+ * from ONE pass over x, then a T-point gather.  Exact fp32; OIDHW weights as they are (no packing); any Cin >= 16.
+ * Filters 1x1x1, (1,3,3), (3,1,1), 3x3x3 with Cout = 1 and 1x1x1, (1,3,3) with Cout = 2 (..._supported).                    */
+int diqt_conv3d_fwd_smallcout_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                        int epd, int eph, int epw);
+int diqt_conv3d_fwd_smallcout(const float* x, const float* w_oidhw, const float* bias, const float* residual, float* y, int B, int D,
+                              int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw,
+                              void* stream);
+
 /* Direct (non-MFMA) grouped / strided convolution for the FLOP-trivial shapes: depthwise 3^3 and
  * patchify k=s=p convs of the attention blocks (imagen_pytorch3D.py:858-869, 913-924, 960-976),
  * temporal depthwise (3,1,1) PEG (imagen_video.py:1351-1352).  Weights OIDHW with I = Cin/groups.   */
@@ -369,6 +379,11 @@ int diqt_l2norm_rows_bwd(const float* y, const float* dy, const float* inv, floa
 /* y[rows][Ca+Cb] = cat(a[rows][Ca], b[rows][Cb]) ; and the inverse split */
 int diqt_concat_channels(const float* a, int Ca, const float* b, int Cb, float* y, size_t rows, void* stream);
 int diqt_split_channels(const float* y, float* a, int Ca, float* b, int Cb, size_t rows, void* stream);
+/* y = cat(sa * a, sb * b) over the channel axis and its adjoint (a = sa * y[:, :Ca], b = sb * y[:, Ca:]; either output may be NULL):
+ * the scaled skip connections cat(x, skip * 2^-0.5) of the U-Nets (imagen_video.py:1743, imagen_pytorch3D.py:1631) in one pass.
+ * float4 lanes when both channel counts are multiples of 4.                                                                  */
+int diqt_concat_channels_scaled(const float* a, int Ca, const float* b, int Cb, float sa, float sb, float* y, size_t rows, void* stream);
+int diqt_split_channels_scaled(const float* y, float* a, int Ca, float* b, int Cb, float sa, float sb, size_t rows, void* stream);
 /* trilinear x`scale` up-sampling with align_corners=True (nn.Upsample imagen_pytorch3D.py:954) and its
  * adjoint (dx must be zeroed by the caller; accumulated with float atomics)                          */
 int diqt_trilinear_up_fwd(const float* x, float* y, int B, int D, int H, int W, int C, int scale, void* stream);

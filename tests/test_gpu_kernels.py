@@ -913,3 +913,57 @@ def test_groupnorm_apply_inside_the_conv_staging_matches_the_two_kernel_path(ops
     with torch.no_grad():
         y3 = ops.gn_conv3d(xd, gd, bd, sd, 8, A, 1e-5, wd, cd, pads, rd)
     assert torch.equal(y3, y), "the result must not depend on whether output statistics are requested"
+
+
+@pytest.mark.parametrize("B,sp,Cin,Cout,k,pad,epad,res", [
+    (2, (6, 20, 20), 65, 1, (1, 3, 3), (0, 1, 1), (0, 0, 0), False),      # the pseudo-3D final conv: 65 channels (rows not 16-byte aligned)
+    (1, (5, 9, 33), 64, 1, (1, 1, 1), (0, 0, 0), (0, 0, 0), True),        # GlobalContext.to_k, ragged tiles, residual
+    (2, (9, 10, 12), 64, 1, (3, 3, 3), (1, 1, 1), (0, 0, 0), False),      # the 3-D final conv: 27 taps, channel chunks
+    (1, (12, 6, 6), 40, 1, (3, 1, 1), (2, 0, 0), (-2, 0, 0), True),       # causal temporal: both pads on the low side
+    (1, (4, 18, 17), 128, 2, (1, 3, 3), (0, 1, 1), (0, 0, 0), False),     # two output channels, three channel chunks
+    (1, (3, 40, 40), 200, 2, (1, 1, 1), (0, 0, 0), (0, 0, 0), True),
+    (1, (7, 7, 7), 16, 1, (3, 3, 3), (0, 0, 0), (0, 0, 0), False),        # un-padded
+])
+def test_conv3d_with_one_or_two_output_channels_on_the_vector_alu(ops, B, sp, Cin, Cout, k, pad, epad, res):
+    """diqt_conv3d_fwd_smallcout (forward only; the backward stays on the generic kernels) against a float64 convolution, and that
+    ops.conv3d routes there with gradients intact."""
+    from diffusioniqt_amd import _lib
+    assert _lib.query("diqt_conv3d_fwd_smallcout_supported", B, *sp, Cin, Cout, *k, *pad, *epad) == 1
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, *sp, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    xp = F.pad(xr, (pad[2], pad[2] + epad[2], pad[1], pad[1] + epad[1], pad[0], pad[0] + epad[0]))
+    yr = F.conv3d(xp, wr, br)
+    r = torch.randn(yr.shape, generator=g) if res else None
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    seen = []
+    real = _lib.call
+    _lib.call = lambda name, *a: (seen.append(name), real(name, *a))[1]
+    try:
+        xd, wd, bd = cl(x).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        y = ops.conv3d(xd, wd, bd, pad, residual=cl(r) if res else None, extra_pad=epad)
+    finally:
+        _lib.call = real
+    assert "diqt_conv3d_fwd_smallcout" in seen and "diqt_conv3d_fwd" not in seen
+    close(cf(y), yr + (r.double() if res else 0), tol=2e-6, what="small-Cout conv fwd")
+    y.backward(cl(dy))
+    close(cf(xd.grad), xr.grad, what="small-Cout conv dx")
+    close(wd.grad, wr.grad, tol=5e-5, what="small-Cout conv dw")
+    close(bd.grad, br.grad, tol=5e-5, what="small-Cout conv db")
+
+
+@pytest.mark.parametrize("shape,Ca,Cb,fa,fb", [((2, 3, 5, 7), 64, 32, 1.0, 2 ** -0.5), ((3, 11), 6, 9, 0.5, 1.5), ((1, 4, 4, 4), 4, 4, 1.0, 1.0),
+                                              ((2, 5), 1, 1, 1.0, 1.0)])
+def test_scaled_concat_and_its_adjoint_bit_exact(ops, shape, Ca, Cb, fa, fb):
+    """cat(fa * a, fb * b) in one pass (the scaled skip connections) and its backward: one fp32 multiply per element, so bit-exact."""
+    g = torch.Generator().manual_seed(Ca * 10 + Cb)
+    a, b = torch.randn(*shape, Ca, generator=g), torch.randn(*shape, Cb, generator=g)
+    dy = torch.randn(*shape, Ca + Cb, generator=g)
+    ad, bd = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.concat_channels(ad, bd, fa, fb)
+    assert torch.equal(y.cpu(), torch.cat((a * fa, b * fb), -1))
+    y.backward(dy.to(DEV))
+    assert torch.equal(ad.grad.cpu(), dy[..., :Ca] * fa) and torch.equal(bd.grad.cpu(), dy[..., Ca:] * fb)

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "diqt_reduce_workspace_bytes": (Z, [I, I]),
     "diqt_groupnorm_stats": (I, [P, P, P, P, Z, I, I, I, I, F, P]),
     "diqt_gn_act_fwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
+    "diqt_gn_act_fwd_h": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, P]),
     "diqt_gn_act_bwd": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_gn_coef_from_partials": (I, [P, I, I, P, P, P, P, I, P, P, P, I, I, I, F, P]),
     "diqt_gn_coef": (I, [P, P, P, P, P, P, I, P, I, I, I, P]),
@@ -118,6 +119,8 @@ PROTOTYPES = {
     "diqt_mqa_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "diqt_mqa_attention_fwd_frames": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P]),
     "diqt_set_convh_workgroups": (I, [I]),
+    "diqt_conv3d_fwd_h_io16_supported": (I, [I] * 15),
+    "diqt_conv3d_fwd_h_io": (I, [P, P, P, P, P] + [I] * 15 + [I, I, I, I, P]),
     "diqt_conv3d_fwd_smallcout_supported": (I, [I] * 15),
     "diqt_conv3d_fwd_smallcout": (I, [P, P, P, P, P] + [I] * 15 + [P]),
     "diqt_temporal_attention_h_supported": (I, [I, I, I, I, I, I]),

@@ -288,15 +288,25 @@ __global__ __launch_bounds__(256) void cast_to_h_kernel(const float* __restrict_
     }
 }
 
-template <int ND, bool BF>   // dim_head = 32 * ND
+// HASREL: a relative-position bias table is given.  A template parameter, not a test of the pointer: hipcc hoists the 32 clamped table
+// indices of a tile (min / max / 64-bit multiply-add each) above the `plain tile` branch, where they cost ~190 vector instructions per
+// tile and wave even when there is no table (the joint space-time attention at the middle of the U-Net: 257 tiles per query block)
+template <int ND, bool BF, bool HASREL>   // dim_head = 32 * ND
 __global__ __launch_bounds__(512, 1) void mqa_flash_fwd_h_kernel(const float* __restrict__ q, const unsigned short* __restrict__ kv,
-                                                                 const float* __restrict__ rel, const float* __restrict__ null_bias,
+                                                                 const float* __restrict__ rel_, const float* __restrict__ null_bias,
                                                                  float* __restrict__ out, int n, int h, int E, int ns, int causal,
                                                                  float scale, int round_out) {
     constexpr int D = 32 * ND, KROWB = 2 * D + 16, VROWB = 2 * HKT + 16, NPF = HKT * (2 * D / 8) / 512;   // 16-byte pieces per thread
+    const float* __restrict__ rel = HASREL ? rel_ : nullptr;
     static_assert(NPF >= 1, "tile too small for 512 threads");
     __shared__ __attribute__((aligned(16))) unsigned char Ksm[2][HKT * KROWB];    // [buffer][key][d] 16-bit, padded rows
-    __shared__ __attribute__((aligned(16))) unsigned char Vsm[2][D * VROWB];      // [buffer][d][key position] 16-bit, padded rows
+    // V ROW-MAJOR like K ([buffer][key][d]); the V^T operand of the second product comes out of `ds_read_b64_tr_b16`, which hands lane i
+    // column i of a 4-key x 16-channel block.  (The first version stored V transposed with eight 2-byte LDS writes per piece: rows 8
+    // channels apart are 1152 B apart, i.e. TWO banks for a whole wave -- 1.9e9 bank-conflict cycles per launch of the 16k-token
+    // attention, a third of its run time.)
+    // rows 192 B apart: the 4 rows x 2 channel blocks a 32-lane half reads at once then fall on 8 disjoint 8-bank groups (48 q + 8 blk)
+    constexpr int VRB = 192;
+    __shared__ __attribute__((aligned(16))) unsigned char Vsm[2][HKT * VRB];
     const int g = blockIdx.y;
     const int M = E + ns, R = n * h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -342,23 +352,23 @@ __global__ __launch_bounds__(512, 1) void mqa_flash_fwd_h_kernel(const float* __
         for (int u = 0; u < NPF; ++u) {
             const int e = u * 512 + tid;
             const int key = e / (2 * D / 8), c8 = (e % (2 * D / 8)) * 8;
-            if (c8 < D) {
-                *reinterpret_cast<u32x4a*>(&Ksm[buf][key * KROWB + c8 * 2]) = pre[u];
-            } else {
-                // key = 16 s + 8 a + 4 half + b  ->  position 16 s + 8 half + 4 a + b
-                const int kk = key & 15, pos = (key & ~15) + 8 * ((kk >> 2) & 1) + 4 * (kk >> 3) + (kk & 3);
-                unsigned char* vb = &Vsm[buf][(c8 - D) * VROWB + pos * 2];
-                const unsigned w0 = pre[u].x, w1 = pre[u].y, w2 = pre[u].z, w3 = pre[u].w;      // by value (component bit-casts, see conv_half.hip)
-                *reinterpret_cast<unsigned short*>(vb) = (unsigned short)(w0 & 0xffffu);
-                *reinterpret_cast<unsigned short*>(vb + VROWB) = (unsigned short)(w0 >> 16);
-                *reinterpret_cast<unsigned short*>(vb + 2 * VROWB) = (unsigned short)(w1 & 0xffffu);
-                *reinterpret_cast<unsigned short*>(vb + 3 * VROWB) = (unsigned short)(w1 >> 16);
-                *reinterpret_cast<unsigned short*>(vb + 4 * VROWB) = (unsigned short)(w2 & 0xffffu);
-                *reinterpret_cast<unsigned short*>(vb + 5 * VROWB) = (unsigned short)(w2 >> 16);
-                *reinterpret_cast<unsigned short*>(vb + 6 * VROWB) = (unsigned short)(w3 & 0xffffu);
-                *reinterpret_cast<unsigned short*>(vb + 7 * VROWB) = (unsigned short)(w3 >> 16);
-            }
+            if (c8 < D) *reinterpret_cast<u32x4a*>(&Ksm[buf][key * KROWB + c8 * 2]) = pre[u];
+            else *reinterpret_cast<u32x4a*>(&Vsm[buf][key * VRB + (c8 - D) * 2]) = pre[u];
         }
+    };
+    // V^T fragment of k-step sx (16 keys) for channel tile c: element j of half hf is key 16 sx + (j < 4 ? 4 hf + j : 8 + 4 hf + j - 4),
+    // the order the P^T registers present the keys in; a 16-lane group reads 4 keys x 16 channels per transposing read
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trd = (lane >> 4) & 1;
+    auto v_frag = [&](const unsigned char* Vb, int c, int sx) {
+        const unsigned char* a0 = Vb + (16 * sx + 4 * hf + trq) * VRB + (32 * c + 16 * trd + 4 * trp) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 8 * VRB));
+        u32x4a r;
+        const unsigned long long l = __builtin_bit_cast(unsigned long long, lo), h2 = __builtin_bit_cast(unsigned long long, hi);
+        r.x = (unsigned)l; r.y = (unsigned)(l >> 32); r.z = (unsigned)h2; r.w = (unsigned)(h2 >> 32);
+        return r;
     };
     const int ntiles = (M + HKT - 1) / HKT;
     load_tile(0);
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(512, 1) void mqa_flash_fwd_h_kernel(const float* __
             pk.z = apack2<BF>(pb[i0 + 4], pb[i0 + 5]); pk.w = apack2<BF>(pb[i0 + 6], pb[i0 + 7]);
 #pragma unroll
             for (int c = 0; c < ND; ++c)
-                o[c] = amfma16<BF>(*reinterpret_cast<const u32x4a*>(Vb + (32 * c + l31) * VROWB + sx * 32 + hf * 16), pk, o[c]);
+                o[c] = amfma16<BF>(v_frag(Vb, c, sx), pk, o[c]);
         }
         if (t + 1 < ntiles) store_tile((t + 1) & 1);
         __syncthreads();
@@ -560,8 +570,10 @@ extern "C" int diqt_mqa_attention_fwd_h(const float* q, const void* kv, const fl
     DIQT_REQUIRE(G <= 65535, DIQT_E_SHAPE, "mqa_attention_fwd_h: G > 65535");
     const dim3 grid((unsigned)(((long long)n * h + AQH - 1) / AQH), G);
     void (*k)(const float*, const unsigned short*, const float*, const float*, float*, int, int, int, int, int, float, int) =
-        d == 64 ? (bf16 ? mqa_flash_fwd_h_kernel<2, true> : mqa_flash_fwd_h_kernel<2, false>)
-                : (bf16 ? mqa_flash_fwd_h_kernel<1, true> : mqa_flash_fwd_h_kernel<1, false>);
+        rel ? (d == 64 ? (bf16 ? mqa_flash_fwd_h_kernel<2, true, true> : mqa_flash_fwd_h_kernel<2, false, true>)
+                       : (bf16 ? mqa_flash_fwd_h_kernel<1, true, true> : mqa_flash_fwd_h_kernel<1, false, true>))
+            : (d == 64 ? (bf16 ? mqa_flash_fwd_h_kernel<2, true, false> : mqa_flash_fwd_h_kernel<2, false, false>)
+                       : (bf16 ? mqa_flash_fwd_h_kernel<1, true, false> : mqa_flash_fwd_h_kernel<1, false, false>));
     hipLaunchKernelGGL(k, grid, dim3(512), 0, (hipStream_t)stream, q, static_cast<const unsigned short*>(kv), rel, null_bias, out, n, h,
                        n_extra, n_self, causal, scale, round_out ? 1 : 0);
     return check_launch("mqa_attention_fwd_h");

@@ -339,7 +339,10 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
 // the last tap group of the current unit, the weight pipeline runs on across units, and the output stores of a unit leave before
 // its closing barrier.  Per-thread halo coordinates are fixed for the whole kernel (the tile geometry is), so a unit's source
 // offsets are a few integer operations per piece instead of an LDS table.  Only for halo tiles that fit the register prefetch.
-template <bool BF, int OCC, int NHR, int TGM>       // workgroups per CU, halo pieces per thread, most taps per weight group
+// XH: x holds 16-bit values (the operand type) instead of fp32 -- a halo piece is 8 channels and goes to the LDS image as it is;
+// YH: y is stored as 16-bit values (round_out, no residual).  The pair of convs of a pseudo-3D block passes its intermediate tensor this
+// way: the values are the ones the fp32 tensor would hold (already rounded to the operand type), at half the bytes.
+template <bool BF, int OCC, int NHR, int TGM, bool XH, bool YH>       // workgroups per CU, halo pieces per thread, most taps per weight group
 __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
                                                               const float* __restrict__ bias, const float* __restrict__ residual,
                                                               float* __restrict__ y, HalfGeom g, int nUnits, int perWg) {
@@ -355,8 +358,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int T = g.kd * g.kh * g.kw;
-    const int hq = tid & 7;
-    const int nHalo = HV * 8;
+    constexpr int PPR = XH ? 4 : 8, PSH = XH ? 2 : 3;      // 16-byte pieces per 32-channel halo row
+    constexpr unsigned XE = XH ? 2u : 4u, YE = YH ? 2u : 4u;   // bytes per element
+    const int hq = tid & (PPR - 1);
+    const int nHalo = HV * PPR;
 
     const int uBegin = blockIdx.x * perWg, uEnd = min(uBegin + perWg, nUnits);
     if (uBegin >= uEnd) return;
@@ -367,10 +372,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     unsigned pc[NHR], prel[NHR];
 #pragma unroll
     for (int u = 0; u < NHR; ++u) {
-        const int idx = u * 512 + tid, hv = min(idx >> 3, HV - 1);
+        const int idx = u * 512 + tid, hv = min(idx >> PSH, HV - 1);
         const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
         pc[u] = idx < nHalo ? ((unsigned)hz | ((unsigned)hy << 10) | ((unsigned)hx << 20)) : 0x3fffffffu;     // past the tile: never in range
-        prel[u] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin) * 4u;
+        prel[u] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin) * XE;
     }
     constexpr int PADB = 16;
     const unsigned limits = (unsigned)(g.D + PADB - 1) | ((unsigned)(g.H + PADB - 1) << 10) | ((unsigned)(g.W + PADB - 1) << 20);
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
         if (tid < HMT) {
             const int od = t.d0 + otd, oh = t.h0 + oth, ow = t.w0 + otw;
             int off = (int)HBUF_OOB;
-            if (od < g.Do && oh < g.Ho && ow < g.Wo) off = (((t.b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout * 4;
+            if (od < g.Do && oh < g.Ho && ow < g.Wo) off = (((t.b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * g.Cout * (int)YE;
             out_off[par * HMT + tid] = off;
         }
     };
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
         // source voxel of a piece = tile origin - pad + piece coordinates, per axis in [0, extent): with c = coordinate + PADB >= 0 in a
         // guarded field, (c | guard) - PADB keeps the guard bit iff c >= PADB and (extent + PADB - 1 | guard) - c keeps it iff c <= that
         const unsigned org = (unsigned)(t.d0 - g.pd + PADB) + ((unsigned)(t.h0 - g.ph + PADB) << 10) + ((unsigned)(t.w0 - g.pw + PADB) << 20);
-        const unsigned base = (unsigned)((((t.b * g.D + t.d0 - g.pd) * g.H + t.h0 - g.ph) * g.W + t.w0 - g.pw) * g.Cin) * 4u;
+        const unsigned base = (unsigned)((((t.b * g.D + t.d0 - g.pd) * g.H + t.h0 - g.ph) * g.W + t.w0 - g.pw) * g.Cin) * XE;
         if (!wide) {
 #pragma unroll
             for (int u = 0; u < NHR; ++u) {
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
 
     u32x4 hr[NHR];
     auto halo_load = [&](int ci0) {
-        const unsigned coff = (ci0 + hq * 4 < g.Cin) ? (unsigned)(ci0 + hq * 4) * 4u : HBUF_OOB_C;
+        const unsigned coff = (ci0 + hq * (32 / PPR) < g.Cin) ? (unsigned)(ci0 + hq * (32 / PPR)) * XE : HBUF_OOB_C;
 #pragma unroll
         for (int u = 0; u < NHR; ++u) hr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, srcv[u] + coff, 0, 0);
     };
@@ -449,10 +454,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
         for (int u = 0; u < NHR; ++u) {
             const int idx = u * 512 + tid;
             if (idx < nHalo) {
-                u32x2 p;
-                p.x = pack2<BF>(asf(hr[u].x), asf(hr[u].y));
-                p.y = pack2<BF>(asf(hr[u].z), asf(hr[u].w));
-                *reinterpret_cast<u32x2*>(halo + (idx >> 3) * HROWB + hq * 8) = p;
+                if constexpr (XH) {
+                    *reinterpret_cast<u32x4*>(halo + (idx >> PSH) * HROWB + hq * 16) = hr[u];
+                } else {
+                    u32x2 p;
+                    p.x = pack2<BF>(asf(hr[u].x), asf(hr[u].y));
+                    p.y = pack2<BF>(asf(hr[u].z), asf(hr[u].w));
+                    *reinterpret_cast<u32x2*>(halo + (idx >> PSH) * HROWB + hq * 8) = p;
+                }
             }
         }
     };
@@ -569,7 +578,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                     const int co0 = cur.n0 + l31, co1 = cur.n0 + 32 + l31;
                     const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
                     const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
-                    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * 4u : HBUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * 4u : HBUF_OOB_C;
+                    const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * YE : HBUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * YE : HBUF_OOB_C;
                     auto epilogue = [&](auto ROUND, auto RES) {
                         float rr0[16], rr1[16];
                         if constexpr (RES.value) {
@@ -586,8 +595,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                             float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
                             if constexpr (ROUND.value) { v0 = round_through<BF>(v0); v1 = round_through<BF>(v1); }
                             if constexpr (RES.value) { v0 += rr0[r]; v1 += rr1[r]; }
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+                            if constexpr (YH) {
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2<BF>(v0, 0.f) & 0xffffu), rs_y, off + c0, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2<BF>(v1, 0.f) & 0xffffu), rs_y, off + c1, 0, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_y, off + c0, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs_y, off + c1, 0, 0);
+                            }
                             acc0[r] = 0.f; acc1[r] = 0.f;
                         }
                     };
@@ -723,9 +737,25 @@ extern "C" int diqt_set_convh_workgroups(int n) {
     return cur;
 }
 
-extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const float* bias, const float* residual, float* y, int B, int D,
-                                 int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph,
-                                 int epw, int bf16, int round_out, void* stream) {
+static bool convh_persistent_takes(const HalfGeom& g, unsigned nwg) {
+    static const bool persist = [] { const char* e = getenv("DIQT_CONVH_PERSIST"); return !(e && e[0] == '0'); }();
+    static const bool nopref = [] { const char* e = getenv("DIQT_CONVH_NOPREF"); return e && e[0] == '1'; }();
+    const int HV = g.HD * g.HH * g.HWd;
+    return persist && !nopref && HV * 8 <= 512 * HHREG && nwg >= 2u * (unsigned)diqt_set_convh_workgroups(0);
+}
+
+// 1 when diqt_conv3d_fwd_h_io takes 16-bit x and / or y for this shape: the persistent kernel's conditions and Cin, Cout % 8 == 0
+extern "C" int diqt_conv3d_fwd_h_io16_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
+                                                int pw, int epd, int eph, int epw) {
+    HalfGeom g;
+    if (Cin % 8 != 0 || Cout % 8 != 0 || !half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return 0;
+    const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
+    return convh_persistent_takes(g, nwg) ? 1 : 0;
+}
+
+static int convh_launch(const void* x, const void* packed_h, const float* bias, const float* residual, void* y, int B, int D, int H, int W,
+                        int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, int bf16,
+                        int round_out, bool xh, bool yh, void* stream) {
     DIQT_REQUIRE(x && packed_h && y, DIQT_E_ALIGN, "conv3d_fwd_h: null pointer");
     DIQT_REQUIRE(aligned16(x) && aligned16(packed_h), DIQT_E_ALIGN, "conv3d_fwd_h: x and the packed weights must be 16-byte aligned");
     HalfGeom g;
@@ -734,7 +764,7 @@ extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const flo
     g.roundOut = round_out ? 1 : 0;
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
     static const bool dbg_on = [] { const char* e = getenv("DIQT_CONVH_DBG"); return e && e[0] == '1'; }();
-    if (dbg_on && nwg <= 65536) {
+    if (dbg_on && nwg <= 65536 && !xh && !yh) {
         if (!g_hdbg) DIQT_REQUIRE(hipMalloc(&g_hdbg, (size_t)65536 * 8 * sizeof(unsigned long long)) == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: debug buffer");
         g.dbg = g_hdbg; g_hdbg_n = nwg;
     }
@@ -742,6 +772,34 @@ extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const flo
     const int HV = g.HD * g.HH * g.HWd;
     static const bool nopref = [] { const char* e = getenv("DIQT_CONVH_NOPREF"); return e && e[0] == '1'; }();
     const bool pref = !nopref && HV * 8 <= 512 * HHREG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!g.dbg && convh_persistent_takes(g, nwg)) {
+        // (two workgroups per CU -- 6 halo pieces per thread, weight groups of <= 5 taps, 128 registers per wave -- measured 1.4x SLOWER
+        // on the 64^3 level-0 shapes: the kernel moves 3.5 TB/s of fp32 activations, 0.75 of what a plain copy reaches)
+        if (xh || yh) {
+            DIQT_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && (!yh || (round_out && !residual)), DIQT_E_UNSUPPORTED,
+                         "conv3d_fwd_h_io: 16-bit tensors need Cin, Cout %% 8 == 0; a 16-bit output needs round_out and no residual");
+            if (xh) g.xBytes /= 2;
+            if (yh) g.yBytes /= 2;
+        }
+        typedef void (*KP)(const float*, const unsigned short*, const float*, const float*, float*, HalfGeom, int, int);
+        const int sel = (bf16 ? 4 : 0) + (xh ? 2 : 0) + (yh ? 1 : 0);
+        static const KP tab[8] = {conv_fwd_hp_kernel<false, 1, HHREG, HTG, false, false>, conv_fwd_hp_kernel<false, 1, HHREG, HTG, false, true>,
+                                  conv_fwd_hp_kernel<false, 1, HHREG, HTG, true, false>,  conv_fwd_hp_kernel<false, 1, HHREG, HTG, true, true>,
+                                  conv_fwd_hp_kernel<true, 1, HHREG, HTG, false, false>,  conv_fwd_hp_kernel<true, 1, HHREG, HTG, false, true>,
+                                  conv_fwd_hp_kernel<true, 1, HHREG, HTG, true, false>,   conv_fwd_hp_kernel<true, 1, HHREG, HTG, true, true>};
+        const KP kp = tab[sel];
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        const int wgs = diqt_set_convh_workgroups(0);
+        const int perWg = (int)((nwg + wgs - 1) / wgs), grid = (int)((nwg + perWg - 1) / perWg);
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(512), lds, s, static_cast<const float*>(x), static_cast<const unsigned short*>(packed_h), bias,
+                           residual, static_cast<float*>(y), g, (int)nwg, perWg);
+        return check_launch("conv3d_fwd_h(persistent)");
+    }
+    DIQT_REQUIRE(!xh && !yh, DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: 16-bit tensors only on the persistent kernel (diqt_conv3d_fwd_h_io16_supported)");
     void (*kern)(const float*, const unsigned short*, const float*, const float*, float*, HalfGeom) =
         bf16 ? (pref ? conv_fwd_h_kernel<true, true> : conv_fwd_h_kernel<true, false>)
              : (pref ? conv_fwd_h_kernel<false, true> : conv_fwd_h_kernel<false, false>);
@@ -749,27 +807,21 @@ extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const flo
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    static const bool persist = [] { const char* e = getenv("DIQT_CONVH_PERSIST"); return !(e && e[0] == '0'); }();
-    const int pwgs = diqt_set_convh_workgroups(0);
-    if (persist && pref && !g.dbg && nwg >= 2u * (unsigned)pwgs) {
-        // (two workgroups per CU -- 6 halo pieces per thread, weight groups of <= 5 taps, 128 registers per wave -- measured 1.4x SLOWER
-        // on the 64^3 level-0 shapes: the kernel is bound by vector-ALU issue of the staging / epilogue code, not by exposed latency)
-        const bool two = false;
-        void (*kp)(const float*, const unsigned short*, const float*, const float*, float*, HalfGeom, int, int) =
-            bf16 ? conv_fwd_hp_kernel<true, 1, HHREG, HTG> : conv_fwd_hp_kernel<false, 1, HHREG, HTG>;
-        const HalfGeom& g2 = g;
-        const size_t ldsp = lds;
-        if (ldsp > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-            DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
-        const int wgs = two ? 2 * pwgs : pwgs;
-        const int perWg = (int)((nwg + wgs - 1) / wgs), grid = (int)((nwg + perWg - 1) / perWg);
-        hipLaunchKernelGGL(kp, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, x, static_cast<const unsigned short*>(packed_h), bias,
-                           residual, y, two ? g2 : g, (int)nwg, perWg);
-        return check_launch("conv3d_fwd_h(persistent)");
-    }
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, (hipStream_t)stream, x, static_cast<const unsigned short*>(packed_h), bias,
-                       residual, y, g);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, s, static_cast<const float*>(x), static_cast<const unsigned short*>(packed_h), bias,
+                       residual, static_cast<float*>(y), g);
     return check_launch("conv3d_fwd_h");
+}
+
+extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const float* bias, const float* residual, float* y, int B, int D,
+                                 int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph,
+                                 int epw, int bf16, int round_out, void* stream) {
+    return convh_launch(x, packed_h, bias, residual, y, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, bf16, round_out, false,
+                        false, stream);
+}
+
+extern "C" int diqt_conv3d_fwd_h_io(const void* x, const void* packed_h, const float* bias, const float* residual, void* y, int B, int D,
+                                    int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph,
+                                    int epw, int bf16, int round_out, int x_half, int y_half, void* stream) {
+    return convh_launch(x, packed_h, bias, residual, y, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, bf16, round_out,
+                        x_half != 0, y_half != 0, stream);
 }

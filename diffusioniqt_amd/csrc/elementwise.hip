@@ -183,13 +183,34 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(GnCoef k, float* __restric
     coef[(size_t)B * k.C + i] = Bc;
 }
 
-template <bool VEC>
+// OUTH: 0: fp32 output; 1 / 2: the output in fp16 / bf16 (VEC only) -- under autocast the consumer is a 16-bit-operand conv that would
+// round these values to that type while staging them: the same numbers at half the bytes written here and read there
+template <int OUTH>
+__device__ __forceinline__ void gn_store4(float* yb, size_t i, float4 v) {
+    if constexpr (OUTH == 0) {
+        *reinterpret_cast<float4*>(yb + i * 4) = v;
+    } else {
+        uint2 p;
+        if constexpr (OUTH == 1) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 a = {(_Float16)v.x, (_Float16)v.y}, c = {(_Float16)v.z, (_Float16)v.w};
+            p.x = __builtin_bit_cast(unsigned, a); p.y = __builtin_bit_cast(unsigned, c);
+        } else {
+            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+            const b2 a = {(__bf16)v.x, (__bf16)v.y}, c = {(__bf16)v.z, (__bf16)v.w};
+            p.x = __builtin_bit_cast(unsigned, a); p.y = __builtin_bit_cast(unsigned, c);
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(yb) + i * 4) = p;
+    }
+}
+
+template <bool VEC, int OUTH = 0>
 __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          GnCoef k, int rows, int act) {
     const int b = blockIdx.y, C = k.C;
     const size_t per = (size_t)rows * C;
     const float* xb = x + (size_t)b * per;
-    float* yb = y + (size_t)b * per;
+    float* yb = OUTH ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(y) + (size_t)b * per) : y + (size_t)b * per;
     if (VEC) {
         // the host sizes the grid so that (gridDim.x * 1024) % C == 0: a thread keeps its 4 channels for the whole
         // loop and the per-(b,c) coefficients live in registers
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
                 v[u].y = act_fwd(A[1] * v[u].y + Bc[1], act);
                 v[u].z = act_fwd(A[2] * v[u].z + Bc[2], act);
                 v[u].w = act_fwd(A[3] * v[u].w + Bc[3], act);
-                *reinterpret_cast<float4*>(yb + (i + u * st) * 4) = v[u];
+                gn_store4<OUTH>(yb, i + u * st, v[u]);
             }
         }
         for (; i < n4; i += st) {
@@ -219,7 +240,7 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
             v.y = act_fwd(A[1] * v.y + Bc[1], act);
             v.z = act_fwd(A[2] * v.z + Bc[2], act);
             v.w = act_fwd(A[3] * v.w + Bc[3], act);
-            *reinterpret_cast<float4*>(yb + i * 4) = v;
+            gn_store4<OUTH>(yb, i, v);
         }
     } else {
         for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
@@ -1696,6 +1717,23 @@ extern "C" int diqt_gn_act_fwd(const float* x, const float* mean, const float* r
     else
         hipLaunchKernelGGL(gn_act_fwd_kernel<false>, grid, dim3(256), 0, STREAM, x, y, k, rows, act);
     return check_launch("gn_act_fwd");
+}
+
+extern "C" int diqt_gn_act_fwd_h(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 const float* scale, const float* shift, int cond_stride, void* y_h, int B, int rows, int C, int G,
+                                 int act, int bf16, void* stream) {
+    DIQT_REQUIRE(x && mean && rstd && y_h, DIQT_E_ALIGN, "gn_act_fwd_h: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_act_fwd_h: bad shape");
+    DIQT_REQUIRE((scale == nullptr) == (shift == nullptr), DIQT_E_SHAPE, "gn_act_fwd_h: scale and shift go together");
+    DIQT_REQUIRE(!scale || cond_stride >= C, DIQT_E_SHAPE, "gn_act_fwd_h: cond_stride < C");
+    const size_t per = (size_t)rows * C;
+    DIQT_REQUIRE(vec_ok(x, static_cast<const float*>(y_h), nullptr, per, C), DIQT_E_UNSUPPORTED,
+                 "gn_act_fwd_h: needs C %% 4 == 0 and 16-byte aligned tensors");
+    GnCoef k{mean, rstd, gamma, beta, scale, shift, C, G, cond_stride};
+    const dim3 grid(gn_grid(per, C, B), B);
+    if (bf16) hipLaunchKernelGGL((gn_act_fwd_kernel<true, 2>), grid, dim3(256), 0, STREAM, x, static_cast<float*>(y_h), k, rows, act);
+    else hipLaunchKernelGGL((gn_act_fwd_kernel<true, 1>), grid, dim3(256), 0, STREAM, x, static_cast<float*>(y_h), k, rows, act);
+    return check_launch("gn_act_fwd_h");
 }
 
 // ext_partials: the reduction pass already done elsewhere (the epilogue of the conv that produced dy, diqt_conv3d_fwd_gnbwd):

@@ -150,11 +150,25 @@ class Conv3d(nn.Module):
         last = ignore_time or not exists(self.temporal_conv)
         if gn is not None:
             norm, ss = gn
+            if not last and ops.lp_mode() is not None:
+                # sampling under autocast: GroupNorm-apply writes the operand type, and so does the per-frame conv (None: shape not taken)
+                tc = self.temporal_conv
+                kt = tc.weight.shape[-1]
+                return ops.conv_pair_nograd_h(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), tc.weight.unsqueeze(-1).unsqueeze(-1),
+                                              tc.bias, (kt - 1, 0, 0), (-(kt - 1), 0, 0), residual,
+                                              gn=(norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps))
             x = ops.gn_conv3d(x, norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps, sc.weight.unsqueeze(2), sc.bias,
                               (0, k // 2, k // 2), residual if last else None, want_stats=want_stats and last)
             if x is None:
                 return None
         else:
+            if not last:        # sampling under autocast: the tensor between the two convs stays in the operand type (half the bytes)
+                tc = self.temporal_conv
+                kt = tc.weight.shape[-1]
+                y = ops.conv_pair_nograd_h(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), tc.weight.unsqueeze(-1).unsqueeze(-1),
+                                           tc.bias, (kt - 1, 0, 0), (-(kt - 1), 0, 0), residual)
+                if y is not None:
+                    return y
             x = ops.conv3d(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), residual=residual if last else None,
                            want_stats=want_stats and last)
         if last:

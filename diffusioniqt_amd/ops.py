@@ -191,32 +191,95 @@ def _packed_h(weight5, bf16, mode=0):
     return packed
 
 
-def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0):
+def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0, x_half=False, y_half=False):
     """fp16 / bf16-operand forward (mode 0) or backward-data (mode 1: x5 is dY, pad / epad already transformed) through
-    diqt_conv3d_fwd_h, or None when the low-precision kernel does not take this shape."""
+    diqt_conv3d_fwd_h, or None when the low-precision kernel does not take this shape.  x_half / y_half: the tensor at that end holds
+    16-bit values of the operand type (diqt_conv3d_fwd_h_io; the caller has asked conv_half_io16_ok)."""
     B, D, H, W, Cin = x5.shape
     kd, kh, kw = weight.shape[2:]
     Cout = weight.shape[0] if mode == 0 else weight.shape[1]
     geo = (B, D, H, W, Cin, Cout, kd, kh, kw, *pad, *epad)
-    Bc = B                      # batch entries per launch: the kernel addresses a tensor through one buffer descriptor (< 1 GiB)
+    hdt = torch.bfloat16 if bf16 else torch.float16
+    ex, ey = (2 if x_half else 4), (2 if y_half else 4)
+    Bc = B                      # batch entries per launch: the kernel addresses a tensor through one buffer descriptor (< 1 GiB of fp32)
     while not _lib.query("diqt_conv3d_fwd_h_supported", Bc, *geo[1:]):
         if Bc % 2 or max(x5[:Bc].numel(), Bc * D * H * W * Cout) * 4 < (1 << 30):
             return None
         Bc //= 2
+    io16 = x_half or y_half
+    assert not io16 or (Bc == B and x5.dtype == (hdt if x_half else torch.float32))
     Do, Ho, Wo = D + 2 * pad[0] + epad[0] - kd + 1, H + 2 * pad[1] + epad[1] - kh + 1, W + 2 * pad[2] + epad[2] - kw + 1
-    y = torch.empty((B, Do, Ho, Wo, Cout), dtype=torch.float32, device=x5.device)
+    y = torch.empty((B, Do, Ho, Wo, Cout), dtype=hdt if y_half else torch.float32, device=x5.device)
     if TIMER.enabled:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
     packed = _packed_h(weight, bf16, mode)
-    for b0 in range(0, B, Bc):
-        _lib.call("diqt_conv3d_fwd_h", x5[b0:b0 + Bc], packed, bias, residual[b0:b0 + Bc] if residual is not None else None,
-                  y[b0:b0 + Bc], Bc, *geo[1:], bf16, 1, _stream())
+    if io16:
+        _lib.call("diqt_conv3d_fwd_h_io", x5, packed, bias, residual, y, *geo, bf16, 1, int(x_half), int(y_half), _stream())
+    else:
+        for b0 in range(0, B, Bc):
+            _lib.call("diqt_conv3d_fwd_h", x5[b0:b0 + Bc], packed, bias, residual[b0:b0 + Bc] if residual is not None else None,
+                      y[b0:b0 + Bc], Bc, *geo[1:], bf16, 1, _stream())
     if TIMER.enabled:
         e.record()
         TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_h_kernel",
                               (B, D, H, W, Cin, Cout, kd, kh, kw)))
     return y
+
+
+def _groupnorm_act_h(x, gamma, beta, ss, groups, act, eps, lp):
+    """act(GN(x) * (scale + 1) + shift) stored in the operand type of the 16-bit conv that consumes it (sampling path under autocast)."""
+    B, C = x.shape[0], x.shape[-1]
+    rows = x.numel() // (B * C)
+    mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    s = _stream()
+    pre = getattr(x, "_diqt_stats", None)
+    if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
+        _lib.call("diqt_groupnorm_stats_from_partials", pre.partials, mean, rstd, B, pre.nblk, rows, C, groups, float(eps), s)
+    else:
+        ws, n = _reduce_ws(B, C, x.device)
+        _lib.call("diqt_groupnorm_stats", x, mean, rstd, ws, n, B, rows, C, groups, float(eps), s)
+    scale = shift = None
+    cs = 0
+    if isinstance(ss, SSView):
+        assert ss.width == 2 * C and ss.base.shape[0] == B
+        scale, cs = ss.base.data_ptr() + 4 * ss.off, ss.base.shape[1]
+        shift = scale + 4 * C
+    elif ss is not None:
+        assert ss.shape == (B, 2 * C) and ss.stride(1) == 1 and ss.is_cuda and ss.dtype == torch.float32
+        scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, ss.stride(0)
+    y = torch.empty(x.shape, dtype=torch.bfloat16 if lp == 1 else torch.float16, device=x.device)
+    _lib.call("diqt_gn_act_fwd_h", x, mean, rstd, gamma, beta, scale, shift, cs, y, B, rows, C, groups, act, lp, s)
+    return y
+
+
+def conv_pair_nograd_h(x, w1, b1, pad1, w2, b2, pad2, epad2, residual=None, gn=None):
+    """Two convs in a row on the sampling path under autocast -- the per-frame and the temporal conv of a pseudo-3D block -- with
+    the tensor between them in the operand type (it holds exactly the values the fp32 tensor would: the first conv's result is rounded
+    to that type either way).  ``gn`` = (gamma, beta, scale_shift, groups, act, eps): x is the raw input of the block's GroupNorm, whose
+    apply pass then writes the first conv's input in the operand type as well.  None when not under autocast or a shape is not taken
+    by the persistent 16-bit kernel."""
+    lp = lp_mode()
+    if lp is None or torch.is_grad_enabled():
+        return None
+    _chk(x, w1, b1, w2, b2, residual)
+    B, D, H, W, Cin = x.shape
+    Cm, C2 = w1.shape[0], w2.shape[0]
+    k1, k2 = tuple(w1.shape[2:]), tuple(w2.shape[2:])
+    D1, H1, W1 = D + 2 * pad1[0] - k1[0] + 1, H + 2 * pad1[1] - k1[1] + 1, W + 2 * pad1[2] - k1[2] + 1
+    if not (_lib.query("diqt_conv3d_fwd_h_io16_supported", B, D, H, W, Cin, Cm, *k1, *pad1, 0, 0, 0)
+            and _lib.query("diqt_conv3d_fwd_h_io16_supported", B, D1, H1, W1, Cm, C2, *k2, *pad2, *epad2)):
+        return None
+    xin, xh = x, False
+    if gn is not None:
+        gamma, beta, ss, groups, act, eps = gn
+        if Cin % 4 != 0 or Cin % groups != 0:
+            return None
+        _chk(gamma, beta, ss.base if isinstance(ss, SSView) else None)
+        xin, xh = _groupnorm_act_h(x, gamma, beta, ss, groups, act, eps, lp), True
+    mid = _conv_fwd_half(xin, w1, b1, None, pad1, (0, 0, 0), lp, x_half=xh, y_half=True)
+    return _conv_fwd_half(mid, w2, b2, residual, pad2, epad2, lp, x_half=True)
 
 
 def _conv_fwd_smallcout(x5, weight, bias, residual, pad, epad):
@@ -1601,6 +1664,20 @@ class _GateResidualFn(Function):
 
 
 def gate_residual(h, gate, res=None):
+    if not torch.is_grad_enabled() and res is not None:
+        # sampling: a ResnetBlock's output usually feeds the next block's first GroupNorm -- its per-workgroup column sums ride along
+        # (groupnorm_act / gn_conv3d read them from ``_diqt_stats``: no statistics pass over the tensor)
+        h, gate = h.contiguous(), gate.contiguous()
+        _chk(h, gate, res)
+        B, C = h.shape[0], h.shape[-1]
+        rows = h.numel() // (B * C)
+        nblk = _lib.query("diqt_gate_residual_stats_blocks", rows, C)
+        if nblk > 0:
+            y = torch.empty_like(h)
+            stats = torch.empty((B, nblk, 2, C), dtype=torch.float32, device=h.device)
+            _lib.call("diqt_gate_residual_fwd_stats", h, gate, res, y, stats, B, rows, C, _stream())
+            y._diqt_stats = ColStats(stats, nblk, rows)
+            return y
     return _GateResidualFn.apply(h.contiguous(), gate.contiguous(), res)
 
 

@@ -86,6 +86,16 @@ int diqt_conv_pack_weight_h(const float* w_oidhw, void* packed_h, int Cout, int 
                             void* stream);   /* mode as in diqt_conv_pack_weight: 1 = flipped / swapped packing for backward-data */
 int diqt_conv3d_fwd_h_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                                 int epd, int eph, int epw);
+/* diqt_conv3d_fwd_h with 16-bit tensors at either end: x_half: x holds values of the operand type (fp16, or bf16 when `bf16`) instead of
+ * fp32; y_half: y is stored in that type (needs round_out and no residual).  The two convs of a pseudo-3D block (per-frame k x k, then
+ * temporal; imagen_video.py:352-406) pass their intermediate tensor this way: the same values the fp32 tensor would hold -- autocast
+ * rounds a conv's result to the operand type -- at half the bytes.  Only where ..._io16_supported says 1 (the persistent kernel's
+ * shapes, Cin and Cout multiples of 8).                                                                                        */
+int diqt_conv3d_fwd_h_io16_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                     int epd, int eph, int epw);
+int diqt_conv3d_fwd_h_io(const void* x, const void* packed_h, const float* bias, const float* residual, void* y, int B, int D, int H,
+                         int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, int bf16,
+                         int round_out, int x_half, int y_half, void* stream);
 /* diqt_conv3d_fwd_h walks (tile, channel-block) units with a persistent kernel of this many workgroups (default 256, one per CU;
  * env DIQT_CONVH_WGS; DIQT_CONVH_PERSIST=0 disables it) when a launch has at least twice as many units and the halo tile fits the
  * register prefetch; n > 0 sets the count, n <= 0 only queries; returns the previous value.  Results do not depend on it.      */
@@ -202,6 +212,10 @@ int diqt_groupnorm_stats(const float* x, float* mean, float* rstd, void* workspa
 int diqt_gn_act_fwd(const float* x, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, const float* scale, const float* shift,
                     int cond_stride, float* y, int B, int rows_per_batch, int C, int G, int act, void* stream);
+/* The same with y stored in fp16 (bf16 when `bf16`): under autocast the consumer is a 16-bit-operand conv (diqt_conv3d_fwd_h_io,
+ * x_half) that would round these values to that type while staging them.  Needs C % 4 == 0 and 16-byte aligned tensors.          */
+int diqt_gn_act_fwd_h(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale,
+                      const float* shift, int cond_stride, void* y_h, int B, int rows, int C, int G, int act, int bf16, void* stream);
 
 /* dx, dgamma[C], dbeta[C], dscale[B][C], dshift[B][C] (last two NULL when scale/shift are).
  * `workspace` holds per-(b,c) partial sums: diqt_reduce_workspace_bytes(B,C).                         */

@@ -404,3 +404,21 @@ def test_edm_self_conditioning_sample_and_loss_match_reference_golden(monkeypatc
         for k in g:
             if k.startswith(f'grad_{tag}:'):
                 close(named[k.split(':', 1)[1]].grad, T(g[k]), 3e-3, k)
+
+
+def test_gate_residual_hands_groupnorm_statistics_to_the_next_block():
+    """Sampling path: h * gate + res also emits per-workgroup column sums of its output (diqt_gate_residual_fwd_stats), which the next
+    block's GroupNorm uses instead of a pass over the tensor."""
+    from diffusioniqt_amd import ops
+    g = torch.Generator().manual_seed(0)
+    B, Fr, S, C = 2, 6, 12, 64
+    h, res = torch.randn(B, Fr, S, S, C, generator=g).to(DEV), torch.randn(B, Fr, S, S, C, generator=g).to(DEV)
+    gate = torch.rand(B, C, generator=g).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    with torch.no_grad():
+        y = ops.gate_residual(h, gate, res)
+        assert getattr(y, "_diqt_stats", None) is not None
+        assert torch.equal(y, h * gate.view(B, 1, 1, 1, C) + res)
+        a = ops.groupnorm_act(y, gamma, beta, None, 8, ops.ACT_SILU, 1e-5)
+        b = ops.groupnorm_act(y.clone(), gamma, beta, None, 8, ops.ACT_SILU, 1e-5)         # the clone carries no statistics
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()

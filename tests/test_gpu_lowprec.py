@@ -363,3 +363,54 @@ def test_temporal_attention_block_one_kernel(B, Fr, P, C, h, causal, mode):
     assert rel(got.double() - x.double(), ref - x.double()) <= 1.5 * ulp
     assert not torch.equal(got, y32) and not torch.equal(got, chain)
     assert rel(got - x, y32 - x) <= 6 * ulp and rel(got - x, chain - x) <= 6 * ulp
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,Fr,S,C1,C2,res", [(2, 10, 20, 32, 64, True), (1, 7, 33, 72, 40, False), (2, 12, 16, 64, 64, True)])
+def test_conv_pair_with_a_16_bit_intermediate_is_bit_identical(B, Fr, S, C1, C2, res, mode):
+    """The per-frame + temporal conv pair of a pseudo-3D block on the sampling path under autocast: the tensor between the two
+    convs is stored in the operand type (diqt_conv3d_fwd_h_io) -- the same values the fp32 tensor holds, so the pair's output must
+    be BIT-IDENTICAL to two separate launches with an fp32 tensor in between."""
+    from diffusioniqt_amd import ops, _lib
+    g = torch.Generator().manual_seed(B * 100 + C1)
+    x = torch.randn(B, Fr, S, S, C1, generator=g).to(DEV)
+    w1 = (torch.randn(C2, C1, 1, 3, 3, generator=g) * 0.05).to(DEV); b1 = torch.randn(C2, generator=g).to(DEV)
+    w2 = (torch.randn(C2, C2, 3, 1, 1, generator=g) * 0.1).to(DEV); b2 = torch.randn(C2, generator=g).to(DEV)
+    r = torch.randn(B, Fr, S, S, C2, generator=g).to(DEV) if res else None
+    prev = _lib.query("diqt_set_convh_workgroups", 3)          # the persistent walk (production: >= 512 units) on a small shape
+    try:
+        with ops.low_precision(mode), torch.no_grad():
+            y = ops.conv_pair_nograd_h(x, w1, b1, (0, 1, 1), w2, b2, (2, 0, 0), (-2, 0, 0), r)
+            assert y is not None and y.dtype == torch.float32
+            mid = ops.conv3d(x, w1, b1, (0, 1, 1))
+            ref = ops.conv3d(mid, w2, b2, (2, 0, 0), residual=r, extra_pad=(-2, 0, 0))
+    finally:
+        _lib.query("diqt_set_convh_workgroups", prev)
+    assert torch.equal(y, ref), (y - ref).abs().max()
+    with torch.no_grad():
+        assert ops.conv_pair_nograd_h(x, w1, b1, (0, 1, 1), w2, b2, (2, 0, 0), (-2, 0, 0), r) is None      # fp32: never
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("with_ss", [False, True])
+def test_block_with_16_bit_groupnorm_output_is_bit_identical(mode, with_ss):
+    """GroupNorm-apply + SiLU stored in the operand type (diqt_gn_act_fwd_h) in front of the 16-bit conv pair: the conv would round the
+    fp32 values to that type while staging them, so the block's output is bit-identical to groupnorm_act (fp32) + two convs."""
+    from diffusioniqt_amd import ops, _lib
+    B, Fr, S, C1, C2 = 2, 9, 24, 64, 32
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(B, Fr, S, S, C1, generator=g) * 2 + 0.5).to(DEV)
+    gamma, beta = torch.randn(C1, generator=g).to(DEV), torch.randn(C1, generator=g).to(DEV)
+    ss = (torch.randn(B, 2 * C1, generator=g) * 0.3).to(DEV) if with_ss else None
+    w1 = (torch.randn(C2, C1, 1, 3, 3, generator=g) * 0.05).to(DEV); b1 = torch.randn(C2, generator=g).to(DEV)
+    w2 = (torch.randn(C2, C2, 3, 1, 1, generator=g) * 0.1).to(DEV); b2 = torch.randn(C2, generator=g).to(DEV)
+    prev = _lib.query("diqt_set_convh_workgroups", 2)
+    try:
+        with ops.low_precision(mode), torch.no_grad():
+            y = ops.conv_pair_nograd_h(x, w1, b1, (0, 1, 1), w2, b2, (2, 0, 0), (-2, 0, 0), None, gn=(gamma, beta, ss, 8, ops.ACT_SILU, 1e-5))
+            assert y is not None
+            xn = ops.groupnorm_act(x, gamma, beta, ss, 8, ops.ACT_SILU, 1e-5)
+            ref = ops.conv3d(ops.conv3d(xn, w1, b1, (0, 1, 1)), w2, b2, (2, 0, 0), extra_pad=(-2, 0, 0))
+    finally:
+        _lib.query("diqt_set_convh_workgroups", prev)
+    assert torch.equal(y, ref), (y - ref).abs().max()

@@ -119,8 +119,9 @@ PROTOTYPES = {
     "diqt_mqa_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "diqt_mqa_attention_fwd_frames": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P]),
     "diqt_set_convh_workgroups": (I, [I]),
-    "diqt_conv3d_fwd_h_io16_supported": (I, [I] * 15),
-    "diqt_conv3d_fwd_h_io": (I, [P, P, P, P, P] + [I] * 15 + [I, I, I, I, P]),
+    "diqt_conv3d_fwd_h_io16_supported": (I, [I] * 17),
+    "diqt_conv3d_fwd_h_stats_blocks": (I, [I] * 17),
+    "diqt_conv3d_fwd_h_io": (I, [P, P, P, P, P] + [I] * 15 + [I, I, I, I, P, P]),
     "diqt_conv3d_fwd_smallcout_supported": (I, [I] * 15),
     "diqt_conv3d_fwd_smallcout": (I, [P, P, P, P, P] + [I] * 15 + [P]),
     "diqt_temporal_attention_h_supported": (I, [I, I, I, I, I, I]),

@@ -342,10 +342,13 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
 // XH: x holds 16-bit values (the operand type) instead of fp32 -- a halo piece is 8 channels and goes to the LDS image as it is;
 // YH: y is stored as 16-bit values (round_out, no residual).  The pair of convs of a pseudo-3D block passes its intermediate tensor this
 // way: the values are the ones the fp32 tensor would hold (already rounded to the operand type), at half the bytes.
-template <bool BF, int OCC, int NHR, int TGM, bool XH, bool YH>       // workgroups per CU, halo pieces per thread, most taps per weight group
+template <bool BF, int OCC, int NHR, int TGM, bool XH, bool YH, bool STATS = false>       // workgroups per CU, halo pieces per thread, most taps per weight group
 __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
                                                               const float* __restrict__ bias, const float* __restrict__ residual,
-                                                              float* __restrict__ y, HalfGeom g, int nUnits, int perWg) {
+                                                              float* __restrict__ y, HalfGeom g, int nUnits, int perWg,
+                                                              float* __restrict__ stats) {
+    // stats (optional): column sums (sum, sum of squares) of the STORED values per (tile, wave) for the consumer's GroupNorm:
+    // [B][tiles per batch * 8][2][Cout]
     constexpr int NWR = (TGM * 256 + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const int HV = g.HD * g.HH * g.HWd;
@@ -579,6 +582,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                     const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
                     const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
                     const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * YE : HBUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * YE : HBUF_OOB_C;
+                    float st0 = 0.f, sq0 = 0.f, st1 = 0.f, sq1 = 0.f;
                     auto epilogue = [&](auto ROUND, auto RES) {
                         float rr0[16], rr1[16];
                         if constexpr (RES.value) {
@@ -595,6 +599,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                             float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
                             if constexpr (ROUND.value) { v0 = round_through<BF>(v0); v1 = round_through<BF>(v1); }
                             if constexpr (RES.value) { v0 += rr0[r]; v1 += rr1[r]; }
+                            if constexpr (STATS) {
+                                const float m = off != HBUF_OOB ? 1.f : 0.f;      // rows of a ragged tile beyond the volume
+                                if constexpr (YH) { v0 = round_through<BF>(v0); v1 = round_through<BF>(v1); }
+                                st0 += m * v0; sq0 += m * v0 * v0; st1 += m * v1; sq1 += m * v1 * v1;
+                            }
                             if constexpr (YH) {
                                 __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2<BF>(v0, 0.f) & 0xffffu), rs_y, off + c0, 0, 0);
                                 __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2<BF>(v1, 0.f) & 0xffffu), rs_y, off + c1, 0, 0);
@@ -610,6 +619,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                         if (residual) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::true_type{}, std::false_type{});
                     } else {
                         if (residual) epilogue(std::false_type{}, std::true_type{}); else epilogue(std::false_type{}, std::false_type{});
+                    }
+                    if constexpr (STATS) {
+                        st0 += __shfl_xor(st0, 32, 64); sq0 += __shfl_xor(sq0, 32, 64);
+                        st1 += __shfl_xor(st1, 32, 64); sq1 += __shfl_xor(sq1, 32, 64);
+                        if (h == 0) {
+                            const int nblk = g.tilesD * g.tilesH * g.tilesW * 8;
+                            const int blk = ((cur.tz * g.tilesH + cur.ty) * g.tilesW + cur.tx) * 8 + wave;
+                            float* sp = stats + ((size_t)cur.b * nblk + blk) * 2 * g.Cout;
+                            if (co0 < g.Cout) { sp[co0] = st0; sp[g.Cout + co0] = sq0; }
+                            if (co1 < g.Cout) { sp[co1] = st1; sp[g.Cout + co1] = sq1; }
+                        }
                     }
                 }
                 if (more) store_wgroup((step + 1) & 1, nn);
@@ -631,7 +651,7 @@ static size_t half_lds_bytes(const HalfGeom& g) {
 }
 
 static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
-                      int epd, int eph, int epw) {
+                      int epd, int eph, int epw, int xe = 4, int ye = 4) {      // xe, ye: bytes per element of x and y
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kd <= 0 || kh <= 0 || kw <= 0) return false;
     if (pd < 0 || ph < 0 || pw < 0 || pd + epd < 0 || ph + eph < 0 || pw + epw < 0) return false;
     if (Cin % 4 != 0) return false;
@@ -671,8 +691,8 @@ static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout
     g.tilesD = hcdiv(g.Do, g.TD); g.tilesH = hcdiv(g.Ho, g.TH); g.tilesW = hcdiv(g.Wo, g.TW);
     const long long nwg = (long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt;
     if (nwg >= (1ll << 31)) return false;
-    const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * 4ull;
-    const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * 4ull;
+    const unsigned long long xb = (unsigned long long)g.B * g.D * g.H * g.W * g.Cin * (unsigned long long)xe;
+    const unsigned long long yb = (unsigned long long)g.B * g.Do * g.Ho * g.Wo * g.Cout * (unsigned long long)ye;
     if (xb >= (1ull << 30) || yb >= (1ull << 30)) return false;       // buffer-descriptor addressing
     g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb;
     return true;
@@ -746,20 +766,32 @@ static bool convh_persistent_takes(const HalfGeom& g, unsigned nwg) {
 
 // 1 when diqt_conv3d_fwd_h_io takes 16-bit x and / or y for this shape: the persistent kernel's conditions and Cin, Cout % 8 == 0
 extern "C" int diqt_conv3d_fwd_h_io16_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
-                                                int pw, int epd, int eph, int epw) {
+                                                int pw, int epd, int eph, int epw, int x_half, int y_half) {
     HalfGeom g;
-    if (Cin % 8 != 0 || Cout % 8 != 0 || !half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return 0;
+    if (Cin % 8 != 0 || Cout % 8 != 0 ||
+        !half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, x_half ? 2 : 4, y_half ? 2 : 4))
+        return 0;
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
     return convh_persistent_takes(g, nwg) ? 1 : 0;
 }
 
+// rows of per-(tile, wave) column sums diqt_conv3d_fwd_h_io writes per batch entry when given `stats` (0: this shape emits none)
+extern "C" int diqt_conv3d_fwd_h_stats_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
+                                              int pw, int epd, int eph, int epw, int x_half, int y_half) {
+    HalfGeom g;
+    if (!half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, x_half ? 2 : 4, y_half ? 2 : 4)) return 0;
+    if ((kd == 1 && kh == 1 && kw == 1) || !x_half || y_half) return 0;          // flattened rows: tiles straddle batch entries
+    const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
+    return convh_persistent_takes(g, nwg) ? g.tilesD * g.tilesH * g.tilesW * 8 : 0;
+}
+
 static int convh_launch(const void* x, const void* packed_h, const float* bias, const float* residual, void* y, int B, int D, int H, int W,
                         int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, int bf16,
-                        int round_out, bool xh, bool yh, void* stream) {
+                        int round_out, bool xh, bool yh, float* stats, void* stream) {
     DIQT_REQUIRE(x && packed_h && y, DIQT_E_ALIGN, "conv3d_fwd_h: null pointer");
     DIQT_REQUIRE(aligned16(x) && aligned16(packed_h), DIQT_E_ALIGN, "conv3d_fwd_h: x and the packed weights must be 16-byte aligned");
     HalfGeom g;
-    DIQT_REQUIRE(half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw), DIQT_E_UNSUPPORTED,
+    DIQT_REQUIRE(half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, xh ? 2 : 4, yh ? 2 : 4), DIQT_E_UNSUPPORTED,
                  "conv3d_fwd_h: shape not supported by the low-precision kernel (diqt_conv3d_fwd_h_supported == 0)");
     g.roundOut = round_out ? 1 : 0;
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
@@ -779,16 +811,17 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
         if (xh || yh) {
             DIQT_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && (!yh || (round_out && !residual)), DIQT_E_UNSUPPORTED,
                          "conv3d_fwd_h_io: 16-bit tensors need Cin, Cout %% 8 == 0; a 16-bit output needs round_out and no residual");
-            if (xh) g.xBytes /= 2;
-            if (yh) g.yBytes /= 2;
         }
-        typedef void (*KP)(const float*, const unsigned short*, const float*, const float*, float*, HalfGeom, int, int);
+        DIQT_REQUIRE(!stats || !(kd == 1 && kh == 1 && kw == 1), DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: no statistics from a 1x1x1 conv");
+        typedef void (*KP)(const float*, const unsigned short*, const float*, const float*, float*, HalfGeom, int, int, float*);
         const int sel = (bf16 ? 4 : 0) + (xh ? 2 : 0) + (yh ? 1 : 0);
         static const KP tab[8] = {conv_fwd_hp_kernel<false, 1, HHREG, HTG, false, false>, conv_fwd_hp_kernel<false, 1, HHREG, HTG, false, true>,
-                                  conv_fwd_hp_kernel<false, 1, HHREG, HTG, true, false>,  conv_fwd_hp_kernel<false, 1, HHREG, HTG, true, true>,
+                                  conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, false>,  conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, true>,
                                   conv_fwd_hp_kernel<true, 1, HHREG, HTG, false, false>,  conv_fwd_hp_kernel<true, 1, HHREG, HTG, false, true>,
-                                  conv_fwd_hp_kernel<true, 1, HHREG, HTG, true, false>,   conv_fwd_hp_kernel<true, 1, HHREG, HTG, true, true>};
-        const KP kp = tab[sel];
+                                  conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, false>,   conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, true>};
+        DIQT_REQUIRE(!stats || (xh && !yh), DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: statistics are built for x_half = 1, y_half = 0");
+        const KP kp = stats ? (bf16 ? conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, false, true> : conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, false, true>)
+                            : tab[sel];
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -796,10 +829,10 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
         const int wgs = diqt_set_convh_workgroups(0);
         const int perWg = (int)((nwg + wgs - 1) / wgs), grid = (int)((nwg + perWg - 1) / perWg);
         hipLaunchKernelGGL(kp, dim3(grid), dim3(512), lds, s, static_cast<const float*>(x), static_cast<const unsigned short*>(packed_h), bias,
-                           residual, static_cast<float*>(y), g, (int)nwg, perWg);
+                           residual, static_cast<float*>(y), g, (int)nwg, perWg, stats);
         return check_launch("conv3d_fwd_h(persistent)");
     }
-    DIQT_REQUIRE(!xh && !yh, DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: 16-bit tensors only on the persistent kernel (diqt_conv3d_fwd_h_io16_supported)");
+    DIQT_REQUIRE(!xh && !yh && !stats, DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: 16-bit tensors only on the persistent kernel (diqt_conv3d_fwd_h_io16_supported)");
     void (*kern)(const float*, const unsigned short*, const float*, const float*, float*, HalfGeom) =
         bf16 ? (pref ? conv_fwd_h_kernel<true, true> : conv_fwd_h_kernel<true, false>)
              : (pref ? conv_fwd_h_kernel<false, true> : conv_fwd_h_kernel<false, false>);
@@ -816,12 +849,12 @@ extern "C" int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const flo
                                  int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph,
                                  int epw, int bf16, int round_out, void* stream) {
     return convh_launch(x, packed_h, bias, residual, y, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, bf16, round_out, false,
-                        false, stream);
+                        false, nullptr, stream);
 }
 
 extern "C" int diqt_conv3d_fwd_h_io(const void* x, const void* packed_h, const float* bias, const float* residual, void* y, int B, int D,
                                     int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph,
-                                    int epw, int bf16, int round_out, int x_half, int y_half, void* stream) {
+                                    int epw, int bf16, int round_out, int x_half, int y_half, float* stats, void* stream) {
     return convh_launch(x, packed_h, bias, residual, y, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, bf16, round_out,
-                        x_half != 0, y_half != 0, stream);
+                        x_half != 0, y_half != 0, stats, stream);
 }

@@ -156,7 +156,7 @@ class Conv3d(nn.Module):
                 kt = tc.weight.shape[-1]
                 return ops.conv_pair_nograd_h(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), tc.weight.unsqueeze(-1).unsqueeze(-1),
                                               tc.bias, (kt - 1, 0, 0), (-(kt - 1), 0, 0), residual,
-                                              gn=(norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps))
+                                              gn=(norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps), want_stats=want_stats)
             x = ops.gn_conv3d(x, norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps, sc.weight.unsqueeze(2), sc.bias,
                               (0, k // 2, k // 2), residual if last else None, want_stats=want_stats and last)
             if x is None:
@@ -166,7 +166,7 @@ class Conv3d(nn.Module):
                 tc = self.temporal_conv
                 kt = tc.weight.shape[-1]
                 y = ops.conv_pair_nograd_h(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), tc.weight.unsqueeze(-1).unsqueeze(-1),
-                                           tc.bias, (kt - 1, 0, 0), (-(kt - 1), 0, 0), residual)
+                                           tc.bias, (kt - 1, 0, 0), (-(kt - 1), 0, 0), residual, want_stats=want_stats)
                 if y is not None:
                     return y
             x = ops.conv3d(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), residual=residual if last else None,

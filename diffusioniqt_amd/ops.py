@@ -191,7 +191,7 @@ def _packed_h(weight5, bf16, mode=0):
     return packed
 
 
-def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0, x_half=False, y_half=False):
+def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0, x_half=False, y_half=False, stats_out=None):
     """fp16 / bf16-operand forward (mode 0) or backward-data (mode 1: x5 is dY, pad / epad already transformed) through
     diqt_conv3d_fwd_h, or None when the low-precision kernel does not take this shape.  x_half / y_half: the tensor at that end holds
     16-bit values of the operand type (diqt_conv3d_fwd_h_io; the caller has asked conv_half_io16_ok)."""
@@ -202,11 +202,11 @@ def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0, x_half=F
     hdt = torch.bfloat16 if bf16 else torch.float16
     ex, ey = (2 if x_half else 4), (2 if y_half else 4)
     Bc = B                      # batch entries per launch: the kernel addresses a tensor through one buffer descriptor (< 1 GiB of fp32)
-    while not _lib.query("diqt_conv3d_fwd_h_supported", Bc, *geo[1:]):
+    io16 = x_half or y_half
+    while not io16 and not _lib.query("diqt_conv3d_fwd_h_supported", Bc, *geo[1:]):
         if Bc % 2 or max(x5[:Bc].numel(), Bc * D * H * W * Cout) * 4 < (1 << 30):
             return None
         Bc //= 2
-    io16 = x_half or y_half
     assert not io16 or (Bc == B and x5.dtype == (hdt if x_half else torch.float32))
     Do, Ho, Wo = D + 2 * pad[0] + epad[0] - kd + 1, H + 2 * pad[1] + epad[1] - kh + 1, W + 2 * pad[2] + epad[2] - kw + 1
     y = torch.empty((B, Do, Ho, Wo, Cout), dtype=hdt if y_half else torch.float32, device=x5.device)
@@ -215,7 +215,13 @@ def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0, x_half=F
         s.record()
     packed = _packed_h(weight, bf16, mode)
     if io16:
-        _lib.call("diqt_conv3d_fwd_h_io", x5, packed, bias, residual, y, *geo, bf16, 1, int(x_half), int(y_half), _stream())
+        stats = None
+        if stats_out is not None:
+            nblk = _lib.query("diqt_conv3d_fwd_h_stats_blocks", *geo, int(x_half), int(y_half))
+            if nblk > 0:                     # per-(tile, wave) column sums of y for the consumer's GroupNorm
+                stats = torch.empty((B, nblk, 2, Cout), dtype=torch.float32, device=x5.device)
+                stats_out.append(ColStats(stats, nblk, Do * Ho * Wo))
+        _lib.call("diqt_conv3d_fwd_h_io", x5, packed, bias, residual, y, *geo, bf16, 1, int(x_half), int(y_half), stats, _stream())
     else:
         for b0 in range(0, B, Bc):
             _lib.call("diqt_conv3d_fwd_h", x5[b0:b0 + Bc], packed, bias, residual[b0:b0 + Bc] if residual is not None else None,
@@ -254,7 +260,7 @@ def _groupnorm_act_h(x, gamma, beta, ss, groups, act, eps, lp):
     return y
 
 
-def conv_pair_nograd_h(x, w1, b1, pad1, w2, b2, pad2, epad2, residual=None, gn=None):
+def conv_pair_nograd_h(x, w1, b1, pad1, w2, b2, pad2, epad2, residual=None, gn=None, want_stats=False):
     """Two convs in a row on the sampling path under autocast -- the per-frame and the temporal conv of a pseudo-3D block -- with
     the tensor between them in the operand type (it holds exactly the values the fp32 tensor would: the first conv's result is rounded
     to that type either way).  ``gn`` = (gamma, beta, scale_shift, groups, act, eps): x is the raw input of the block's GroupNorm, whose
@@ -268,18 +274,23 @@ def conv_pair_nograd_h(x, w1, b1, pad1, w2, b2, pad2, epad2, residual=None, gn=N
     Cm, C2 = w1.shape[0], w2.shape[0]
     k1, k2 = tuple(w1.shape[2:]), tuple(w2.shape[2:])
     D1, H1, W1 = D + 2 * pad1[0] - k1[0] + 1, H + 2 * pad1[1] - k1[1] + 1, W + 2 * pad1[2] - k1[2] + 1
-    if not (_lib.query("diqt_conv3d_fwd_h_io16_supported", B, D, H, W, Cin, Cm, *k1, *pad1, 0, 0, 0)
-            and _lib.query("diqt_conv3d_fwd_h_io16_supported", B, D1, H1, W1, Cm, C2, *k2, *pad2, *epad2)):
+    xh = gn is not None
+    if xh and (Cin % 4 != 0 or Cin % gn[3] != 0):
         return None
-    xin, xh = x, False
-    if gn is not None:
+    if not (_lib.query("diqt_conv3d_fwd_h_io16_supported", B, D, H, W, Cin, Cm, *k1, *pad1, 0, 0, 0, int(xh), 1)
+            and _lib.query("diqt_conv3d_fwd_h_io16_supported", B, D1, H1, W1, Cm, C2, *k2, *pad2, *epad2, 1, 0)):
+        return None
+    xin = x
+    if xh:
         gamma, beta, ss, groups, act, eps = gn
-        if Cin % 4 != 0 or Cin % groups != 0:
-            return None
         _chk(gamma, beta, ss.base if isinstance(ss, SSView) else None)
-        xin, xh = _groupnorm_act_h(x, gamma, beta, ss, groups, act, eps, lp), True
+        xin = _groupnorm_act_h(x, gamma, beta, ss, groups, act, eps, lp)
     mid = _conv_fwd_half(xin, w1, b1, None, pad1, (0, 0, 0), lp, x_half=xh, y_half=True)
-    return _conv_fwd_half(mid, w2, b2, residual, pad2, epad2, lp, x_half=True)
+    holder = [] if want_stats else None
+    y = _conv_fwd_half(mid, w2, b2, residual, pad2, epad2, lp, x_half=True, stats_out=holder)
+    if holder:
+        y._diqt_stats = holder[0]           # consumed by the next GroupNorm on this exact tensor
+    return y
 
 
 def _conv_fwd_smallcout(x5, weight, bias, residual, pad, epad):

@@ -92,10 +92,15 @@ int diqt_conv3d_fwd_h_supported(int B, int D, int H, int W, int Cin, int Cout, i
  * rounds a conv's result to the operand type -- at half the bytes.  Only where ..._io16_supported says 1 (the persistent kernel's
  * shapes, Cin and Cout multiples of 8).                                                                                        */
 int diqt_conv3d_fwd_h_io16_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
-                                     int epd, int eph, int epw);
+                                     int epd, int eph, int epw, int x_half, int y_half);
+/* stats (may be NULL): per-(tile, wave) column sums (sum, sum of squares) of the stored values for the consumer's GroupNorm,
+ * [B][nblk][2][Cout] with nblk = diqt_conv3d_fwd_h_stats_blocks(...) (0: none for this shape); feed them to
+ * diqt_groupnorm_stats_from_partials -- the statistics pass over the tensor disappears.                                        */
+int diqt_conv3d_fwd_h_stats_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                   int epd, int eph, int epw, int x_half, int y_half);
 int diqt_conv3d_fwd_h_io(const void* x, const void* packed_h, const float* bias, const float* residual, void* y, int B, int D, int H,
                          int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, int bf16,
-                         int round_out, int x_half, int y_half, void* stream);
+                         int round_out, int x_half, int y_half, float* stats, void* stream);
 /* diqt_conv3d_fwd_h walks (tile, channel-block) units with a persistent kernel of this many workgroups (default 256, one per CU;
  * env DIQT_CONVH_WGS; DIQT_CONVH_PERSIST=0 disables it) when a launch has at least twice as many units and the halo tile fits the
  * register prefetch; n > 0 sets the count, n <= 0 only queries; returns the previous value.  Results do not depend on it.      */

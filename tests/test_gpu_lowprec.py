@@ -380,8 +380,13 @@ def test_conv_pair_with_a_16_bit_intermediate_is_bit_identical(B, Fr, S, C1, C2,
     prev = _lib.query("diqt_set_convh_workgroups", 3)          # the persistent walk (production: >= 512 units) on a small shape
     try:
         with ops.low_precision(mode), torch.no_grad():
-            y = ops.conv_pair_nograd_h(x, w1, b1, (0, 1, 1), w2, b2, (2, 0, 0), (-2, 0, 0), r)
+            y = ops.conv_pair_nograd_h(x, w1, b1, (0, 1, 1), w2, b2, (2, 0, 0), (-2, 0, 0), r, want_stats=True)
             assert y is not None and y.dtype == torch.float32
+            st = y._diqt_stats              # per-(tile, wave) column sums of the stored values, for the next GroupNorm
+            assert st.rows == Fr * S * S and st.partials.shape[0] == B and st.partials.shape[2:] == (2, C2)
+            yd = y.double().reshape(B, -1, C2)
+            assert torch.allclose(st.partials.double().sum(1)[:, 0], yd.sum(1), rtol=1e-5, atol=1e-3)
+            assert torch.allclose(st.partials.double().sum(1)[:, 1], (yd * yd).sum(1), rtol=1e-5, atol=1e-3)
             mid = ops.conv3d(x, w1, b1, (0, 1, 1))
             ref = ops.conv3d(mid, w2, b2, (2, 0, 0), residual=r, extra_pad=(-2, 0, 0))
     finally:

@@ -53,9 +53,11 @@ __device__ __forceinline__ float attn_bias_mask(float v, int j, int M, int E, in
     return dead ? -INFINITY : v + b;
 }
 
-template <int ND>           // dim_head = 32 * ND
+// HASREL: a relative-position bias table is given -- a template parameter, see mqa_flash_fwd_h_kernel (the table-index arithmetic of a
+// tile is hoisted above the `plain tile` branch: vector instructions that share the f32 MFMA's lanes, spent even without a table)
+template <int ND, bool HASREL = true>           // dim_head = 32 * ND
 __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
-                                                               const float* __restrict__ rel, const float* __restrict__ null_bias,
+                                                               const float* __restrict__ rel_, const float* __restrict__ null_bias,
                                                                float* __restrict__ out, float* __restrict__ lse, int n, int h, int E,
                                                                int ns, int causal, float scale, int P, const float* __restrict__ nullkv) {
     // P > 0: the sequences are the FRAME axis of channels-last tensors q[B][n][P][h D], kv[B][n][P][2 D], out like q (sequence
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_fwd_kernel(const float* __re
     // attentions -- and the lone extra key / value (E == 1, the learned null row) comes from nullkv[2 D] instead of a concatenated copy
     // of kv.  P == 0: q[G][n][h D], kv[G][E + ns][2 D] as documented above.
     constexpr int D = 32 * ND, ROW = D + 4, NPF = AKT * (2 * D / 4) / 256;    // float4 pieces of a K|V tile per thread
+    const float* __restrict__ rel = HASREL ? rel_ : nullptr;
     __shared__ __attribute__((aligned(16))) float KVs[2][2][AKT * ROW];       // [buffer][K | V][key][ROW]
     const int g = blockIdx.y;
     const int M = E + ns, R = n * h;                       // keys, query rows of this batch entry
@@ -500,11 +503,11 @@ extern "C" int diqt_mqa_attention_fwd(const float* q, const float* kv, const flo
     DIQT_REQUIRE(G <= 65535, DIQT_E_SHAPE, "mqa_attention_fwd: G > 65535");
     const dim3 grid((unsigned)(((long long)n * h + AQ - 1) / AQ), G);
     if (d == 64)
-        hipLaunchKernelGGL(mqa_flash_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, (float*)nullptr, n, h,
-                           n_extra, n_self, causal, scale, 0, (const float*)nullptr);
+        hipLaunchKernelGGL((rel ? mqa_flash_fwd_kernel<2, true> : mqa_flash_fwd_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, q, kv,
+                           rel, null_bias, out, (float*)nullptr, n, h, n_extra, n_self, causal, scale, 0, (const float*)nullptr);
     else
-        hipLaunchKernelGGL(mqa_flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, kv, rel, null_bias, out, (float*)nullptr, n, h,
-                           n_extra, n_self, causal, scale, 0, (const float*)nullptr);
+        hipLaunchKernelGGL((rel ? mqa_flash_fwd_kernel<1, true> : mqa_flash_fwd_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, q, kv,
+                           rel, null_bias, out, (float*)nullptr, n, h, n_extra, n_self, causal, scale, 0, (const float*)nullptr);
     return check_launch("mqa_attention_fwd");
 }
 

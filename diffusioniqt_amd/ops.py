@@ -228,8 +228,9 @@ def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0, x_half=F
                       y[b0:b0 + Bc], Bc, *geo[1:], bf16, 1, _stream())
     if TIMER.enabled:
         e.record()
-        TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_fwd_h_kernel",
-                              (B, D, H, W, Cin, Cout, kd, kh, kw)))
+        # rocprofv3's name of the kernel that ran: launches of >= 2 x 256 units take the persistent form
+        tag = "conv_fwd_hp_kernel" if io16 or _lib.query("diqt_conv3d_fwd_h_io16_supported", *geo, 0, 0) else "conv_fwd_h_kernel"
+        TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, tag, (B, D, H, W, Cin, Cout, kd, kh, kw)))
     return y
 
 

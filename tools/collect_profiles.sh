@@ -18,6 +18,10 @@ stats sample python3 $R/bench.py --mode sample --steps 20 --warmup 3 $B
 stats train python3 $R/bench.py --mode train --steps 12 --warmup 4 $B
 stats unet3d_eval python3 $R/tools/unet3d_bench.py 64 32 8
 stats unet3d_train python3 $R/tools/unet3d_train_bench.py 64 32 8
+# one C5 stage-2 U-Net eval under autocast fp16 (Unet3D dim 64, 64 frames x 64 x 64, batch 8): the cascade's dominant loop body
+NO_LAYER_ATTNS=1 AUTOCAST=fp16 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5s2 -o c5s2 -- python3 $R/tools/unet3d_bench.py 64 64 8 > $OUT/c5s2_fp16.log 2>&1
+cp $(find /tmp/p_c5s2 -name "*kernel_stats.csv" | head -1) $OUT/c5s2_fp16_kernel_stats.csv
+echo "done c5s2"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $R/bench.py --mode both --steps 4 --warmup 4 $B > $OUT/pmc_fetch.log 2>&1
 echo "done fetch"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $R/bench.py --mode both --steps 4 --warmup 4 $B > $OUT/pmc_write.log 2>&1

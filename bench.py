@@ -200,11 +200,16 @@ def main():
         """Per-kernel HIP-event timing of n more calls, OUTSIDE any timed region -> {tag: (ms, flops, launches)}."""
         if args.no_kernel_timer:
             return {}
+        from diffusioniqt_amd import graphs
         sync_all()
         ops.TIMER.reset()
         ops.TIMER.enabled = True
-        for _ in range(n):
-            fn()
+        was, graphs.ENABLED = graphs.ENABLED, False      # per-launch events need the launches to come from Python, not from a replay
+        try:
+            for _ in range(n):
+                fn()
+        finally:
+            graphs.ENABLED = was
         sync_all()
         ops.TIMER.enabled = False
         return ops.TIMER.summary()

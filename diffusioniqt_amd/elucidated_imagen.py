@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .graphs import GraphCache
 from .imagen_pytorch3D import (GaussianDiffusionContinuousTimes, Unet, NullUnet, exists, default, cast_tuple, identity, maybe,
                                normalize_neg_one_to_one, unnormalize_zero_to_one, eval_decorator, to_channels_last,
                                to_channels_first, log_snr_to_alpha_sigma)
@@ -94,6 +95,7 @@ class ElucidatedImagen(nn.Module):
         hparams = [num_sample_steps, sigma_min, sigma_max, sigma_data, rho, P_mean, P_std, S_churn, S_tmin, S_tmax, S_noise]
         hparams = [cast_tuple(hp, num_unets) for hp in hparams]
         self.hparams = [Hparams(*unet_hp) for unet_hp in zip(*hparams)]
+        self._graphs = GraphCache()           # hipGraph replay of the U-Net evaluations of a sampling loop (graphs.py)
         self.register_buffer('_temp', torch.tensor([0.]), persistent=False)
         self.to(next(self.unets.parameters()).device)
 
@@ -178,7 +180,12 @@ class ElucidatedImagen(nn.Module):
         sig = torch.full((B,), float(sigma)) if isinstance(sigma, float) else sigma.detach().float().cpu()
         cin, cskip, cout = (f(sigma_data, sig).to(dev) for f in (self.c_in, self.c_skip, self.c_out))
         x_in = ops.axpby3(noised_images.contiguous(), None, None, cin, None, None)
-        net_out = unet_forward(x_in, self.c_noise(sig).to(dev), **kwargs)
+        owner = getattr(unet_forward, '__self__', None)
+        if owner is not None and not torch.is_grad_enabled():
+            # sampling: after two eager calls the U-Net evaluation replays as a hipGraph (the small stages of a cascade are launch-bound)
+            net_out = self._graphs.run(owner, unet_forward, (x_in, self.c_noise(sig).to(dev)), kwargs)
+        else:
+            net_out = unet_forward(x_in, self.c_noise(sig).to(dev), **kwargs)
         if clamp and dynamic_threshold:
             out = ops.axpby3(noised_images.contiguous(), net_out.contiguous(), None, cskip, cout, None, 0., 0., 0)
             return self.threshold_x_start(out, True)

@@ -1,0 +1,112 @@
+"""hipGraph capture + replay of a no-grad U-Net evaluation (sampling loops).
+
+The small stages of a cascade are launch-bound: one `Unet3D` eval of the C5 cascade's first stage (32 frames x 32 x 32, batch 8, autocast)
+is ~560 kernel launches and 8.8 ms of GPU work but 15 ms of wall time when every launch is issued from Python.  A sampler calls the
+same U-Net with the same shapes 2 N - 1 times per stage, so after two eager calls the evaluation is captured once into a hipGraph
+(`torch.cuda.CUDAGraph`: the ctypes launches of libdiqt_hip.so go to torch's current stream, which is the capture stream) and replayed:
+inputs are copied into the captured buffers, the output is copied out.  Nothing about the computation changes -- the same kernels with the
+same arguments -- so results are bit-identical to the eager calls.  Only evaluations that ARE launch-bound are captured: the last eager call
+is timed on the host and on the GPU, and a GPU-bound evaluation (the 64^3 stage: 55 ms of kernels behind 6 ms of launching) stays eager.
+
+A captured graph also froze what the eager calls cached on the host side (packed weight copies, position-bias tables): the key holds the
+parameters' version counters, so an optimizer step or a `load_state_dict` retires the graph.  `DIQT_GRAPHS=0` switches the cache off, `=2` captures regardless of the timing (tests).
+"""
+import os
+import time
+
+import torch
+
+from . import ops
+
+ENABLED = os.environ.get("DIQT_GRAPHS", "1") != "0"
+FORCE = os.environ.get("DIQT_GRAPHS") == "2"       # capture whether or not the evaluation is launch-bound (tests)
+
+
+def _sig(v):
+    if torch.is_tensor(v):
+        return ("T", tuple(v.shape), v.dtype, v.device.index)
+    if isinstance(v, (list, tuple)):
+        return tuple(_sig(x) for x in v)
+    return v if isinstance(v, (int, float, bool, str, type(None))) else ("O", id(v))
+
+
+class GraphCache:
+    def __init__(self, warm=2, max_entries=4):
+        self.entries = {}
+        self.warm, self.max_entries = warm, max_entries
+        self.replays = 0                                 # diagnostics / tests
+
+    def clear(self):
+        self.entries.clear()
+
+    def run(self, owner, fn, args, kwargs):
+        """``fn(*args, **kwargs)`` -- eagerly the first ``warm`` times a (module, shapes, precision, parameter versions) combination is seen,
+        through a captured graph afterwards.  ``owner``: the nn.Module whose parameters ``fn`` reads."""
+        if not ENABLED or torch.is_grad_enabled() or not args[0].is_cuda:
+            return fn(*args, **kwargs)
+        params = list(owner.parameters())
+        key = (id(owner), ops.lp_mode(), ops._WEIGHT_EPOCH, sum(p._version for p in params), params[0].data_ptr() if params else 0,
+               _sig(args), tuple(sorted((k, _sig(v)) for k, v in kwargs.items())))
+        ent = self.entries.get(key)
+        if ent is None:
+            if len(self.entries) >= self.max_entries:    # stale keys (older parameter versions, other shapes): drop them and their pools
+                self.entries.clear()
+            ent = self.entries[key] = dict(calls=0, graph=None, failed=False)
+        if ent["failed"]:
+            return fn(*args, **kwargs)
+        if ent["graph"] is None:
+            ent["calls"] += 1
+            if ent["calls"] < self.warm:
+                return fn(*args, **kwargs)
+            if ent["calls"] == self.warm:
+                # the last eager call is timed on both sides: issuing its launches from Python (host) against its span on the GPU
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                t0 = time.perf_counter()
+                out = fn(*args, **kwargs)
+                ent["host_ms"] = (time.perf_counter() - t0) * 1e3
+                e1.record()
+                ent["events"] = (e0, e1)
+                return out
+            if "launch_bound" not in ent:
+                e0, e1 = ent.pop("events")
+                e1.synchronize()
+                ent["gpu_ms"] = e0.elapsed_time(e1)
+                # GPU-bound: the host runs ahead and spends a fraction of the GPU's time issuing; launch-bound: the two are the same
+                ent["launch_bound"] = FORCE or ent["host_ms"] > 0.7 * ent["gpu_ms"]
+                if not ent["launch_bound"]:
+                    ent["failed"] = True                 # stays eager: a replay would only add the input / output copies
+                    return fn(*args, **kwargs)
+            self._capture(ent, fn, args, kwargs)
+            if ent["failed"]:
+                return fn(*args, **kwargs)
+        for dst, src in zip(ent["args"], args):
+            if torch.is_tensor(dst):
+                dst.copy_(src)
+        for k, dst in ent["kwargs"].items():
+            if torch.is_tensor(dst):
+                dst.copy_(kwargs[k])
+        ent["graph"].replay()
+        self.replays += 1
+        return ent["out"].clone()
+
+    @staticmethod
+    def _capture(ent, fn, args, kwargs):
+        clone = lambda v: v.clone() if torch.is_tensor(v) else v
+        s_args, s_kwargs = [clone(a) for a in args], {k: clone(v) for k, v in kwargs.items()}
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                # one more eager run on a side stream: every lazily built cache is warm
+                fn(*s_args, **s_kwargs)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn(*s_args, **s_kwargs)
+            ent.update(graph=g, args=s_args, kwargs=s_kwargs, out=out)
+        except Exception as e:                           # noqa: BLE001 -- capture refused (an op that synchronises): stay eager for this key
+            torch.cuda.synchronize()
+            ent["failed"] = True
+            ent["error"] = repr(e)
+            if FORCE:                                    # strict mode for tests
+                raise

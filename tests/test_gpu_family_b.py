@@ -422,3 +422,55 @@ def test_gate_residual_hands_groupnorm_statistics_to_the_next_block():
         a = ops.groupnorm_act(y, gamma, beta, None, 8, ops.ACT_SILU, 1e-5)
         b = ops.groupnorm_act(y.clone(), gamma, beta, None, 8, ops.ACT_SILU, 1e-5)         # the clone carries no statistics
     assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+@pytest.mark.parametrize("lp", [None, torch.float16])
+def test_sampling_replays_the_unet_as_a_graph_bit_identically(lp):
+    """ElucidatedImagen.sample: after two eager U-Net evaluations the third and later ones of a stage replay a captured hipGraph
+    (graphs.py).  Same kernels, same arguments: the sample must be BIT-IDENTICAL to the all-eager run; an optimizer step
+    (parameter version change) retires the graph."""
+    import contextlib
+    from diffusioniqt_amd import graphs
+    from diffusioniqt_amd.imagen_video import Unet3D
+    from diffusioniqt_amd.elucidated_imagen import ElucidatedImagen
+    torch.manual_seed(0)
+    kw = dict(dim=16, dim_mults=(1, 2), channels=1, cond_on_text=False, text_embed_dim=None, layer_attns=False, layer_cross_attns=False,
+              attend_at_middle=True, num_resnet_blocks=1, attn_pool_text=False, attn_heads=2, attn_dim_head=16)
+    u1, u2 = Unet3D(**{**kw, 'lowres_cond': False}), Unet3D(**{**kw, 'lowres_cond': True})
+    for u in (u1, u2):
+        for p in u.final_conv.parameters():
+            torch.nn.init.normal_(p, std=0.05)
+    elu = ElucidatedImagen(unets=(u1, u2), image_sizes=(8, 16), channels=1, condition_on_text=False, auto_normalize_img=False,
+                           num_sample_steps=4, temporal_downsample_factor=(2, 1)).to(DEV)
+    B, Fr = 2, 8
+    g = torch.Generator().manual_seed(1)
+    noise = [[torch.randn(B, 1, Fr // 2, 8, 8, generator=g) for _ in range(5)],                       # init + 4 steps
+             [torch.randn(B, 1, Fr, 16, 16, generator=g) for _ in range(6)]]                          # lowres noise + init + 4 steps
+    ctx = (lambda: torch.autocast('cuda', dtype=lp)) if lp is not None else contextlib.nullcontext
+
+    def run():
+        with ctx():
+            return elu.sample(batch_size=B, video_frames=Fr, use_tqdm=False, noise=[t for n in noise for t in n]).cpu()
+    was, wasf = graphs.ENABLED, graphs.FORCE
+    try:
+        graphs.FORCE = True                               # capture even if this tiny net were not launch-bound
+        graphs.ENABLED = False
+        eager = run()
+        graphs.ENABLED = True
+        elu._graphs.clear(); elu._graphs.replays = 0
+        got = run()
+        n1 = elu._graphs.replays
+        assert n1 == 2 * (7 - 2), n1                      # 7 evals per stage (4 Heun steps: 2 N - 1), the first two eager
+        assert all(not e["failed"] for e in elu._graphs.entries.values())
+        assert torch.equal(got, eager)
+        again = run()                                     # the graphs are reused: all 14 evals replay
+        assert elu._graphs.replays == n1 + 14 and torch.equal(again, eager)
+        with torch.no_grad():
+            u2.final_conv.weight.mul_(1.5)                # a parameter changes: its graph is retired, the result follows the new weights
+        graphs.ENABLED = False
+        eager2 = run()
+        graphs.ENABLED = True
+        got2 = run()
+        assert torch.equal(got2, eager2) and not torch.equal(got2, eager)
+    finally:
+        graphs.ENABLED, graphs.FORCE = was, wasf

@@ -15,7 +15,8 @@
 //     y^T += W_o^T o^T        A = W_o^T rows (registers / L2), B = o^T from the accumulator registers
 // An accumulator tile used as the next B operand presents the reduction index in the order 4 hf + 8 g + e; the A side of that product
 // stores its reduction axis in the same order (LDS positions of k's channels and v^T's keys, host-packed W_o).
-// Wave w of the 4 handles heads w, w + 4 (weights of its heads live in registers for the whole kernel when C == 64); the per-wave
+// Wave w handles head w (8 waves, two per SIMD) or heads w, w + 4 (4 waves); the weights of its heads live in registers for the whole
+// kernel when C == 64; the per-wave
 // partial y^T go through LDS and are summed in a fixed order (deterministic), then LayerNorm + residual + store.
 // The null key / value (imagen_video.py:471-481) is one extra score per query, handled on the VALU.
 #include "common.h"
@@ -67,7 +68,7 @@ struct TAGeom {
 
 constexpr int TD = 64;          // dim_head
 
-template <int C, int N>
+template <int C, int N, int NW = 4>
 struct TACfg {
     static constexpr int TT = N / 32;                 // token tiles
     static constexpr int XROWB = C * 2 + 16;          // xn row: C 16-bit channels + pad
@@ -81,20 +82,25 @@ struct TACfg {
     static constexpr int NULL_OFF = REL_OFF + 8 * 2 * N * 4;      // k_null[64], v_null[64] floats
     static constexpr int PART_OFF = NULL_OFF + 2 * TD * 4;        // [4 waves][N][PROW] floats
     static constexpr int LDS = PART_OFF + 4 * N * PROW * 4;
-    static constexpr int TPR = 256 / N;               // threads per row in the staging / final passes
+    static constexpr int TPR = 64 * NW / N;           // threads per row in the staging / final passes
     static constexpr int QPT = (C / 4) / TPR;         // float4 quads per thread
     static constexpr bool WREG = C == 64;             // weights of a wave's heads in registers
     static_assert(N == 32 || N == 64, "32 or 64 frames");
     static_assert(C % 64 == 0 && C <= 256, "channels");
+    static_assert((C / 4) % TPR == 0, "whole float4 quads per thread");
 };
 
-template <int C, int N, bool BF, int HPW>
-__global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __restrict__ x, const float* __restrict__ g1,
+// NW waves, HPW heads per wave (heads = NW * HPW): 4 x 2 is one wave per SIMD with both heads' weights in registers; 8 x 1 puts two
+// waves on a SIMD, so one wave's soft-max (vector ALU) runs under the other's MFMAs -- and with half the weights per wave the
+// accumulators stay in arch registers (the 4 x 2 build spends 550 v_accvgpr_read per sequence moving them)
+template <int C, int N, bool BF, int HPW, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void temporal_attn_h_kernel(const float* __restrict__ x, const float* __restrict__ g1,
                                                                  const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wkv,
                                                                  const unsigned short* __restrict__ wo, const float* __restrict__ g2,
                                                                  const float* __restrict__ nullkv, const float* __restrict__ rel,
                                                                  const float* __restrict__ null_bias, float* __restrict__ y, TAGeom g) {
-    using Cf = TACfg<C, N>;
+    using Cf = TACfg<C, N, NW>;
+    constexpr int NT = 64 * NW;
     constexpr int TT = Cf::TT, KB = C / 16, CT = C / 32, CH = C / 64, QPT = Cf::QPT, TPR = Cf::TPR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ta[];
     unsigned char* xnS = smem_ta + Cf::XN_OFF;
@@ -106,11 +112,11 @@ __global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hf = lane >> 5;
-    const int h = g.h;                 // = 4 HPW: wave w owns heads w, w + 4
+    const int h = g.h;                 // = NW * HPW: wave w owns heads w, w + NW
     const int row = tid / TPR, part = tid % TPR;
 
     // ---- once per workgroup: bias tables, null key / value, gains ----
-    for (int e = tid; e < h * 2 * N; e += 256) {
+    for (int e = tid; e < h * 2 * N; e += NT) {
         const int hd = e / (2 * N), idx = e % (2 * N);
         // entry idx = query - key + N - 1: keys behind the query (idx < N - 1) are masked when causal
         const float b = (g.has_rel && idx < 2 * N - 1) ? rel[(size_t)idx * h + hd] : 0.f;
@@ -161,13 +167,13 @@ __global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __
     };
     constexpr int WR = Cf::WREG ? 1 : 0;
     u32x4t wqR[WR ? HPW : 1][2][WR ? KB : 1], woR[WR ? HPW : 1][WR ? CT : 1][4];
-    // kv projection tiles of this wave: N = 64: (k, dt, tt) and (v, dt, tt) with dt = wave & 1, tt = wave >> 1; N = 32: one tile, kind = wave >> 1
-    const int kvDt = wave & 1, kvTt = TT == 2 ? wave >> 1 : 0;
-    u32x4t wkvR[2][WR ? KB : 1];
+    // k / v projection tiles: t = (kind, tt, dt) in [0, 4 TT); wave w takes t = w, w + NW, ...
+    constexpr int KVT = (4 * TT + NW - 1) / NW;
+    u32x4t wkvR[KVT][WR ? KB : 1];
     if (WR) {
 #pragma unroll
         for (int u = 0; u < HPW; ++u) {
-            const int hd = wave + 4 * u;
+            const int hd = wave + NW * u;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -178,9 +184,10 @@ __global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __
                 for (int k4 = 0; k4 < 4; ++k4) woR[u][ct][k4] = load_wo(hd, ct, k4);
         }
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            wkvR[0][kb] = load_wkv(TT == 2 ? 0 : (wave >> 1), kvDt, kb);
-            wkvR[1][kb] = load_wkv(1, kvDt, kb);
+        for (int u = 0; u < KVT; ++u) {
+            const int t = min(wave + NW * u, 4 * TT - 1);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) wkvR[u][kb] = load_wkv(t / (2 * TT), t & 1, kb);
         }
     }
     __syncthreads();
@@ -240,8 +247,10 @@ __global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __
         __syncthreads();
         // ================= phase B: k (rows in LDS, channel positions permuted) and v^T (key positions permuted) =================
 #pragma unroll
-        for (int u = 0; u < TT; ++u) {
-            const int kind = TT == 2 ? u : (wave >> 1);                // 0: k (orientation W x xn^T), 1: v (orientation xn x W^T)
+        for (int u = 0; u < KVT; ++u) {
+            const int t = wave + NW * u;
+            if (t >= 4 * TT) continue;                                 // wave-uniform (8 waves, 32 frames: waves 4 .. 7 have no tile)
+            const int kind = t / (2 * TT), kvDt = t & 1, kvTt = (t % (2 * TT)) >> 1;       // 0: k (orientation W x xn^T), 1: v (xn x W^T)
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -250,13 +259,13 @@ __global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
                     const u32x4t xf = *reinterpret_cast<const u32x4t*>(xr + 32 * kb);
-                    acc = tmfma<BF>(WR ? wkvR[TT == 2 ? u : 0][WR ? kb : 0] : load_wkv(0, kvDt, kb), xf, acc);
+                    acc = tmfma<BF>(WR ? wkvR[u][WR ? kb : 0] : load_wkv(0, kvDt, kb), xf, acc);
                 }
             } else {
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
                     const u32x4t xf = *reinterpret_cast<const u32x4t*>(xr + 32 * kb);
-                    acc = tmfma<BF>(xf, WR ? wkvR[TT == 2 ? u : 0][WR ? kb : 0] : load_wkv(1, kvDt, kb), acc);
+                    acc = tmfma<BF>(xf, WR ? wkvR[u][WR ? kb : 0] : load_wkv(1, kvDt, kb), acc);
                 }
             }
             if (kind == 0) {        // acc: rows = channels 32 dt + (4 hf + 8 g4 + e), column = token 32 tt + l31
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < HPW; ++u) {
             {
-                const int hd = wave + 4 * u;
+                const int hd = wave + NW * u;
                 if (!WR) __builtin_amdgcn_sched_barrier(0);          // weights come from L2: keep one head's loads in flight, not both
                 // ---- q^T = W_q xn^T (softmax scale folded into W_q) ----
                 f32x16 qacc[2][TT];
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __
 #pragma unroll
             for (int u = 0; u < HPW; ++u) {
                 {
-                    const int hd = wave + 4 * u;
+                    const int hd = wave + NW * u;
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
@@ -436,17 +445,31 @@ __global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __
                 }
             }
             if (cb) __syncthreads();                     // the previous block's partials have been read
+            // 4 slots of [N][PROW]: with 8 waves, waves 4 .. 7 write theirs first, waves 0 .. 3 add those to their own and write the sums
+            auto slot_rw = [&](int slot, bool add, bool store) {
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
+                for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                for (int tt = 0; tt < TT; ++tt) {
-                    float* pr = partS + ((size_t)wave * N + 32 * tt + l31) * Cf::PROW + 32 * c2 + 4 * hf;
+                    for (int tt = 0; tt < TT; ++tt) {
+                        float* pr = partS + ((size_t)slot * N + 32 * tt + l31) * Cf::PROW + 32 * c2 + 4 * hf;
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const f32x16& a = yacc[c2][tt];
-                        *reinterpret_cast<float4*>(pr + 8 * g4) = make_float4(a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]);
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            f32x16& a = yacc[c2][tt];
+                            if (add) {
+                                const float4 t = *reinterpret_cast<const float4*>(pr + 8 * g4);
+                                a[4 * g4] += t.x; a[4 * g4 + 1] += t.y; a[4 * g4 + 2] += t.z; a[4 * g4 + 3] += t.w;
+                            }
+                            if (store) *reinterpret_cast<float4*>(pr + 8 * g4) = make_float4(a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]);
+                        }
                     }
-                }
+            };
+            if (NW == 8) {
+                if (wave >= 4) slot_rw(wave - 4, false, true);
+                __syncthreads();
+                if (wave < 4) slot_rw(wave, true, true);
+            } else {
+                slot_rw(wave, false, true);
+            }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < QPT; ++u) {
@@ -507,20 +530,28 @@ __global__ __launch_bounds__(256, 1) void temporal_attn_h_kernel(const float* __
 template <int C, int N>
 int ta_launch(const float* x, const float* g1, const void* wq, const void* wkv, const void* wo, const float* g2, const float* nullkv,
               const float* rel, const float* null_bias, float* y, const TAGeom& g, int bf16, hipStream_t s) {
-    using Cf = TACfg<C, N>;
-    auto kern = g.h == 8 ? (bf16 ? temporal_attn_h_kernel<C, N, true, 2> : temporal_attn_h_kernel<C, N, false, 2>)
-                         : (bf16 ? temporal_attn_h_kernel<C, N, true, 1> : temporal_attn_h_kernel<C, N, false, 1>);
-    static_assert(Cf::LDS <= 160 * 1024, "LDS");
-    if (Cf::LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
-        DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "temporal_attention_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
+    // 8 heads: one head per wave, 8 waves (two per SIMD); DIQT_TATTN_W4=1: the first build, 4 waves x 2 heads.  4 heads: 4 waves x 1 head.
+    static const bool w4 = [] { const char* e = getenv("DIQT_TATTN_W4"); return e && e[0] == '1'; }();
     static const int wgs = [] { const char* e = getenv("DIQT_TATTN_WGS"); return e ? atoi(e) : 256; }();
     const int grid = g.nseq < wgs ? g.nseq : wgs;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cf::LDS, s, x, g1, static_cast<const unsigned short*>(wq),
-                       static_cast<const unsigned short*>(wkv), static_cast<const unsigned short*>(wo), g2, nullkv, rel, null_bias, y, g);
-    return check_launch("temporal_attention_h");
+    auto go = [&](auto kern, int threads, int lds) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "temporal_attention_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, x, g1, static_cast<const unsigned short*>(wq),
+                           static_cast<const unsigned short*>(wkv), static_cast<const unsigned short*>(wo), g2, nullkv, rel, null_bias, y, g);
+        return check_launch("temporal_attention_h");
+    };
+    static_assert(TACfg<C, N, 4>::LDS <= 160 * 1024 && TACfg<C, N, 8>::LDS <= 160 * 1024, "LDS");
+    // (C = 128, weights re-read from L2: the 4-wave build measures faster, 604 vs 641 us on 8192 sequences of 64 frames)
+    if (g.h == 8 && !w4 && C != 128)
+        return bf16 ? go(temporal_attn_h_kernel<C, N, true, 1, 8>, 512, TACfg<C, N, 8>::LDS) : go(temporal_attn_h_kernel<C, N, false, 1, 8>, 512, TACfg<C, N, 8>::LDS);
+    if (g.h == 8)
+        return bf16 ? go(temporal_attn_h_kernel<C, N, true, 2, 4>, 256, TACfg<C, N, 4>::LDS) : go(temporal_attn_h_kernel<C, N, false, 2, 4>, 256, TACfg<C, N, 4>::LDS);
+    return bf16 ? go(temporal_attn_h_kernel<C, N, true, 1, 4>, 256, TACfg<C, N, 4>::LDS) : go(temporal_attn_h_kernel<C, N, false, 1, 4>, 256, TACfg<C, N, 4>::LDS);
 }
+
 
 }  // namespace
 }  // namespace diqt

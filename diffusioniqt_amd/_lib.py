@@ -41,7 +41,7 @@ PROTOTYPES = {
     "diqt_reduce_workspace_bytes": (Z, [I, I]),
     "diqt_groupnorm_stats": (I, [P, P, P, P, Z, I, I, I, I, F, P]),
     "diqt_gn_act_fwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
-    "diqt_gn_act_fwd_h": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "diqt_gn_act_fwd_h": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "diqt_gn_act_bwd": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_gn_coef_from_partials": (I, [P, I, I, P, P, P, P, I, P, P, P, I, I, I, F, P]),
     "diqt_gn_coef": (I, [P, P, P, P, P, P, I, P, I, I, I, P]),

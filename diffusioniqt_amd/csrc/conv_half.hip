@@ -780,7 +780,7 @@ extern "C" int diqt_conv3d_fwd_h_stats_blocks(int B, int D, int H, int W, int Ci
                                               int pw, int epd, int eph, int epw, int x_half, int y_half) {
     HalfGeom g;
     if (!half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, x_half ? 2 : 4, y_half ? 2 : 4)) return 0;
-    if ((kd == 1 && kh == 1 && kw == 1) || !x_half || y_half) return 0;          // flattened rows: tiles straddle batch entries
+    if ((kd == 1 && kh == 1 && kw == 1) || !x_half) return 0;          // flattened rows: tiles straddle batch entries
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
     return convh_persistent_takes(g, nwg) ? g.tilesD * g.tilesH * g.tilesW * 8 : 0;
 }
@@ -819,9 +819,10 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
                                   conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, false>,  conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, true>,
                                   conv_fwd_hp_kernel<true, 1, HHREG, HTG, false, false>,  conv_fwd_hp_kernel<true, 1, HHREG, HTG, false, true>,
                                   conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, false>,   conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, true>};
-        DIQT_REQUIRE(!stats || (xh && !yh), DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: statistics are built for x_half = 1, y_half = 0");
-        const KP kp = stats ? (bf16 ? conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, false, true> : conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, false, true>)
-                            : tab[sel];
+        DIQT_REQUIRE(!stats || xh, DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: statistics are built for x_half = 1");
+        const KP kp = !stats ? tab[sel]
+                    : yh ? (bf16 ? conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, true, true> : conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, true, true>)
+                         : (bf16 ? conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, false, true> : conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, false, true>);
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));

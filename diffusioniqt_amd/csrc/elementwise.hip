@@ -204,12 +204,30 @@ __device__ __forceinline__ void gn_store4(float* yb, size_t i, float4 v) {
     }
 }
 
-template <bool VEC, int OUTH = 0>
+// INH: x holds 16-bit values of type OUTH (the 16-bit output of the conv in front, diqt_conv3d_fwd_h_io y_half)
+template <int INH>
+__device__ __forceinline__ float4 gn_load4(const float* xb, size_t i) {
+    if constexpr (INH == 0) {
+        return *reinterpret_cast<const float4*>(xb + i * 4);
+    } else {
+        const uint2 p = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(xb) + i * 4);
+        if constexpr (INH == 1) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 a = __builtin_bit_cast(h2, p.x), c = __builtin_bit_cast(h2, p.y);
+            return make_float4((float)a.x, (float)a.y, (float)c.x, (float)c.y);
+        } else {
+            return make_float4(__builtin_bit_cast(float, p.x << 16), __builtin_bit_cast(float, p.x & 0xffff0000u),
+                               __builtin_bit_cast(float, p.y << 16), __builtin_bit_cast(float, p.y & 0xffff0000u));
+        }
+    }
+}
+
+template <bool VEC, int OUTH = 0, int INH = 0>
 __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          GnCoef k, int rows, int act) {
     const int b = blockIdx.y, C = k.C;
     const size_t per = (size_t)rows * C;
-    const float* xb = x + (size_t)b * per;
+    const float* xb = INH ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * per) : x + (size_t)b * per;
     float* yb = OUTH ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(y) + (size_t)b * per) : y + (size_t)b * per;
     if (VEC) {
         // the host sizes the grid so that (gridDim.x * 1024) % C == 0: a thread keeps its 4 channels for the whole
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
         for (; i + 3 * st < n4; i += 4 * st) {          // 4 loads in flight
             float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xb + (i + u * st) * 4);
+            for (int u = 0; u < 4; ++u) v[u] = gn_load4<INH>(xb, i + u * st);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u].x = act_fwd(A[0] * v[u].x + Bc[0], act);
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
             }
         }
         for (; i < n4; i += st) {
-            float4 v = *reinterpret_cast<const float4*>(xb + i * 4);
+            float4 v = gn_load4<INH>(xb, i);
             v.x = act_fwd(A[0] * v.x + Bc[0], act);
             v.y = act_fwd(A[1] * v.y + Bc[1], act);
             v.z = act_fwd(A[2] * v.z + Bc[2], act);
@@ -1760,9 +1778,10 @@ extern "C" int diqt_gn_act_fwd(const float* x, const float* mean, const float* r
     return check_launch("gn_act_fwd");
 }
 
-extern "C" int diqt_gn_act_fwd_h(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+extern "C" int diqt_gn_act_fwd_h(const void* x_, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                  const float* scale, const float* shift, int cond_stride, void* y_h, int B, int rows, int C, int G,
-                                 int act, int bf16, void* stream) {
+                                 int act, int bf16, int x_half, void* stream) {
+    const float* x = static_cast<const float*>(x_);
     DIQT_REQUIRE(x && mean && rstd && y_h, DIQT_E_ALIGN, "gn_act_fwd_h: null pointer");
     DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_act_fwd_h: bad shape");
     DIQT_REQUIRE((scale == nullptr) == (shift == nullptr), DIQT_E_SHAPE, "gn_act_fwd_h: scale and shift go together");
@@ -1772,8 +1791,13 @@ extern "C" int diqt_gn_act_fwd_h(const float* x, const float* mean, const float*
                  "gn_act_fwd_h: needs C %% 4 == 0 and 16-byte aligned tensors");
     GnCoef k{mean, rstd, gamma, beta, scale, shift, C, G, cond_stride};
     const dim3 grid(gn_grid(per, C, B), B);
-    if (bf16) hipLaunchKernelGGL((gn_act_fwd_kernel<true, 2>), grid, dim3(256), 0, STREAM, x, static_cast<float*>(y_h), k, rows, act);
-    else hipLaunchKernelGGL((gn_act_fwd_kernel<true, 1>), grid, dim3(256), 0, STREAM, x, static_cast<float*>(y_h), k, rows, act);
+    if (x_half) {
+        if (bf16) hipLaunchKernelGGL((gn_act_fwd_kernel<true, 2, 2>), grid, dim3(256), 0, STREAM, x, static_cast<float*>(y_h), k, rows, act);
+        else hipLaunchKernelGGL((gn_act_fwd_kernel<true, 1, 1>), grid, dim3(256), 0, STREAM, x, static_cast<float*>(y_h), k, rows, act);
+    } else {
+        if (bf16) hipLaunchKernelGGL((gn_act_fwd_kernel<true, 2>), grid, dim3(256), 0, STREAM, x, static_cast<float*>(y_h), k, rows, act);
+        else hipLaunchKernelGGL((gn_act_fwd_kernel<true, 1>), grid, dim3(256), 0, STREAM, x, static_cast<float*>(y_h), k, rows, act);
+    }
     return check_launch("gn_act_fwd_h");
 }
 

@@ -141,7 +141,7 @@ class Conv3d(nn.Module):
             nn.init.dirac_(self.temporal_conv.weight.data)
             nn.init.zeros_(self.temporal_conv.bias.data)
 
-    def forward(self, x, ignore_time=False, residual=None, want_stats=False, gn=None):
+    def forward(self, x, ignore_time=False, residual=None, want_stats=False, gn=None, out_half=False):
         """``residual`` is added in the epilogue of the LAST conv of the pair (the caller's ``h + res``), whose per-tile column sums
         (``want_stats``) feed the consumer's GroupNorm.  ``gn`` = (GroupNorm module, scale_shift): x is the RAW GroupNorm input and the
         per-frame conv applies GroupNorm + SiLU while staging it (sampling path, ops.gn_conv3d); returns None when that is not taken."""
@@ -156,7 +156,8 @@ class Conv3d(nn.Module):
                 kt = tc.weight.shape[-1]
                 return ops.conv_pair_nograd_h(x, sc.weight.unsqueeze(2), sc.bias, (0, k // 2, k // 2), tc.weight.unsqueeze(-1).unsqueeze(-1),
                                               tc.bias, (kt - 1, 0, 0), (-(kt - 1), 0, 0), residual,
-                                              gn=(norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps), want_stats=want_stats)
+                                              gn=(norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps), want_stats=want_stats,
+                                              out_half=out_half)
             x = ops.gn_conv3d(x, norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps, sc.weight.unsqueeze(2), sc.bias,
                               (0, k // 2, k // 2), residual if last else None, want_stats=want_stats and last)
             if x is None:
@@ -376,14 +377,17 @@ class Block(nn.Module):
         self.activation = SiLU()
         self.project = Conv3d(dim, dim_out, 3, padding=1)
 
-    def forward(self, x, scale_shift=None, ignore_time=False, residual=None, emit_stats=False, tap=False):
-        """``tap``: also returns an alias of x for its other consumer (the ResnetBlock's residual branch; ops.groupnorm_act)."""
+    def forward(self, x, scale_shift=None, ignore_time=False, residual=None, emit_stats=False, tap=False, out_half=False):
+        """``tap``: also returns an alias of x for its other consumer (the ResnetBlock's residual branch; ops.groupnorm_act).
+        ``out_half`` (sampling under autocast): the output only feeds another Block's GroupNorm and may come back in the operand type."""
         gn = self.groupnorm
         if not torch.is_grad_enabled():
             # sampling: GroupNorm-apply + SiLU inside the per-frame conv's input staging (no elementwise pass); None: shape not taken
-            y = self.project(x, ignore_time=ignore_time, residual=residual, want_stats=emit_stats, gn=(gn, scale_shift))
+            y = self.project(x, ignore_time=ignore_time, residual=residual, want_stats=emit_stats, gn=(gn, scale_shift), out_half=out_half)
             if y is not None:
                 return (y, x) if tap else y
+            if x.dtype != torch.float32:                 # a 16-bit block output whose consumer does not take the 16-bit path after all
+                x = x.float()
         if tap:
             x, alias = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_SILU, gn.eps, tap=True)
             return self.project(x, ignore_time=ignore_time, residual=residual, want_stats=emit_stats), alias
@@ -433,7 +437,7 @@ class ResnetBlock(nn.Module):
                 scale_shift = self.time_mlp(time_emb)
         # block2's GroupNorm statistics come from the epilogue of block1's last conv (unless cross attention rewrites h in between)
         # (the residual branch reads x through block1's alias: its gradient is added inside the GroupNorm backward)
-        h, x = self.block1(x, ignore_time=ignore_time, emit_stats=not exists(self.cross_attn), tap=True)
+        h, x = self.block1(x, ignore_time=ignore_time, emit_stats=not exists(self.cross_attn), tap=True, out_half=not exists(self.cross_attn))
         if exists(self.cross_attn):
             assert exists(cond)
             h = ops.add(self.cross_attn(h, context=cond), h)

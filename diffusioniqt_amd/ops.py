@@ -235,15 +235,19 @@ def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0, x_half=F
 
 
 def _groupnorm_act_h(x, gamma, beta, ss, groups, act, eps, lp):
-    """act(GN(x) * (scale + 1) + shift) stored in the operand type of the 16-bit conv that consumes it (sampling path under autocast)."""
+    """act(GN(x) * (scale + 1) + shift) stored in the operand type of the 16-bit conv that consumes it (sampling path under autocast).
+    x: fp32, or the 16-bit output of a conv of this path (conv_pair_nograd_h(out_half=True): it carries its GroupNorm statistics)."""
     B, C = x.shape[0], x.shape[-1]
     rows = x.numel() // (B * C)
     mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     s = _stream()
     pre = getattr(x, "_diqt_stats", None)
+    x_half = x.dtype != torch.float32
     if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
         _lib.call("diqt_groupnorm_stats_from_partials", pre.partials, mean, rstd, B, pre.nblk, rows, C, groups, float(eps), s)
+    elif x_half:
+        raise RuntimeError("a 16-bit block output must carry the GroupNorm statistics of the conv that wrote it")
     else:
         ws, n = _reduce_ws(B, C, x.device)
         _lib.call("diqt_groupnorm_stats", x, mean, rstd, ws, n, B, rows, C, groups, float(eps), s)
@@ -257,11 +261,11 @@ def _groupnorm_act_h(x, gamma, beta, ss, groups, act, eps, lp):
         assert ss.shape == (B, 2 * C) and ss.stride(1) == 1 and ss.is_cuda and ss.dtype == torch.float32
         scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, ss.stride(0)
     y = torch.empty(x.shape, dtype=torch.bfloat16 if lp == 1 else torch.float16, device=x.device)
-    _lib.call("diqt_gn_act_fwd_h", x, mean, rstd, gamma, beta, scale, shift, cs, y, B, rows, C, groups, act, lp, s)
+    _lib.call("diqt_gn_act_fwd_h", x, mean, rstd, gamma, beta, scale, shift, cs, y, B, rows, C, groups, act, lp, int(x_half), s)
     return y
 
 
-def conv_pair_nograd_h(x, w1, b1, pad1, w2, b2, pad2, epad2, residual=None, gn=None, want_stats=False):
+def conv_pair_nograd_h(x, w1, b1, pad1, w2, b2, pad2, epad2, residual=None, gn=None, want_stats=False, out_half=False):
     """Two convs in a row on the sampling path under autocast -- the per-frame and the temporal conv of a pseudo-3D block -- with
     the tensor between them in the operand type (it holds exactly the values the fp32 tensor would: the first conv's result is rounded
     to that type either way).  ``gn`` = (gamma, beta, scale_shift, groups, act, eps): x is the raw input of the block's GroupNorm, whose
@@ -270,7 +274,9 @@ def conv_pair_nograd_h(x, w1, b1, pad1, w2, b2, pad2, epad2, residual=None, gn=N
     lp = lp_mode()
     if lp is None or torch.is_grad_enabled():
         return None
-    _chk(x, w1, b1, w2, b2, residual)
+    x_is_half = x.dtype != torch.float32                  # the 16-bit output of the previous block's pair (out_half)
+    assert not x_is_half or gn is not None
+    _chk(None if x_is_half else x, w1, b1, w2, b2, residual)
     B, D, H, W, Cin = x.shape
     Cm, C2 = w1.shape[0], w2.shape[0]
     k1, k2 = tuple(w1.shape[2:]), tuple(w2.shape[2:])
@@ -287,10 +293,16 @@ def conv_pair_nograd_h(x, w1, b1, pad1, w2, b2, pad2, epad2, residual=None, gn=N
         _chk(gamma, beta, ss.base if isinstance(ss, SSView) else None)
         xin = _groupnorm_act_h(x, gamma, beta, ss, groups, act, eps, lp)
     mid = _conv_fwd_half(xin, w1, b1, None, pad1, (0, 0, 0), lp, x_half=xh, y_half=True)
+    # out_half: the pair's output only feeds the next block's GroupNorm (ResnetBlock: block1 -> block2) -- it is stored in the operand type
+    # too (no residual, so it holds fp16-exact values) PROVIDED the statistics that GroupNorm needs come along
+    out_half = bool(out_half and want_stats and residual is None
+                    and _lib.query("diqt_conv3d_fwd_h_io16_supported", B, D1, H1, W1, Cm, C2, *k2, *pad2, *epad2, 1, 1)
+                    and _lib.query("diqt_conv3d_fwd_h_stats_blocks", B, D1, H1, W1, Cm, C2, *k2, *pad2, *epad2, 1, 1) > 0)
     holder = [] if want_stats else None
-    y = _conv_fwd_half(mid, w2, b2, residual, pad2, epad2, lp, x_half=True, stats_out=holder)
+    y = _conv_fwd_half(mid, w2, b2, residual, pad2, epad2, lp, x_half=True, y_half=out_half, stats_out=holder)
     if holder:
         y._diqt_stats = holder[0]           # consumed by the next GroupNorm on this exact tensor
+    assert not out_half or holder
     return y
 
 

@@ -218,9 +218,11 @@ int diqt_gn_act_fwd(const float* x, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, const float* scale, const float* shift,
                     int cond_stride, float* y, int B, int rows_per_batch, int C, int G, int act, void* stream);
 /* The same with y stored in fp16 (bf16 when `bf16`): under autocast the consumer is a 16-bit-operand conv (diqt_conv3d_fwd_h_io,
- * x_half) that would round these values to that type while staging them.  Needs C % 4 == 0 and 16-byte aligned tensors.          */
-int diqt_gn_act_fwd_h(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale,
-                      const float* shift, int cond_stride, void* y_h, int B, int rows, int C, int G, int act, int bf16, void* stream);
+ * x_half) that would round these values to that type while staging them.  x_half: x is itself the 16-bit output of such a conv
+ * (y_half; its GroupNorm statistics come from that conv's `stats`).  Needs C % 4 == 0 and 16-byte aligned tensors.               */
+int diqt_gn_act_fwd_h(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale,
+                      const float* shift, int cond_stride, void* y_h, int B, int rows, int C, int G, int act, int bf16, int x_half,
+                      void* stream);
 
 /* dx, dgamma[C], dbeta[C], dscale[B][C], dshift[B][C] (last two NULL when scale/shift are).
  * `workspace` holds per-(b,c) partial sums: diqt_reduce_workspace_bytes(B,C).                         */

@@ -419,3 +419,32 @@ def test_block_with_16_bit_groupnorm_output_is_bit_identical(mode, with_ss):
     finally:
         _lib.query("diqt_set_convh_workgroups", prev)
     assert torch.equal(y, ref), (y - ref).abs().max()
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_resnet_block_with_16_bit_tensors_between_its_blocks_is_bit_identical(mode):
+    """Sampling under autocast: block1's output (temporal conv, no residual) only feeds block2's GroupNorm, so it is stored in the operand
+    type together with its GroupNorm statistics (diqt_conv3d_fwd_h_io y_half + stats, diqt_gn_act_fwd_h x_half).  The values are the ones
+    the fp32 tensor holds: the ResnetBlock's output must be bit-identical to the run with an fp32 tensor in between."""
+    from diffusioniqt_amd import ops, _lib
+    from diffusioniqt_amd.imagen_video import ResnetBlock
+    torch.manual_seed(4)
+    blk = ResnetBlock(32, 64, time_cond_dim=48, groups=8, use_gca=True).to(DEV).eval()
+    x = torch.randn(2, 8, 16, 16, 32, device=DEV)
+    t = torch.randn(2, 48, device=DEV)
+    seen = []
+    real_call, real_pair = _lib.call, ops.conv_pair_nograd_h
+    spy = lambda name, *a: (seen.append((name, a)), real_call(name, *a))[1]
+    prev = _lib.query("diqt_set_convh_workgroups", 2)
+    try:
+        _lib.call = spy
+        with torch.no_grad(), torch.autocast('cuda', dtype=LP[mode]):
+            y = blk(x, t)
+            halves = [a for n, a in seen if n == "diqt_gn_act_fwd_h"]
+            assert len(halves) == 2 and [a[-2] for a in halves] == [0, 1]          # block1 reads fp32, block2 reads block1's 16-bit output
+            ops.conv_pair_nograd_h = lambda *a, **k: real_pair(*a, **{**k, 'out_half': False})
+            ref = blk(x, t)
+    finally:
+        _lib.call, ops.conv_pair_nograd_h = real_call, real_pair
+        _lib.query("diqt_set_convh_workgroups", prev)
+    assert torch.equal(y, ref), (y - ref).abs().max()

@@ -294,14 +294,17 @@ __global__ __launch_bounds__(256) void cast_to_h_kernel(const float* __restrict_
 // HASREL: a relative-position bias table is given.  A template parameter, not a test of the pointer: hipcc hoists the 32 clamped table
 // indices of a tile (min / max / 64-bit multiply-add each) above the `plain tile` branch, where they cost ~190 vector instructions per
 // tile and wave even when there is no table (the joint space-time attention at the middle of the U-Net: 257 tiles per query block)
-template <int ND, bool BF, bool HASREL>   // dim_head = 32 * ND
-__global__ __launch_bounds__(512, 1) void mqa_flash_fwd_h_kernel(const float* __restrict__ q, const unsigned short* __restrict__ kv,
+// NWV waves per workgroup: 8 (256 query rows; K|V streamed once per 256 rows) or 4 with TWO workgroups per CU -- the two waves of a SIMD then
+// belong to different workgroups and are not held in the same phase by the tile barrier, so one's soft-max can run under the other's MFMAs
+template <int ND, bool BF, bool HASREL, int NWV = 8>   // dim_head = 32 * ND
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void mqa_flash_fwd_h_kernel(const float* __restrict__ q, const unsigned short* __restrict__ kv,
                                                                  const float* __restrict__ rel_, const float* __restrict__ null_bias,
                                                                  float* __restrict__ out, int n, int h, int E, int ns, int causal,
                                                                  float scale, int round_out) {
-    constexpr int D = 32 * ND, KROWB = 2 * D + 16, VROWB = 2 * HKT + 16, NPF = HKT * (2 * D / 8) / 512;   // 16-byte pieces per thread
+    constexpr int NTH = 64 * NWV, AQW = 32 * NWV;
+    constexpr int D = 32 * ND, KROWB = 2 * D + 16, VROWB = 2 * HKT + 16, NPF = HKT * (2 * D / 8) / NTH;   // 16-byte pieces per thread
     const float* __restrict__ rel = HASREL ? rel_ : nullptr;
-    static_assert(NPF >= 1, "tile too small for 512 threads");
+    static_assert(NPF >= 1, "tile too small for the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char Ksm[2][HKT * KROWB];    // [buffer][key][d] 16-bit, padded rows
     // V ROW-MAJOR like K ([buffer][key][d]); the V^T operand of the second product comes out of `ds_read_b64_tr_b16`, which hands lane i
     // column i of a 4-key x 16-channel block.  (The first version stored V transposed with eight 2-byte LDS writes per piece: rows 8
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void mqa_flash_fwd_h_kernel(const float* __
     const int M = E + ns, R = n * h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hf = lane >> 5;
-    const int r = blockIdx.x * AQH + wave * 32 + l31;
+    const int r = blockIdx.x * AQW + wave * 32 + l31;
     const bool rvalid = r < R;
     const int rc = rvalid ? r : R - 1;
     const int qi = rc / h, qh = rc % h;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(512, 1) void mqa_flash_fwd_h_kernel(const float* __
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
-            const int e = u * 512 + tid;
+            const int e = u * NTH + tid;
             const int key = e / (2 * D / 8), c8 = (e % (2 * D / 8)) * 8;
             const int j = t * HKT + key;
             const u32x4a v = *reinterpret_cast<const u32x4a*>(kvg + (size_t)min(j, M - 1) * 2 * D + c8);
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(512, 1) void mqa_flash_fwd_h_kernel(const float* __
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
-            const int e = u * 512 + tid;
+            const int e = u * NTH + tid;
             const int key = e / (2 * D / 8), c8 = (e % (2 * D / 8)) * 8;
             if (c8 < D) *reinterpret_cast<u32x4a*>(&Ksm[buf][key * KROWB + c8 * 2]) = pre[u];
             else *reinterpret_cast<u32x4a*>(&Vsm[buf][key * VRB + (c8 - D) * 2]) = pre[u];
@@ -571,13 +574,18 @@ extern "C" int diqt_mqa_attention_fwd_h(const float* q, const void* kv, const fl
     DIQT_REQUIRE(!null_bias || n_extra >= 1, DIQT_E_SHAPE, "mqa_attention_fwd_h: null bias without a null key");
     DIQT_REQUIRE(aligned16(q) && aligned16(kv) && aligned16(out), DIQT_E_ALIGN, "mqa_attention_fwd_h: pointers must be 16-byte aligned");
     DIQT_REQUIRE(G <= 65535, DIQT_E_SHAPE, "mqa_attention_fwd_h: G > 65535");
-    const dim3 grid((unsigned)(((long long)n * h + AQH - 1) / AQH), G);
+    // long un-biased sequences (the joint space-time attention): 4-wave workgroups, two per CU (see the kernel); DIQT_ATTN_H_W8=1: always 8 waves
+    static const bool w8 = [] { const char* e = getenv("DIQT_ATTN_H_W8"); return e && e[0] == '1'; }();
+    const bool four = !w8 && !rel && d == 64 && (long long)n * h >= 4096;
+    const int rowsPerWg = four ? 128 : AQH;
+    const dim3 grid((unsigned)(((long long)n * h + rowsPerWg - 1) / rowsPerWg), G);
     void (*k)(const float*, const unsigned short*, const float*, const float*, float*, int, int, int, int, int, float, int) =
-        rel ? (d == 64 ? (bf16 ? mqa_flash_fwd_h_kernel<2, true, true> : mqa_flash_fwd_h_kernel<2, false, true>)
-                       : (bf16 ? mqa_flash_fwd_h_kernel<1, true, true> : mqa_flash_fwd_h_kernel<1, false, true>))
-            : (d == 64 ? (bf16 ? mqa_flash_fwd_h_kernel<2, true, false> : mqa_flash_fwd_h_kernel<2, false, false>)
-                       : (bf16 ? mqa_flash_fwd_h_kernel<1, true, false> : mqa_flash_fwd_h_kernel<1, false, false>));
-    hipLaunchKernelGGL(k, grid, dim3(512), 0, (hipStream_t)stream, q, static_cast<const unsigned short*>(kv), rel, null_bias, out, n, h,
+        four ? (bf16 ? mqa_flash_fwd_h_kernel<2, true, false, 4> : mqa_flash_fwd_h_kernel<2, false, false, 4>)
+        : rel ? (d == 64 ? (bf16 ? mqa_flash_fwd_h_kernel<2, true, true> : mqa_flash_fwd_h_kernel<2, false, true>)
+                         : (bf16 ? mqa_flash_fwd_h_kernel<1, true, true> : mqa_flash_fwd_h_kernel<1, false, true>))
+              : (d == 64 ? (bf16 ? mqa_flash_fwd_h_kernel<2, true, false> : mqa_flash_fwd_h_kernel<2, false, false>)
+                         : (bf16 ? mqa_flash_fwd_h_kernel<1, true, false> : mqa_flash_fwd_h_kernel<1, false, false>));
+    hipLaunchKernelGGL(k, grid, dim3(four ? 256 : 512), 0, (hipStream_t)stream, q, static_cast<const unsigned short*>(kv), rel, null_bias, out, n, h,
                        n_extra, n_self, causal, scale, round_out ? 1 : 0);
     return check_launch("mqa_attention_fwd_h");
 }

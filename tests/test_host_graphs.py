@@ -1,0 +1,37 @@
+"""Host logic of the hipGraph cache (diffusioniqt_amd/graphs.py) that needs no GPU: keys, the eager gates, entry bookkeeping."""
+import torch
+
+from diffusioniqt_amd import graphs
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(3))
+        self.calls = 0
+
+    def forward(self, x, t, flag=None):
+        self.calls += 1
+        return x * self.w.sum() + t
+
+
+def test_cpu_tensors_and_grad_mode_stay_eager():
+    net, cache = _Net(), graphs.GraphCache()
+    x, t = torch.ones(2, 3), torch.zeros(2, 1)
+    with torch.no_grad():
+        for _ in range(5):
+            y = cache.run(net, net.forward, (x, t), dict(flag=None))
+    assert net.calls == 5 and cache.replays == 0 and not cache.entries          # CPU tensors: never keyed, never captured
+    assert torch.equal(y, x * 3)
+    y = cache.run(net, net.forward, (x, t), {})                                  # autograd on: eager too
+    assert y.requires_grad and net.calls == 6
+
+
+def test_signature_distinguishes_shapes_dtypes_and_plain_values():
+    a, b = torch.zeros(2, 3), torch.zeros(2, 4)
+    assert graphs._sig(a) != graphs._sig(b) and graphs._sig(a) == graphs._sig(torch.ones(2, 3))
+    assert graphs._sig(a) != graphs._sig(a.double())
+    assert graphs._sig((a, 1.5, None)) == graphs._sig((torch.ones(2, 3), 1.5, None))
+    assert graphs._sig(0.5) == 0.5 and graphs._sig("x") == "x"
+    o = object()
+    assert graphs._sig(o) == ("O", id(o))

@@ -46,6 +46,8 @@ struct HalfGeom {
     int HD, HH, HWd;
     int TG, nGroups;             // taps per weight group, groups per chunk
     int roundOut;                // 1: round the result to the operand type before the fp32 store (autocast semantics)
+    int NS, realChunks;          // persistent kernel, pointwise filters: NS > 1 consecutive 32-channel chunks are staged per step and walked
+                                 // like taps (nChunks then counts steps of NS chunks, realChunks the 32-channel chunks)
     unsigned xBytes, yBytes;
     unsigned long long* dbg;     // diagnostic cycle stamps per workgroup (DIQT_CONVH_DBG=1), NULL in production
 };
@@ -353,7 +355,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const int HV = g.HD * g.HH * g.HWd;
     unsigned char* halo = hsm;                                         // [HV][80 B]
-    unsigned char* wbuf = hsm + (size_t)HV * HROWB;                    // [2][TG][64][80 B]
+    const int sliceBytes = HV * HROWB;                                 // one 32-channel halo image
+    unsigned char* wbuf = hsm + (size_t)g.NS * sliceBytes;             // [2][TG][64][80 B]
     const int wbufBytes = g.TG * HNT * HROWB;
     int* out_off = reinterpret_cast<int*>(wbuf + 2 * (size_t)wbufBytes);   // [2][256]: by unit parity
 
@@ -364,7 +367,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     constexpr int PPR = XH ? 4 : 8, PSH = XH ? 2 : 3;      // 16-byte pieces per 32-channel halo row
     constexpr unsigned XE = XH ? 2u : 4u, YE = YH ? 2u : 4u;   // bytes per element
     const int hq = tid & (PPR - 1);
-    const int nHalo = HV * PPR;
+    const int nSlice = HV * PPR;                    // pieces of one 32-channel image
+    const int nHalo = nSlice * g.NS;
 
     const int uBegin = blockIdx.x * perWg, uEnd = min(uBegin + perWg, nUnits);
     if (uBegin >= uEnd) return;
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     unsigned pc[NHR], prel[NHR];
 #pragma unroll
     for (int u = 0; u < NHR; ++u) {
-        const int idx = u * 512 + tid, hv = min(idx >> PSH, HV - 1);
+        const int idx = u * 512 + tid, hv = min((idx >= nSlice ? idx - nSlice : idx) >> PSH, HV - 1);      // NS <= 2
         const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
         pc[u] = idx < nHalo ? ((unsigned)hz | ((unsigned)hy << 10) | ((unsigned)hx << 20)) : 0x3fffffffu;     // past the tile: never in range
         prel[u] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin) * XE;
@@ -448,22 +452,26 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
 
     u32x4 hr[NHR];
     auto halo_load = [&](int ci0) {
-        const unsigned coff = (ci0 + hq * (32 / PPR) < g.Cin) ? (unsigned)(ci0 + hq * (32 / PPR)) * XE : HBUF_OOB_C;
 #pragma unroll
-        for (int u = 0; u < NHR; ++u) hr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, srcv[u] + coff, 0, 0);
+        for (int u = 0; u < NHR; ++u) {
+            const int ch = ci0 + (u * 512 + tid >= nSlice ? HCK : 0) + hq * (32 / PPR);   // second slice of a pointwise step: the next 32 channels
+            const unsigned coff = ch < g.Cin ? (unsigned)ch * XE : HBUF_OOB_C;
+            hr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, srcv[u] + coff, 0, 0);
+        }
     };
     auto halo_store = [&]() {
 #pragma unroll
         for (int u = 0; u < NHR; ++u) {
             const int idx = u * 512 + tid;
             if (idx < nHalo) {
+                unsigned char* img = idx >= nSlice ? halo + sliceBytes + ((idx - nSlice) >> PSH) * HROWB : halo + (idx >> PSH) * HROWB;
                 if constexpr (XH) {
-                    *reinterpret_cast<u32x4*>(halo + (idx >> PSH) * HROWB + hq * 16) = hr[u];
+                    *reinterpret_cast<u32x4*>(img + hq * 16) = hr[u];
                 } else {
                     u32x2 p;
                     p.x = pack2<BF>(asf(hr[u].x), asf(hr[u].y));
                     p.y = pack2<BF>(asf(hr[u].z), asf(hr[u].w));
-                    *reinterpret_cast<u32x2*>(halo + (idx >> PSH) * HROWB + hq * 8) = p;
+                    *reinterpret_cast<u32x2*>(img + hq * 8) = p;
                 }
             }
         }
@@ -503,10 +511,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     Unit cur = decode(uBegin);
     write_out_table(cur, 0);
     unit_sources(cur);
+    const bool pww = g.NS > 1;                      // pointwise filter: a step's "taps" are NS consecutive channel chunks
+    const int firstTaps = pww ? min(g.NS, g.realChunks) : min(g.TG, T);
     halo_load(0);
-    load_wgroup(0, 0, min(g.TG, T), cur.n0);
+    load_wgroup(0, 0, firstTaps, cur.n0);
     halo_store();
-    store_wgroup(0, min(g.TG, T));
+    store_wgroup(0, firstTaps);
     __syncthreads();
 
     int step = 0;
@@ -519,21 +529,23 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
         }
         for (int chunk = 0; chunk < g.nChunks; ++chunk) {
             for (int grp = 0; grp < g.nGroups; ++grp, ++step) {
-                const int t0 = grp * g.TG, nTap = min(g.TG, T - t0);
+                const int t0 = grp * g.TG, nTap = pww ? min(g.NS, g.realChunks - chunk * g.NS) : min(g.TG, T - t0);
                 const bool lastGrp = grp + 1 == g.nGroups, lastStep = lastGrp && chunk + 1 == g.nChunks;
                 const bool more = !lastStep || hasNext;
-                const int nchunk = lastStep ? 0 : (lastGrp ? chunk + 1 : chunk), nt0 = lastGrp ? 0 : t0 + g.TG, nn = min(g.TG, T - nt0);
-                if (more) load_wgroup(nchunk, nt0, nn, lastStep ? nxt.n0 : cur.n0);
+                const int nchunk = lastStep ? 0 : (lastGrp ? chunk + 1 : chunk), nt0 = lastGrp ? 0 : t0 + g.TG;
+                const int nn = pww ? min(g.NS, g.realChunks - nchunk * g.NS) : min(g.TG, T - nt0);
+                if (more) load_wgroup(nchunk * g.NS, nt0, nn, lastStep ? nxt.n0 : cur.n0);
                 const bool pref = lastGrp && more;
                 if (pref) {
                     if (lastStep) unit_sources(nxt);
-                    halo_load(lastStep ? 0 : (chunk + 1) * HCK);
+                    halo_load(lastStep ? 0 : (chunk + 1) * HCK * g.NS);
                 }
                 const unsigned char* wcur = wbuf + (step & 1) * wbufBytes + b_base;
                 const unsigned char* ap = halo + a_base;
                 int kx = t0 % g.kw, ky = (t0 / g.kw) % g.kh, kz = t0 / (g.kw * g.kh);
                 int toff = ((kz * g.HH + ky) * g.HWd + kx) * HROWB;
                 auto next_tap = [&]() {
+                    if (pww) { toff += sliceBytes; return; }
                     toff += HROWB;
                     if (++kx == g.kw) {
                         kx = 0; toff += (g.HWd - g.kw) * HROWB;
@@ -647,7 +659,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
 static size_t half_lds_bytes(const HalfGeom& g) {
     const size_t HV = (size_t)g.HD * g.HH * g.HWd;
     const size_t tables = (HMT + HV) > 2 * HMT ? (HMT + HV) : 2 * HMT;      // one-unit kernel: out_off + halo_src; persistent: out_off x 2
-    return HV * HROWB + 2 * (size_t)g.TG * HNT * HROWB + tables * sizeof(int);
+    return (size_t)g.NS * HV * HROWB + 2 * (size_t)g.TG * HNT * HROWB + tables * sizeof(int);
 }
 
 static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
@@ -671,6 +683,7 @@ static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout
     g.nNt = hcdiv(Cout, HNT); g.CoutPad = g.nNt * HNT; g.nChunks = hcdiv(Cin, HCK);
     g.roundOut = 1;
     g.dbg = nullptr;
+    g.NS = 1; g.realChunks = g.nChunks;
     static const int cand[][3] = {{4, 8, 8}, {8, 8, 4}, {8, 4, 8}, {2, 8, 16}, {2, 16, 8}, {1, 16, 16}, {16, 4, 4}, {4, 4, 16}, {4, 16, 4},
                                   {16, 16, 1}, {16, 1, 16}, {32, 4, 2}, {64, 2, 2}, {256, 1, 1}, {1, 1, 256}, {1, 256, 1}, {1, 8, 32},
                                   {1, 32, 8}, {8, 32, 1}, {32, 8, 1}, {1, 4, 64}, {1, 2, 128}, {128, 2, 1}, {128, 1, 2}};
@@ -800,7 +813,7 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
         if (!g_hdbg) DIQT_REQUIRE(hipMalloc(&g_hdbg, (size_t)65536 * 8 * sizeof(unsigned long long)) == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: debug buffer");
         g.dbg = g_hdbg; g_hdbg_n = nwg;
     }
-    const size_t lds = half_lds_bytes(g);
+    size_t lds = half_lds_bytes(g);
     const int HV = g.HD * g.HH * g.HWd;
     static const bool nopref = [] { const char* e = getenv("DIQT_CONVH_NOPREF"); return e && e[0] == '1'; }();
     const bool pref = !nopref && HV * 8 <= 512 * HHREG;
@@ -813,6 +826,13 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
                          "conv3d_fwd_h_io: 16-bit tensors need Cin, Cout %% 8 == 0; a 16-bit output needs round_out and no residual");
         }
         DIQT_REQUIRE(!stats || !(kd == 1 && kh == 1 && kw == 1), DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: no statistics from a 1x1x1 conv");
+        static const bool nowide = [] { const char* e = getenv("DIQT_CONVH_NOWIDE"); return e && e[0] == '1'; }();
+        if (kd * kh * kw == 1 && g.nChunks >= 2 && !nowide) {
+            // pointwise: 4 MFMAs of a wave per 32-channel chunk and two barriers around them -- stage TWO chunks per step and walk them like
+            // taps (their weight panels are consecutive in the packed layout [chunk][tap = 1][co][32])
+            g.NS = 2; g.realChunks = g.nChunks; g.nChunks = (g.realChunks + 1) / 2; g.TG = 2; g.nGroups = 1;
+        }
+        lds = half_lds_bytes(g);
         typedef void (*KP)(const float*, const unsigned short*, const float*, const float*, float*, HalfGeom, int, int, float*);
         const int sel = (bf16 ? 4 : 0) + (xh ? 2 : 0) + (yh ? 1 : 0);
         static const KP tab[8] = {conv_fwd_hp_kernel<false, 1, HHREG, HTG, false, false>, conv_fwd_hp_kernel<false, 1, HHREG, HTG, false, true>,

@@ -130,6 +130,8 @@ PROTOTYPES = {
     "diqt_mqa_attention_bwd_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
     "diqt_mqa_attention_bwd": (I, [P] * 11 + [P, Z, I, I, I, I, I, I, I, F, P]),
     "diqt_weighted_colsum": (I, [P, P, P, P, Z, I, I, I, P]),
+    "diqt_softmax_pool_supported": (I, [I, I, I]),
+    "diqt_softmax_pool": (I, [P, P, P, P, Z, I, I, I, P]),
     "diqt_patch_gather": (I, [P, P, P, P, I, I, I, I, I, F, F, P]),
     "diqt_patch_scatter": (I, [P, P, P, P, I, I, I, I, I, P]),
     "diqt_background_reset": (I, [P, P, Z, F, F, F, P]),

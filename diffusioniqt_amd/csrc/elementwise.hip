@@ -95,6 +95,105 @@ static inline int red_nblk(int rows) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// GlobalContext pooling in ONE pass over x (imagen_video.py:957-982, sampling path):
+//   pooled[b][c] = sum_n softmax_n(x[b][n][:] . w)[n] * x[b][n][c]
+// The three-kernel form (to_k conv, soft-max over all positions, weighted column sum) reads x twice and round-trips the logits; here
+// every row is read once: its logit is a dot product reduced over the C/4 lanes that hold the row, and the weighted sum is kept
+// online (running maximum m, normaliser l, sums acc: rescaled by exp(m - m') when the maximum moves), per row group, per workgroup
+// (LDS), then over the workgroups of a batch entry by gc_pool_final_kernel -- all in a fixed order.  The conv's bias shifts every logit
+// alike and drops out of the soft-max.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gc_pool_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ partial,
+                                                      int rows, int C) {
+    __shared__ float4 shA[256];
+    __shared__ float shM[64], shL[64];
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int rowsPer = (rows + nblk - 1) / nblk;
+    const int r0 = blk * rowsPer;
+    const int r1 = min(r0 + rowsPer, rows);
+    const int tpr = C >> 2, rpar = 256 / tpr;                  // lanes per row (16, 32 or 64: inside one wave), rows in flight
+    const int rr = threadIdx.x / tpr, cq = threadIdx.x % tpr;
+    const float4 wv = *reinterpret_cast<const float4*>(w + cq * 4);
+    const float* xb = x + (size_t)b * rows * C + cq * 4;
+    float m = -INFINITY, l = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto row_dot = [&](const float4& v) {
+        float d = v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+        for (int o = 1; o < tpr; o <<= 1) d += __shfl_xor(d, o, 64);
+        return d;
+    };
+    auto take = [&](const float4& v, float sc) {
+        const float mn = fmaxf(m, sc);
+        const float f = __expf(m - mn), e = __expf(sc - mn);       // m = -inf on the first row: f = 0
+        acc.x = acc.x * f + e * v.x; acc.y = acc.y * f + e * v.y; acc.z = acc.z * f + e * v.z; acc.w = acc.w * f + e * v.w;
+        l = l * f + e;
+        m = mn;
+    };
+    int r = r0 + rr;
+    for (; r + 3 * rpar < r1; r += 4 * rpar) {                 // 4 independent 16-byte loads in flight per lane
+        float4 v[4];
+        float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xb + (size_t)(r + u * rpar) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sc[u] = row_dot(v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) take(v[u], sc[u]);
+    }
+    for (; r < r1; r += rpar) {                                // (a row group's lanes leave the loop together: r depends on rr only)
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)r * C);
+        take(v, row_dot(v));
+    }
+    shA[threadIdx.x] = acc;
+    if (cq == 0) { shM[rr] = m; shL[rr] = l; }
+    __syncthreads();
+    if (threadIdx.x < tpr) {
+        float M = -INFINITY;
+        for (int k = 0; k < rpar; ++k) M = fmaxf(M, shM[k]);
+        float L = 0.f;
+        float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < rpar; ++k) {
+            const float f = shM[k] == -INFINITY ? 0.f : __expf(shM[k] - M);
+            const float4 t = shA[k * tpr + threadIdx.x];
+            L += shL[k] * f;
+            A.x += t.x * f; A.y += t.y * f; A.z += t.z * f; A.w += t.w * f;
+        }
+        float* dst = partial + ((size_t)b * nblk + blk) * (C + 4);
+        if (threadIdx.x == 0) { dst[0] = M; dst[1] = L; }
+        *reinterpret_cast<float4*>(dst + 4 + threadIdx.x * 4) = A;
+    }
+}
+__global__ __launch_bounds__(256) void gc_pool_final_kernel(const float* __restrict__ partial, float* __restrict__ pooled, int nblk, int C) {
+    // nblk <= 256 partials (m, l, acc[C]) of one batch entry: thread k scales partial k, then thread c sums channel c over k in order
+    __shared__ float f[256], red[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* p = partial + (size_t)b * nblk * (C + 4);
+    const float mk = t < nblk ? p[(size_t)t * (C + 4)] : -INFINITY;
+    red[t] = mk;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+        __syncthreads();
+    }
+    const float M = red[0];
+    __syncthreads();
+    const float fk = mk == -INFINITY ? 0.f : __expf(mk - M);
+    f[t] = fk;
+    red[t] = t < nblk ? p[(size_t)t * (C + 4) + 1] * fk : 0.f;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {                  // fixed tree: deterministic
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    const float L = red[0];
+    for (int c = t; c < C; c += 256) {
+        float a = 0.f;
+        for (int k = 0; k < nblk; ++k) a += p[(size_t)k * (C + 4) + 4 + c] * f[k];
+        pooled[(size_t)b * C + c] = a / L;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // GroupNorm statistics
 // ---------------------------------------------------------------------------------------------
 struct MomentsF {
@@ -1655,6 +1754,26 @@ using namespace diqt;
 extern "C" size_t diqt_reduce_workspace_bytes(int B, int C) {
     if (B <= 0 || C <= 0) return 0;
     return ((size_t)B * RED_NBLK * 2 * C + (size_t)2 * B * C + (size_t)2 * B * C + 64) * sizeof(float);
+}
+
+// pooled[b][c] = sum_n softmax_n(x[b][n][:] . w)[n] x[b][n][c]; C in {64, 128, 256}; workspace: diqt_reduce_workspace_bytes(B, C)
+extern "C" int diqt_softmax_pool_supported(int B, int rows, int C) {
+    static const bool off = [] { const char* e = getenv("DIQT_NO_GCPOOL"); return e && e[0] == '1'; }();
+    return !off && B > 0 && rows > 0 && (C == 64 || C == 128 || C == 256) ? 1 : 0;
+}
+extern "C" int diqt_softmax_pool(const float* x, const float* w, float* pooled, void* workspace, size_t workspace_bytes, int B, int rows,
+                                 int C, void* stream) {
+    DIQT_REQUIRE(x && w && pooled && workspace, DIQT_E_ALIGN, "softmax_pool: null pointer");
+    DIQT_REQUIRE(diqt_softmax_pool_supported(B, rows, C), DIQT_E_UNSUPPORTED, "softmax_pool: C must be 64, 128 or 256 (got %d)", C);
+    DIQT_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace), DIQT_E_ALIGN, "softmax_pool: pointers must be 16-byte aligned");
+    DIQT_REQUIRE(workspace_bytes >= diqt_reduce_workspace_bytes(B, C), DIQT_E_WORKSPACE, "softmax_pool: workspace too small");
+    const int nblk = red_nblk(rows);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(gc_pool_kernel, dim3(nblk, B), dim3(256), 0, STREAM, x, w, partial, rows, C);
+    int rc = check_launch("softmax_pool/partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gc_pool_final_kernel, dim3(B), dim3(256), 0, STREAM, partial, pooled, nblk, C);
+    return check_launch("softmax_pool/final");
 }
 
 static bool vec_ok(const void* a, const void* b, const void* c, size_t per_batch_elems, int C) {

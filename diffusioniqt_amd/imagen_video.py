@@ -407,6 +407,9 @@ class GlobalContext(nn.Module):
     def forward(self, x):
         B, C = x.shape[0], x.shape[-1]
         n = x.numel() // (B * C)
+        pooled = ops.softmax_pool_nograd(x.reshape(B, n, C), self.to_k.weight.reshape(C))      # sampling: to_k, soft-max and pooling in ONE pass
+        if pooled is not None:
+            return self.net(pooled.reshape(B, 1, 1, 1, C)).reshape(B, -1)
         ctx = self.to_k(x).reshape(B, n)
         p = ops.softmax(ctx, dim=-1)                                              # over all (f h w) positions
         pooled = ops.weighted_pool(p, x.reshape(B, n, C))                         # [B, C] = softmax(ctx) . x

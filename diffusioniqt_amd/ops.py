@@ -1412,6 +1412,22 @@ class _WeightedPoolFn(Function):
         return dw, dx
 
 
+def softmax_pool_nograd(x, w):
+    """GlobalContext pooling in one pass (sampling path): x[B, n, C], w[C] -> pooled[B, C] = sum_n softmax_n(x . w)[n] x[n]; None when
+    the shape is not taken or autograd is recording."""
+    if torch.is_grad_enabled():
+        return None
+    B, n, C = x.shape
+    if not _lib.query("diqt_softmax_pool_supported", B, n, C):
+        return None
+    x, w = x.contiguous(), w.contiguous()
+    _chk(x, w)
+    pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    ws, nb = _reduce_ws(B, C, x.device)
+    _lib.call("diqt_softmax_pool", x, w, pooled, ws, nb, B, n, C, _stream())
+    return pooled
+
+
 def weighted_pool(w, x):
     """w: [B, n] weights, x: [B, n, C] -> [B, C]"""
     return _WeightedPoolFn.apply(w.contiguous(), x.contiguous())

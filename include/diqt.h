@@ -337,6 +337,12 @@ int diqt_learned_sinu_bwd(const float* t, const float* w, const float* dout, flo
 /* pooled[b][c] = mean over rows_per_batch of x[b][.][c]  (AdaptiveAvgPool3d(1) :620,630) */
 int diqt_channel_mean(const float* x, float* pooled, void* workspace, size_t workspace_bytes,
                       int B, int rows_per_batch, int C, void* stream);
+/* The whole pooling of GlobalContext in one pass over x (sampling path): pooled[b][c] = sum_n softmax_n(x[b][n][:] . w)[n] * x[b][n][c]
+ * -- to_k (a 1x1 conv to one channel; its bias drops out of the soft-max), softmax over all positions and the weighted sum
+ * (imagen_video.py:957-982).  Online soft-max, fixed-order combines.  C in {64, 128, 256}; workspace: diqt_reduce_workspace_bytes(B, C). */
+int diqt_softmax_pool_supported(int B, int rows, int C);
+int diqt_softmax_pool(const float* x, const float* w, float* pooled, void* workspace, size_t workspace_bytes, int B, int rows, int C,
+                      void* stream);
 /* out[b][c] = sum_rows w[b][row] * x[b][row][c] — the attention-weighted pooling of GlobalContext
  * (imagen_video.py:975-979: einsum('b i n, b c n -> b c i', softmax(context), x)); workspace: diqt_reduce_workspace_bytes(B, C). */
 int diqt_weighted_colsum(const float* x, const float* w, float* out, void* workspace, size_t workspace_bytes,

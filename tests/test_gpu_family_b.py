@@ -474,3 +474,27 @@ def test_sampling_replays_the_unet_as_a_graph_bit_identically(lp):
         assert torch.equal(got2, eager2) and not torch.equal(got2, eager)
     finally:
         graphs.ENABLED, graphs.FORCE = was, wasf
+
+
+@pytest.mark.parametrize("B,n,C,scale", [(2, 5000, 64, 1.0), (1, 777, 128, 4.0), (3, 64, 256, 1.0), (2, 70000, 64, 20.0)])
+def test_global_context_pooling_in_one_pass(B, n, C, scale):
+    """diqt_softmax_pool: pooled = sum_n softmax_n(x . w) x in one pass (online soft-max; large logits exercise the rescaling), against
+    float64; and GlobalContext on the sampling path against its three-kernel form (autograd path)."""
+    from diffusioniqt_amd import ops
+    from diffusioniqt_amd.imagen_video import GlobalContext
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(B, n, C, generator=g)
+    w = torch.randn(C, generator=g) * scale / C ** 0.5
+    with torch.no_grad():
+        got = ops.softmax_pool_nograd(x.to(DEV), w.to(DEV))
+    assert got is not None
+    p = (x.double() @ w.double()).softmax(dim=-1)
+    ref = torch.einsum('bn,bnc->bc', p, x.double())
+    assert (got.cpu().double() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1e-3)
+    if C == 64 and n == 5000:
+        gc = GlobalContext(dim_in=C, dim_out=C).to(DEV).eval()
+        xv = x.reshape(B, 10, 20, 25, C).to(DEV)
+        with torch.no_grad():
+            fast = gc(xv)
+        slow = gc(xv)                                    # autograd on: to_k conv -> softmax -> weighted_pool
+        assert (fast - slow.detach()).abs().max().item() <= 1e-5

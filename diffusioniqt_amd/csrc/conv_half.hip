@@ -344,21 +344,25 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restr
 // XH: x holds 16-bit values (the operand type) instead of fp32 -- a halo piece is 8 channels and goes to the LDS image as it is;
 // YH: y is stored as 16-bit values (round_out, no residual).  The pair of convs of a pseudo-3D block passes its intermediate tensor this
 // way: the values are the ones the fp32 tensor would hold (already rounded to the operand type), at half the bytes.
-template <bool BF, int OCC, int NHR, int TGM, bool XH, bool YH, bool STATS = false>       // workgroups per CU, halo pieces per thread, most taps per weight group
-__global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
+// MW waves per workgroup: 8 (a wave owns 32 voxels x 64 channels) or 4 with TWO workgroups per CU (a wave owns 64 voxels x 64 channels:
+// 8 fragment reads per 8 MFMAs instead of 6 per 4 -- the 8-wave form asks 187 B/clk of the 128 B/clk LDS; one weight buffer, so that
+// two workgroups fit, and the other workgroup covers the refill)
+template <bool BF, int OCC, int NHR, int TGM, bool XH, bool YH, bool STATS = false, int MW = 8>       // workgroups per CU, halo pieces per thread, most taps per weight group
+__global__ __launch_bounds__(64 * MW, MW == 4 ? 2 : 2 * OCC) void conv_fwd_hp_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
                                                               const float* __restrict__ bias, const float* __restrict__ residual,
                                                               float* __restrict__ y, HalfGeom g, int nUnits, int perWg,
                                                               float* __restrict__ stats) {
     // stats (optional): column sums (sum, sum of squares) of the STORED values per (tile, wave) for the consumer's GroupNorm:
     // [B][tiles per batch * 8][2][Cout]
-    constexpr int NWR = (TGM * 256 + 511) / 512;
+    constexpr int NT = 64 * MW, RB = 8 / MW, WB = MW == 4 ? 1 : 2;      // threads, 32-voxel row blocks per wave, weight buffers
+    constexpr int NWR = (TGM * 256 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const int HV = g.HD * g.HH * g.HWd;
     unsigned char* halo = hsm;                                         // [HV][80 B]
     const int sliceBytes = HV * HROWB;                                 // one 32-channel halo image
     unsigned char* wbuf = hsm + (size_t)g.NS * sliceBytes;             // [2][TG][64][80 B]
     const int wbufBytes = g.TG * HNT * HROWB;
-    int* out_off = reinterpret_cast<int*>(wbuf + 2 * (size_t)wbufBytes);   // [2][256]: by unit parity
+    int* out_off = reinterpret_cast<int*>(wbuf + WB * (size_t)wbufBytes);  // [2][256]: by unit parity
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     unsigned pc[NHR], prel[NHR];
 #pragma unroll
     for (int u = 0; u < NHR; ++u) {
-        const int idx = u * 512 + tid, hv = min((idx >= nSlice ? idx - nSlice : idx) >> PSH, HV - 1);      // NS <= 2
+        const int idx = u * NT + tid, hv = min((idx >= nSlice ? idx - nSlice : idx) >> PSH, HV - 1);      // NS <= 2
         const int hx = hv % g.HWd, hy = (hv / g.HWd) % g.HH, hz = hv / (g.HWd * g.HH);
         pc[u] = idx < nHalo ? ((unsigned)hz | ((unsigned)hy << 10) | ((unsigned)hx << 20)) : 0x3fffffffu;     // past the tile: never in range
         prel[u] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin) * XE;
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     auto halo_load = [&](int ci0) {
 #pragma unroll
         for (int u = 0; u < NHR; ++u) {
-            const int ch = ci0 + (u * 512 + tid >= nSlice ? HCK : 0) + hq * (32 / PPR);   // second slice of a pointwise step: the next 32 channels
+            const int ch = ci0 + (u * NT + tid >= nSlice ? HCK : 0) + hq * (32 / PPR);   // second slice of a pointwise step: the next 32 channels
             const unsigned coff = ch < g.Cin ? (unsigned)ch * XE : HBUF_OOB_C;
             hr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, srcv[u] + coff, 0, 0);
         }
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     auto halo_store = [&]() {
 #pragma unroll
         for (int u = 0; u < NHR; ++u) {
-            const int idx = u * 512 + tid;
+            const int idx = u * NT + tid;
             if (idx < nHalo) {
                 unsigned char* img = idx >= nSlice ? halo + sliceBytes + ((idx - nSlice) >> PSH) * HROWB : halo + (idx >> PSH) * HROWB;
                 if constexpr (XH) {
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
         const unsigned short* src = wp + ((size_t)chunk * T * g.CoutPad + n0) * HCK;
 #pragma unroll
         for (int u = 0; u < NWR; ++u) {
-            const int idx = u * 512 + tid;
+            const int idx = u * NT + tid;
             const int tap = min(idx >> 8, n - 1), row = (idx >> 2) & 63, q = idx & 3;
             wr[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(t0 + tap) * g.CoutPad + row) * HCK + q * 8);
         }
@@ -490,23 +494,26 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
         unsigned char* dst = wbuf + buf * wbufBytes;
 #pragma unroll
         for (int u = 0; u < NWR; ++u) {
-            const int idx = u * 512 + tid;
+            const int idx = u * NT + tid;
             const int tap = idx >> 8, row = (idx >> 2) & 63, q = idx & 3;
             if (tap < n) *reinterpret_cast<u32x4*>(dst + (tap * HNT + row) * HROWB + q * 16) = wr[u];
         }
     };
 
-    int a_base;
-    {
-        const int v = wave * 32 + l31;
+    int a_base[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int v = (wave * RB + rb) * 32 + l31;
         const int tw = v % g.TW, th = (v / g.TW) % g.TH, td = v / (g.TW * g.TH);
-        a_base = ((td * g.HH + th) * g.HWd + tw) * HROWB + h * 16;
+        a_base[rb] = ((td * g.HH + th) * g.HWd + tw) * HROWB + h * 16;
     }
     const int b_base = l31 * HROWB + h * 16;
 
-    f32x16 acc0, acc1;
+    f32x16 accA[RB], accB[RB];                      // output channels n0 + l31 / n0 + 32 + l31 of each row block
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accA[rb][i] = 0.f; accB[rb][i] = 0.f; }
 
     Unit cur = decode(uBegin);
     write_out_table(cur, 0);
@@ -534,14 +541,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                 const bool more = !lastStep || hasNext;
                 const int nchunk = lastStep ? 0 : (lastGrp ? chunk + 1 : chunk), nt0 = lastGrp ? 0 : t0 + g.TG;
                 const int nn = pww ? min(g.NS, g.realChunks - nchunk * g.NS) : min(g.TG, T - nt0);
-                if (more) load_wgroup(nchunk * g.NS, nt0, nn, lastStep ? nxt.n0 : cur.n0);
+                if (more && WB == 2) load_wgroup(nchunk * g.NS, nt0, nn, lastStep ? nxt.n0 : cur.n0);
                 const bool pref = lastGrp && more;
                 if (pref) {
                     if (lastStep) unit_sources(nxt);
                     halo_load(lastStep ? 0 : (chunk + 1) * HCK * g.NS);
                 }
-                const unsigned char* wcur = wbuf + (step & 1) * wbufBytes + b_base;
-                const unsigned char* ap = halo + a_base;
+                const unsigned char* wcur = wbuf + (WB == 2 ? (step & 1) : 0) * wbufBytes + b_base;
+                const unsigned char* ap = halo;
                 int kx = t0 % g.kw, ky = (t0 / g.kw) % g.kh, kz = t0 / (g.kw * g.kh);
                 int toff = ((kz * g.HH + ky) * g.HWd + kx) * HROWB;
                 auto next_tap = [&]() {
@@ -552,21 +559,24 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                         if (++ky == g.kh) { ky = 0; toff += (g.HH - g.kh) * g.HWd * HROWB; }
                     }
                 };
-                if constexpr (OCC == 2) {
-                    // four waves per SIMD: the other waves cover a tap's fragment reads, no register double-buffering (128 registers)
+                if constexpr (MW == 4) {
+                    // two workgroups per CU: the other workgroup's waves cover a tap's fragment reads (no register double-buffering)
                     for (int t = 0; t < nTap; ++t) {
                         const unsigned char* wn = wcur + t * (HNT * HROWB);
-                        const u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + toff), a1 = *reinterpret_cast<const u32x4*>(ap + toff + 32);
                         const u32x4 b00 = *reinterpret_cast<const u32x4*>(wn), b01 = *reinterpret_cast<const u32x4*>(wn + 32);
                         const u32x4 b10 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB), b11 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB + 32);
-                        acc0 = mfma16<BF>(a0, b00, acc0);
-                        acc1 = mfma16<BF>(a0, b10, acc1);
-                        acc0 = mfma16<BF>(a1, b01, acc0);
-                        acc1 = mfma16<BF>(a1, b11, acc1);
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) {
+                            const u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + a_base[rb] + toff), a1 = *reinterpret_cast<const u32x4*>(ap + a_base[rb] + toff + 32);
+                            accA[rb] = mfma16<BF>(a0, b00, accA[rb]);
+                            accB[rb] = mfma16<BF>(a0, b10, accB[rb]);
+                            accA[rb] = mfma16<BF>(a1, b01, accA[rb]);
+                            accB[rb] = mfma16<BF>(a1, b11, accB[rb]);
+                        }
                         next_tap();
                     }
                 } else {
-                u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + toff), a1 = *reinterpret_cast<const u32x4*>(ap + toff + 32);
+                u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + a_base[0] + toff), a1 = *reinterpret_cast<const u32x4*>(ap + a_base[0] + toff + 32);
                 u32x4 b00 = *reinterpret_cast<const u32x4*>(wcur), b01 = *reinterpret_cast<const u32x4*>(wcur + 32);
                 u32x4 b10 = *reinterpret_cast<const u32x4*>(wcur + 32 * HROWB), b11 = *reinterpret_cast<const u32x4*>(wcur + 32 * HROWB + 32);
                 __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): see conv_fwd_h_kernel
@@ -575,27 +585,32 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                     if (t + 1 < nTap) {
                         next_tap();
                         const unsigned char* wn = wcur + (t + 1) * (HNT * HROWB);
-                        na0 = *reinterpret_cast<const u32x4*>(ap + toff); na1 = *reinterpret_cast<const u32x4*>(ap + toff + 32);
+                        na0 = *reinterpret_cast<const u32x4*>(ap + a_base[0] + toff); na1 = *reinterpret_cast<const u32x4*>(ap + a_base[0] + toff + 32);
                         nb00 = *reinterpret_cast<const u32x4*>(wn); nb01 = *reinterpret_cast<const u32x4*>(wn + 32);
                         nb10 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB); nb11 = *reinterpret_cast<const u32x4*>(wn + 32 * HROWB + 32);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    acc0 = mfma16<BF>(a0, b00, acc0);
-                    acc1 = mfma16<BF>(a0, b10, acc1);
-                    acc0 = mfma16<BF>(a1, b01, acc0);
-                    acc1 = mfma16<BF>(a1, b11, acc1);
+                    accA[0] = mfma16<BF>(a0, b00, accA[0]);
+                    accB[0] = mfma16<BF>(a0, b10, accB[0]);
+                    accA[0] = mfma16<BF>(a1, b01, accA[0]);
+                    accB[0] = mfma16<BF>(a1, b11, accB[0]);
                     if (t + 1 < nTap) { a0 = na0; a1 = na1; b00 = nb00; b01 = nb01; b10 = nb10; b11 = nb11; }
                 }
                 }
                 if (lastStep) {
                     // ---- epilogue of this unit (before its closing barrier: the stores drain while the next unit is staged) ----
-                    const int* oo = out_off + ((un - uBegin) & 1) * HMT + wave * 32 + 4 * h;
+                    const int* oo0 = out_off + ((un - uBegin) & 1) * HMT + wave * (32 * RB) + 4 * h;
                     const int co0 = cur.n0 + l31, co1 = cur.n0 + 32 + l31;
                     const float bias0 = (bias && co0 < g.Cout) ? bias[co0] : 0.f;
                     const float bias1 = (bias && co1 < g.Cout) ? bias[co1] : 0.f;
                     const unsigned c0 = co0 < g.Cout ? (unsigned)co0 * YE : HBUF_OOB_C, c1 = co1 < g.Cout ? (unsigned)co1 * YE : HBUF_OOB_C;
                     float st0 = 0.f, sq0 = 0.f, st1 = 0.f, sq1 = 0.f;
                     auto epilogue = [&](auto ROUND, auto RES) {
+#pragma unroll
+                      for (int rb = 0; rb < RB; ++rb) {
+                        const int* oo = oo0 + 32 * rb;
+                        f32x16& acc0 = accA[rb];
+                        f32x16& acc1 = accB[rb];
                         float rr0[16], rr1[16];
                         if constexpr (RES.value) {
 #pragma unroll
@@ -625,6 +640,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                             }
                             acc0[r] = 0.f; acc1[r] = 0.f;
                         }
+                      }
                     };
                     // kernel-uniform switches as branches (as selects they cost two v_cndmask per output element)
                     if (g.roundOut) {
@@ -636,18 +652,27 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
                         st0 += __shfl_xor(st0, 32, 64); sq0 += __shfl_xor(sq0, 32, 64);
                         st1 += __shfl_xor(st1, 32, 64); sq1 += __shfl_xor(sq1, 32, 64);
                         if (h == 0) {
-                            const int nblk = g.tilesD * g.tilesH * g.tilesW * 8;
-                            const int blk = ((cur.tz * g.tilesH + cur.ty) * g.tilesW + cur.tx) * 8 + wave;
+                            const int nblk = g.tilesD * g.tilesH * g.tilesW * MW;
+                            const int blk = ((cur.tz * g.tilesH + cur.ty) * g.tilesW + cur.tx) * MW + wave;
                             float* sp = stats + ((size_t)cur.b * nblk + blk) * 2 * g.Cout;
                             if (co0 < g.Cout) { sp[co0] = st0; sp[g.Cout + co0] = sq0; }
                             if (co1 < g.Cout) { sp[co1] = st1; sp[g.Cout + co1] = sq1; }
                         }
                     }
                 }
-                if (more) store_wgroup((step + 1) & 1, nn);
-                if (pref) {
-                    __syncthreads();                     // every wave is done with this chunk's halo image
-                    halo_store();
+                if (WB == 2) {
+                    if (more) store_wgroup((step + 1) & 1, nn);
+                    if (pref) {
+                        __syncthreads();                 // every wave is done with this chunk's halo image
+                        halo_store();
+                    }
+                } else {                                 // one weight buffer: refilled, like the halo image, once every wave has left the tap loop
+                    __syncthreads();
+                    if (more) {                          // loaded HERE, not before the tap loop: 36 registers less across the loop
+                        load_wgroup(nchunk * g.NS, nt0, nn, lastStep ? nxt.n0 : cur.n0);
+                        store_wgroup(0, nn);
+                    }
+                    if (pref) halo_store();
                 }
                 __syncthreads();
             }
@@ -656,10 +681,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_fwd_hp_kernel(const float* 
     }
 }
 
-static size_t half_lds_bytes(const HalfGeom& g) {
+static size_t half_lds_bytes(const HalfGeom& g, int wbufs = 2) {
     const size_t HV = (size_t)g.HD * g.HH * g.HWd;
     const size_t tables = (HMT + HV) > 2 * HMT ? (HMT + HV) : 2 * HMT;      // one-unit kernel: out_off + halo_src; persistent: out_off x 2
-    return (size_t)g.NS * HV * HROWB + 2 * (size_t)g.TG * HNT * HROWB + tables * sizeof(int);
+    return (size_t)g.NS * HV * HROWB + (size_t)wbufs * g.TG * HNT * HROWB + tables * sizeof(int);
 }
 
 static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
@@ -777,6 +802,13 @@ static bool convh_persistent_takes(const HalfGeom& g, unsigned nwg) {
     return persist && !nopref && HV * 8 <= 512 * HHREG && nwg >= 2u * (unsigned)diqt_set_convh_workgroups(0);
 }
 
+// 16-bit input on the persistent kernel: 4-wave workgroups (64 voxels x 64 channels per wave, one weight buffer), two per CU, when both fit
+static bool convh_four_waves(const HalfGeom& g, bool xh) {
+    static const bool off = [] { const char* e = getenv("DIQT_CONVH_W8"); return e && e[0] == '1'; }();
+    const int HV = g.HD * g.HH * g.HWd;
+    return xh && !off && g.kd * g.kh * g.kw > 1 && HV * 4 <= 256 * 6 && half_lds_bytes(g, 1) <= 80 * 1024 - 1024;
+}
+
 // 1 when diqt_conv3d_fwd_h_io takes 16-bit x and / or y for this shape: the persistent kernel's conditions and Cin, Cout % 8 == 0
 extern "C" int diqt_conv3d_fwd_h_io16_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
                                                 int pw, int epd, int eph, int epw, int x_half, int y_half) {
@@ -795,7 +827,7 @@ extern "C" int diqt_conv3d_fwd_h_stats_blocks(int B, int D, int H, int W, int Ci
     if (!half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, x_half ? 2 : 4, y_half ? 2 : 4)) return 0;
     if ((kd == 1 && kh == 1 && kw == 1) || !x_half) return 0;          // flattened rows: tiles straddle batch entries
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
-    return convh_persistent_takes(g, nwg) ? g.tilesD * g.tilesH * g.tilesW * 8 : 0;
+    return convh_persistent_takes(g, nwg) ? g.tilesD * g.tilesH * g.tilesW * (convh_four_waves(g, x_half != 0) ? 4 : 8) : 0;
 }
 
 static int convh_launch(const void* x, const void* packed_h, const float* bias, const float* residual, void* y, int B, int D, int H, int W,
@@ -840,16 +872,26 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
                                   conv_fwd_hp_kernel<true, 1, HHREG, HTG, false, false>,  conv_fwd_hp_kernel<true, 1, HHREG, HTG, false, true>,
                                   conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, false>,   conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, true>};
         DIQT_REQUIRE(!stats || xh, DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: statistics are built for x_half = 1");
-        const KP kp = !stats ? tab[sel]
-                    : yh ? (bf16 ? conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, true, true> : conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, true, true>)
-                         : (bf16 ? conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, false, true> : conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, false, true>);
+        const bool four = convh_four_waves(g, xh);
+        KP kp;
+        if (four) {
+            lds = half_lds_bytes(g, 1);
+            kp = stats ? (yh ? (bf16 ? conv_fwd_hp_kernel<true, 1, 6, HTG, true, true, true, 4> : conv_fwd_hp_kernel<false, 1, 6, HTG, true, true, true, 4>)
+                             : (bf16 ? conv_fwd_hp_kernel<true, 1, 6, HTG, true, false, true, 4> : conv_fwd_hp_kernel<false, 1, 6, HTG, true, false, true, 4>))
+                       : (yh ? (bf16 ? conv_fwd_hp_kernel<true, 1, 6, HTG, true, true, false, 4> : conv_fwd_hp_kernel<false, 1, 6, HTG, true, true, false, 4>)
+                             : (bf16 ? conv_fwd_hp_kernel<true, 1, 6, HTG, true, false, false, 4> : conv_fwd_hp_kernel<false, 1, 6, HTG, true, false, false, 4>));
+        } else {
+            kp = !stats ? tab[sel]
+               : yh ? (bf16 ? conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, true, true> : conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, true, true>)
+                    : (bf16 ? conv_fwd_hp_kernel<true, 1, HHREG / 2, HTG, true, false, true> : conv_fwd_hp_kernel<false, 1, HHREG / 2, HTG, true, false, true>);
+        }
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
-        const int wgs = diqt_set_convh_workgroups(0);
+        const int wgs = diqt_set_convh_workgroups(0) * (four ? 2 : 1);
         const int perWg = (int)((nwg + wgs - 1) / wgs), grid = (int)((nwg + perWg - 1) / perWg);
-        hipLaunchKernelGGL(kp, dim3(grid), dim3(512), lds, s, static_cast<const float*>(x), static_cast<const unsigned short*>(packed_h), bias,
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(four ? 256 : 512), lds, s, static_cast<const float*>(x), static_cast<const unsigned short*>(packed_h), bias,
                            residual, static_cast<float*>(y), g, (int)nwg, perWg, stats);
         return check_launch("conv3d_fwd_h(persistent)");
     }

@@ -805,8 +805,11 @@ static bool convh_persistent_takes(const HalfGeom& g, unsigned nwg) {
 // 16-bit input on the persistent kernel: 4-wave workgroups (64 voxels x 64 channels per wave, one weight buffer), two per CU, when both fit
 static bool convh_four_waves(const HalfGeom& g, bool xh) {
     static const bool off = [] { const char* e = getenv("DIQT_CONVH_W8"); return e && e[0] == '1'; }();
+    static const bool pw4 = [] { const char* e = getenv("DIQT_CONVH_PW4"); return !(e && e[0] == '0'); }();
     const int HV = g.HD * g.HH * g.HWd;
-    return xh && !off && g.kd * g.kh * g.kw > 1 && HV * 4 <= 256 * 6 && half_lds_bytes(g, 1) <= 80 * 1024 - 1024;
+    if (off || half_lds_bytes(g, 1) > 80 * 1024 - 1024) return false;
+    if (g.kd * g.kh * g.kw > 1) return xh && HV * 4 <= 256 * 6;
+    return pw4 && !xh && g.NS == 1 && HV * 8 <= 256 * 8;     // pointwise, fp32 rows, one chunk per step: 8 pieces per thread
 }
 
 // 1 when diqt_conv3d_fwd_h_io takes 16-bit x and / or y for this shape: the persistent kernel's conditions and Cin, Cout % 8 == 0
@@ -859,7 +862,9 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
         }
         DIQT_REQUIRE(!stats || !(kd == 1 && kh == 1 && kw == 1), DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: no statistics from a 1x1x1 conv");
         static const bool nowide = [] { const char* e = getenv("DIQT_CONVH_NOWIDE"); return e && e[0] == '1'; }();
-        if (kd * kh * kw == 1 && g.nChunks >= 2 && !nowide) {
+        // (fp32 rows of a pointwise conv: the 4-wave build below at one chunk per step measures slightly faster than two chunks per step on 8 waves)
+        static const bool pw4first = [] { const char* e = getenv("DIQT_CONVH_PW4"); return !(e && e[0] == '0'); }();
+        if (kd * kh * kw == 1 && g.nChunks >= 2 && !nowide && !(pw4first && !xh)) {
             // pointwise: 4 MFMAs of a wave per 32-channel chunk and two barriers around them -- stage TWO chunks per step and walk them like
             // taps (their weight panels are consecutive in the packed layout [chunk][tap = 1][co][32])
             g.NS = 2; g.realChunks = g.nChunks; g.nChunks = (g.realChunks + 1) / 2; g.TG = 2; g.nGroups = 1;
@@ -874,7 +879,12 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
         DIQT_REQUIRE(!stats || xh, DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: statistics are built for x_half = 1");
         const bool four = convh_four_waves(g, xh);
         KP kp;
-        if (four) {
+        if (four && !xh) {
+            DIQT_REQUIRE(!stats, DIQT_E_UNSUPPORTED, "conv3d_fwd_h_io: statistics are built for x_half = 1");
+            lds = half_lds_bytes(g, 1);
+            kp = yh ? (bf16 ? conv_fwd_hp_kernel<true, 1, 8, HTG, false, true, false, 4> : conv_fwd_hp_kernel<false, 1, 8, HTG, false, true, false, 4>)
+                    : (bf16 ? conv_fwd_hp_kernel<true, 1, 8, HTG, false, false, false, 4> : conv_fwd_hp_kernel<false, 1, 8, HTG, false, false, false, 4>);
+        } else if (four) {
             lds = half_lds_bytes(g, 1);
             kp = stats ? (yh ? (bf16 ? conv_fwd_hp_kernel<true, 1, 6, HTG, true, true, true, 4> : conv_fwd_hp_kernel<false, 1, 6, HTG, true, true, true, 4>)
                              : (bf16 ? conv_fwd_hp_kernel<true, 1, 6, HTG, true, false, true, 4> : conv_fwd_hp_kernel<false, 1, 6, HTG, true, false, true, 4>))

@@ -799,7 +799,9 @@ static bool convh_persistent_takes(const HalfGeom& g, unsigned nwg) {
     static const bool persist = [] { const char* e = getenv("DIQT_CONVH_PERSIST"); return !(e && e[0] == '0'); }();
     static const bool nopref = [] { const char* e = getenv("DIQT_CONVH_NOPREF"); return e && e[0] == '1'; }();
     const int HV = g.HD * g.HH * g.HWd;
-    return persist && !nopref && HV * 8 <= 512 * HHREG && nwg >= 2u * (unsigned)diqt_set_convh_workgroups(0);
+    // (filters of more than one tap group -- 3x3x3 -- stay on the one-unit kernel: 93.9 vs 102.3 us on 64 -> 64 @ 8 x 32^3, the walk's prefetch
+    // registers spill there and 4 units per workgroup amortise little)
+    return persist && !nopref && g.nGroups == 1 && HV * 8 <= 512 * HHREG && nwg >= 2u * (unsigned)diqt_set_convh_workgroups(0);
 }
 
 // 16-bit input on the persistent kernel: 4-wave workgroups (64 voxels x 64 channels per wave, one weight buffer), two per CU, when both fit

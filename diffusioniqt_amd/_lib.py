@@ -197,5 +197,24 @@ def call(name, *args):
         raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
 
 
+_memo = {}
+
+
 def query(name, *args):
-    return getattr(load(), name)(*args)
+    """Calls a value-returning entry point.  The shape queries (``*_supported``, ``*_bytes``, ``*_blocks``, ``*_elems``, ``*_kernel_id``) are
+    pure functions of their integer arguments and of the library's run-time switches, so their results are memoised -- a conv launch asks
+    three or four of them, and launch-bound steps (744 launches per bf16 training micro-step) pay for every ctypes round trip.  Any
+    ``diqt_set_*`` call (a switch changes) empties the memo; ``diqt_get_*`` is never cached."""
+    if name.startswith("diqt_set_"):
+        _memo.clear()
+        return getattr(load(), name)(*args)
+    if name.startswith("diqt_get_"):
+        return getattr(load(), name)(*args)
+    key = (name, args)
+    try:
+        return _memo[key]
+    except KeyError:
+        v = _memo[key] = getattr(load(), name)(*args)
+        return v
+    except TypeError:                                    # an unhashable argument: not a shape query
+        return getattr(load(), name)(*args)

@@ -22,6 +22,7 @@
 //   layout and are reduced in a fixed order (deterministic) by conv_reduce_dw_kernel.
 #include "common.h"
 #include "conv_wgrad.h"
+#include "conv_wgrad_h.h"
 #include "conv_pw.h"
 #include "conv_fwd9.h"
 #include <type_traits>
@@ -2279,6 +2280,36 @@ static ScPlan sc_plan(const ConvGeom& g) {
     while (ks * 2 * tiles <= 256 && p.V % (ks * 2) == 0 && p.V / (ks * 2) >= 256) ks *= 2;
     p.ks = ks;
     return p;
+}
+
+// ---- weight gradient with 16-bit MFMA operands (bf16 training): conv_wgrad_h.hip + the fixed-order slab sum of conv_wgrad3_kernel ----
+extern "C" size_t diqt_conv3d_bwd_weight_h_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd,
+                                                           int ph, int pw, int epd, int eph, int epw) {
+    WHGeom g;
+    int ks = 0;
+    if (!wgradh_plan(g, ks, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)) return 0;       // 0: shape not taken
+    return ((size_t)ks * Cout * Cin * kd * kh * kw + (size_t)ks * g.CoutPad) * sizeof(float);
+}
+extern "C" int diqt_conv3d_bwd_weight_h(const float* x, const float* dy, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                                        int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                                        int epd, int eph, int epw, int bf16, void* stream) {
+    DIQT_REQUIRE(x && dy && dw && workspace, DIQT_E_ALIGN, "conv3d_bwd_weight_h: null pointer");
+    DIQT_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace), DIQT_E_ALIGN, "conv3d_bwd_weight_h: pointers must be 16-byte aligned");
+    WHGeom g;
+    int ks = 0;
+    DIQT_REQUIRE(wgradh_plan(g, ks, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw), DIQT_E_UNSUPPORTED,
+                 "conv3d_bwd_weight_h: shape not taken (diqt_conv3d_bwd_weight_h_workspace_bytes == 0)");
+    const int T = kd * kh * kw;
+    const size_t need = ((size_t)ks * Cout * Cin * T + (size_t)ks * g.CoutPad) * sizeof(float);
+    DIQT_REQUIRE(workspace_bytes >= need, DIQT_E_WORKSPACE, "conv3d_bwd_weight_h: workspace %zu < %zu", workspace_bytes, need);
+    float* slabs = static_cast<float*>(workspace);
+    float* bias_part = dbias ? slabs + (size_t)ks * Cout * Cin * T : nullptr;
+    int rc = wgradh_launch(x, dy, slabs, bias_part, g, ks, bf16, stream);
+    if (rc) return rc;
+    const size_t n4 = (size_t)Cout * Cin * T / 4;
+    hipLaunchKernelGGL(conv_reduce_dw3_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(512), 0, (hipStream_t)stream, slabs, dw, n4, ks, Cout,
+                       g.CoutPad, bias_part, bias_part ? dbias : nullptr, ks);
+    return check_launch("conv_reduce_dw3(h)");
 }
 
 extern "C" size_t diqt_conv3d_bwd_weight_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd,

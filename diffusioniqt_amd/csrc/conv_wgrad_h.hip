@@ -1,0 +1,291 @@
+// Weight gradient of the stride-1 3x3x3 convolution with 16-bit MFMA operands (bf16 training, `ImagenTrainer(precision='bf16')`:
+// the reference's autocast backward computes the weight gradient in the forward's type, trainer.py:293-311):
+//   dW[co][ci][tap] = sum_v dY[v][co] * X[v + tap][ci]      M = co, N = ci, K = voxels, on v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate
+//
+// Both operands are summed over VOXELS, the slow axis of the channels-last tensors, so neither is k-contiguous in memory.  The fp32 kernel
+// (conv_wgrad.hip) reads them as scalars per lane (v_mfma_f32_32x32x2_f32 takes one k per lane); for the 8-wide k of the 16-bit MFMA the
+// LDS images stay ROW-MAJOR [voxel][channel] -- exactly as staged from HBM, converted to 16 bit on the way -- and the fragments come out
+// of `ds_read_b64_tr_b16`: a 16-lane group reads 4 voxels x 16 channels and hands lane i channel i of the 4 voxels.  A filter tap is then a
+// whole-row offset in the halo image (no alignment constraints on the shifted reads).
+//   * 256 threads, one wave per SIMD; a workgroup owns 64 co x 32 ci x all 27 taps and walks a split-K range of 128-voxel tiles (2 x 4 x 16);
+//     wave w = (co half, tap parity): 14 / 13 accumulator tiles (224 AGPRs);
+//   * the next tile's dY rows and X halo rows are loaded global -> registers (range-checked buffer loads: zero padding, ragged tiles)
+//     before the current tile's MFMAs and converted + written to LDS behind them (two barriers per tile);
+//   * LDS rows: X 64 B (32 ci), dY 192 B (64 co + pad): the 4 rows x 2 channel blocks of a 32-lane half fall on disjoint bank groups;
+//   * partial slabs [slice][Cout][Cin][taps] and bias partials [slice][CoutPad] as conv_wgrad3_kernel writes them: the same fixed-order
+//     reduce (conv_reduce_dw3_kernel) finishes the gradient -- deterministic.
+#include "common.h"
+#include "conv_wgrad_h.h"
+#include <stdlib.h>
+
+namespace diqt {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8w __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4w lds_s16x4w;
+
+constexpr unsigned WH_OOB = 0x80000000u;
+constexpr int WTD = 2, WTH = 4, WTW = 16, WMV = WTD * WTH * WTW;        // 128-voxel tile: 8 k-blocks of 16 voxels (one row of 16 along W)
+constexpr int WK = 3, WT = 27;
+constexpr int WHD = WTD + 2, WHH = WTH + 2, WHW = WTW + 2, WHV = WHD * WHH * WHW;    // 4 x 6 x 18 = 432 halo voxels
+constexpr int XROW = 64, YROW = 192;                                    // LDS row bytes
+constexpr int NPX = (WHV * 8 + 255) / 256, NPY = WMV * 16 / 256;        // float4 pieces per thread: 14 and 8
+constexpr int WH_LDS_TILE = WHV * XROW + WMV * YROW, WH_LDS_STAGE = 16 * 32 * WT * 4;
+constexpr int WH_LDS = WH_LDS_TILE > WH_LDS_STAGE ? WH_LDS_TILE : WH_LDS_STAGE;
+
+// (by value: __builtin_bit_cast on a vector COMPONENT lvalue reads element 0 for every component on this hipcc, see conv_half.hip)
+__device__ __forceinline__ float wasf(unsigned u) { return __builtin_bit_cast(float, u); }
+
+template <bool BF>
+__device__ __forceinline__ unsigned wpack2(float a, float b) {
+    if (BF) {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        b2 v = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, v);
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 v = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+}
+template <bool BF>
+__device__ __forceinline__ f32x16 wmfma(u32x4w a, u32x4w b, f32x16 c) {
+    if (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8w, a), __builtin_bit_cast(bf16x8w, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8w, a), __builtin_bit_cast(f16x8w, b), c, 0, 0, 0);
+}
+// 8 k-values (voxels r0 .. r0 + 7 of the image, this lane's channel) as one MFMA operand: two transposing reads of 4 rows each
+__device__ __forceinline__ u32x4w tr_frag(const unsigned char* p, int rowBytes) {
+    const s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w*)p);
+    const s16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w*)(p + 4 * rowBytes));
+    const unsigned long long l = __builtin_bit_cast(unsigned long long, lo), h = __builtin_bit_cast(unsigned long long, hi);
+    u32x4w r;
+    r.x = (unsigned)l; r.y = (unsigned)(l >> 32); r.z = (unsigned)h; r.w = (unsigned)(h >> 32);
+    return r;
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ slabs, float* __restrict__ bias_part, WHGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+    unsigned char* Xs = smw;                         // [432][64 B]   halo voxels x 32 ci
+    unsigned char* Ys = smw + WHV * XROW;            // [128][192 B]  tile voxels x 64 co
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int ct = wave & 1, tpar = wave >> 1;       // co half, tap parity: taps tpar, tpar + 2, ...
+    const int NTW = tpar ? WT / 2 : (WT + 1) / 2;    // 13 / 14 taps
+    int bx = blockIdx.x;
+    const int cob = bx % g.nCoB; bx /= g.nCoB;
+    const int cib = bx;
+    const int co0 = cob * 64, ci0 = cib * 32;
+    const int mtBegin = blockIdx.y * g.tilesPerSplit, mtEnd = min(mtBegin + g.tilesPerSplit, g.MT);
+
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, (int)g.yBytes, 0x00020000);
+
+    // ---- this thread's staging pieces (tile-independent part): halo coordinates as guarded 10-bit fields (range tests of a tile are two
+    // subtractions, see conv_fwd_hp_kernel) and the element offset inside the tile's halo ----
+    constexpr unsigned GUARD = (1u << 9) | (1u << 19) | (1u << 29), PADB = 16u, LOW = PADB | (PADB << 10) | (PADB << 20);
+    unsigned xpc[NPX], xrel[NPX], xdst[NPX];
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) {
+        const int idx = u * 256 + tid, row = idx >> 3, q4 = idx & 7;
+        const bool ok = row < WHV && ci0 + q4 * 4 < g.Cin;
+        const int hx = row % WHW, hy = (row / WHW) % WHH, hz = row / (WHW * WHH);
+        xpc[u] = ok ? ((unsigned)hz | ((unsigned)hy << 10) | ((unsigned)hx << 20)) : 0x3fffffffu;      // no piece: never in range
+        xrel[u] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin + ci0 + q4 * 4) * 4u;
+        xdst[u] = row < WHV ? (unsigned)(row * XROW + q4 * 8) : 0xffffffffu;
+    }
+    const unsigned limits = (unsigned)(g.D + PADB - 1) | ((unsigned)(g.H + PADB - 1) << 10) | ((unsigned)(g.W + PADB - 1) << 20);
+    unsigned yrel[NPY], ypc[NPY];
+#pragma unroll
+    for (int u = 0; u < NPY; ++u) {
+        const int row = (u * 256 + tid) >> 4;
+        const int tw = row % WTW, th = (row / WTW) % WTH, td = row / (WTW * WTH);
+        ypc[u] = (unsigned)td | ((unsigned)th << 10) | ((unsigned)tw << 20);
+        yrel[u] = (unsigned)(((td * g.Ho + th) * g.Wo + tw) * g.Cout + co0 + (tid & 15) * 4) * 4u;
+    }
+    const unsigned ylimits = (unsigned)(g.Do + PADB - 1) | ((unsigned)(g.Ho + PADB - 1) << 10) | ((unsigned)(g.Wo + PADB - 1) << 20);
+    const int yq = tid & 15;                          // this thread's co quad of a dY row (the same for all its pieces)
+    const bool yok = co0 + yq * 4 < g.Cout;
+    // ---- fragment addresses ----
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+    const unsigned char* aBase = Ys + (8 * hf + trq) * YROW + (32 * ct + 16 * trc + 4 * trp) * 2;
+    const unsigned char* bBase = Xs + (8 * hf + trq) * XROW + (16 * trc + 4 * trp) * 2;
+    int tapOff[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        const int t = min(2 * i + tpar, WT - 1);
+        tapOff[i] = (((t / 9) * WHH + (t / 3) % 3) * WHW + t % 3) * XROW;
+    }
+
+    f32x16 acc[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 px[NPX], py[NPY];
+    auto load_tile = [&](int mt) {
+        int m = mt;
+        const int tx = m % g.tilesW; m /= g.tilesW;
+        const int ty = m % g.tilesH; m /= g.tilesH;
+        const int tz = m % g.tilesD;
+        const int b = m / g.tilesD;
+        const int d0 = tz * WTD, h0 = ty * WTH, w0 = tx * WTW;
+        const unsigned xorg = (unsigned)(d0 - g.pd + (int)PADB) + ((unsigned)(h0 - g.ph + (int)PADB) << 10) + ((unsigned)(w0 - g.pw + (int)PADB) << 20);
+        const unsigned xbase = (unsigned)((((b * g.D + d0 - g.pd) * g.H + h0 - g.ph) * g.W + w0 - g.pw) * g.Cin) * 4u;
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            const unsigned c = xpc[u] + xorg;                     // fields < 512: extents <= 255 (plan), PADB, a halo of 2
+            const unsigned okm = ((c | GUARD) - LOW) & ((limits | GUARD) - c) & GUARD;
+            const unsigned off = (okm == GUARD && xpc[u] != 0x3fffffffu) ? xbase + xrel[u] : WH_OOB;
+            const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+            px[u] = make_float4(wasf(v.x), wasf(v.y), wasf(v.z), wasf(v.w));
+        }
+        const unsigned yorg = (unsigned)(d0 + (int)PADB) + ((unsigned)(h0 + (int)PADB) << 10) + ((unsigned)(w0 + (int)PADB) << 20);
+        const unsigned ybase = (unsigned)((((b * g.Do + d0) * g.Ho + h0) * g.Wo + w0) * g.Cout) * 4u;
+#pragma unroll
+        for (int u = 0; u < NPY; ++u) {
+            const unsigned c = ypc[u] + yorg;
+            const unsigned okm = ((c | GUARD) - LOW) & ((ylimits | GUARD) - c) & GUARD;
+            const unsigned off = (yok && okm == GUARD) ? ybase + yrel[u] : WH_OOB;
+            const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
+            py[u] = make_float4(wasf(v.x), wasf(v.y), wasf(v.z), wasf(v.w));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            if (xdst[u] != 0xffffffffu) {
+                u32x2w w;
+                w.x = wpack2<BF>(px[u].x, px[u].y); w.y = wpack2<BF>(px[u].z, px[u].w);
+                *reinterpret_cast<u32x2w*>(Xs + xdst[u]) = w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NPY; ++u) {
+            const int row = (u * 256 + tid) >> 4;
+            u32x2w w;
+            w.x = wpack2<BF>(py[u].x, py[u].y); w.y = wpack2<BF>(py[u].z, py[u].w);
+            *reinterpret_cast<u32x2w*>(Ys + row * YROW + yq * 8) = w;
+            bsum.x += py[u].x; bsum.y += py[u].y; bsum.z += py[u].z; bsum.w += py[u].w;      // exact fp32 dY: the bias gradient
+        }
+    };
+
+    if (mtBegin < mtEnd) load_tile(mtBegin);
+    for (int mt = mtBegin; mt < mtEnd; ++mt) {
+        store_tile();
+        __syncthreads();
+        if (mt + 1 < mtEnd) load_tile(mt + 1);              // in flight behind this tile's MFMAs
+#pragma unroll 1
+        for (int kb = 0; kb < WMV / 16; ++kb) {              // 16 voxels: row (d, h) = (kb / 4, kb % 4) of the tile, all 16 w
+            const u32x4w a = tr_frag(aBase + kb * 16 * YROW, YROW);
+            const unsigned char* bp = bBase + (((kb >> 2) * WHH + (kb & 3)) * WHW) * XROW;
+            // the B fragments run PD taps ahead of their MFMA: an LDS read is ~150 cycles away, an MFMA 32 -- one tap ahead (what the
+            // compiler makes of the plain loop) left every MFMA waiting for its own operands (57 % of the wave's cycles in s_waitcnt)
+            constexpr int PD = 5;
+            u32x4w bq[PD];
+#pragma unroll
+            for (int i = 0; i < PD; ++i) bq[i] = tr_frag(bp + tapOff[i], XROW);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) {
+                if (i < NTW) {                                   // wave-uniform (13 or 14 taps)
+                    const u32x4w b = bq[i % PD];
+                    if (i + PD < 14 && i + PD < NTW) bq[i % PD] = tr_frag(bp + tapOff[i + PD], XROW);
+                    acc[i] = wmfma<BF>(a, b, acc[i]);
+                }
+            }
+        }
+        __syncthreads();                                      // every wave is done with the images
+    }
+
+    // ---- slab [slice][Cout][Cin][taps]: this wave's co half x 32 ci x its taps ----
+    // Through LDS in four rounds of 16 output channels, so that the slab leaves in its [co][ci][tap] order as 16-byte stores of contiguous
+    // runs (a (co, this ci block) pair is 32 x 27 contiguous floats).  Straight from the accumulators every lane would write 216 single
+    // floats 108 bytes apart: 14 M partial 32-byte sectors per launch -- that alone was about half of the kernel's time.
+    float* slab = slabs + (size_t)blockIdx.y * g.Cout * g.Cin * WT;
+    float* stage = reinterpret_cast<float*>(smw);           // [16 co][32 ci][27 taps]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (ct == (r >> 1)) {                               // wave-uniform: the two waves (tap parities) that hold these channels
+#pragma unroll
+            for (int i = 0; i < 14; ++i) {
+                if (i < NTW) {
+                    const int tap = 2 * i + tpar;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int j = 8 * (r & 1) + jj;                           // accumulator rows 16 (r & 1) .. + 15 of this wave's 32
+                        const int cl = (jj & 3) + 8 * (jj >> 2) + 4 * hf;          // channel inside the group of 16
+                        stage[(cl * 32 + l31) * WT + tap] = acc[i][j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int f = tid; f < 16 * 32 * WT / 4; f += 256) {
+            const int cl = f / (32 * WT / 4), k4 = f % (32 * WT / 4);
+            const int co = co0 + 16 * r + cl;
+            if (co < g.Cout)
+                *reinterpret_cast<float4*>(slab + ((size_t)co * g.Cin + ci0) * WT + 4 * k4) = *reinterpret_cast<const float4*>(stage + (cl * 32 * WT) + 4 * k4);
+        }
+        __syncthreads();
+    }
+    // ---- bias partial of this slice (workgroups of the first ci block): 16 threads share a co quad ----
+    if (bias_part && cib == 0) {
+        float4* red = reinterpret_cast<float4*>(smw);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 16) {
+            float4 s = red[tid];
+            for (int k = 1; k < 16; ++k) { const float4 t = red[tid + 16 * k]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+            float* bp = bias_part + (size_t)blockIdx.y * g.CoutPad + co0 + tid * 4;
+            if (co0 + tid * 4 < g.Cout) { bp[0] = s.x; bp[1] = s.y; bp[2] = s.z; bp[3] = s.w; }
+        }
+    }
+}
+
+}  // namespace
+
+bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
+                 int epd, int eph, int epw) {
+    static const bool off = [] { const char* e = getenv("DIQT_NO_WGRADH"); return e && e[0] == '1'; }();
+    if (off || kd != 3 || kh != 3 || kw != 3 || Cin % 32 != 0 || Cout % 4 != 0 || Cin < 32 || Cout < 32) return false;
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || pd < 0 || ph < 0 || pw < 0 || pd > 16 || ph > 16 || pw > 16) return false;
+    if (D > 255 || H > 255 || W > 255) return false;                   // packed 10-bit coordinate fields in the kernel
+    g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.pd = pd; g.ph = ph; g.pw = pw;
+    g.Do = D + 2 * pd + epd - 2; g.Ho = H + 2 * ph + eph - 2; g.Wo = W + 2 * pw + epw - 2;
+    if (g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return false;
+    g.tilesD = (g.Do + WTD - 1) / WTD; g.tilesH = (g.Ho + WTH - 1) / WTH; g.tilesW = (g.Wo + WTW - 1) / WTW;
+    const long long mt = (long long)B * g.tilesD * g.tilesH * g.tilesW;
+    if (mt >= (1ll << 30)) return false;
+    g.MT = (int)mt;
+    g.nCoB = (Cout + 63) / 64; g.nCiB = Cin / 32; g.CoutPad = g.nCoB * 64;
+    const unsigned long long xb = (unsigned long long)B * D * H * W * Cin * 4ull, yb = (unsigned long long)B * g.Do * g.Ho * g.Wo * Cout * 4ull;
+    if (xb >= (1ull << 30) || yb >= (1ull << 30)) return false;
+    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb;
+    const int blocks = g.nCoB * g.nCiB;
+    ksplit = 256 / blocks;
+    if (ksplit > g.MT) ksplit = g.MT;
+    if (ksplit < 1) ksplit = 1;
+    g.tilesPerSplit = (g.MT + ksplit - 1) / ksplit;
+    ksplit = (g.MT + g.tilesPerSplit - 1) / g.tilesPerSplit;
+    return true;
+}
+
+int wgradh_launch(const float* x, const float* dy, float* slabs, float* bias_part, const WHGeom& g, int ksplit, int bf16, void* stream) {
+    auto kern = bf16 ? conv_wgrad_h_kernel<true> : conv_wgrad_h_kernel<false>;
+    if (WH_LDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS);
+        DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_bwd_weight_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(g.nCoB * g.nCiB, ksplit), dim3(256), WH_LDS, (hipStream_t)stream, x, dy, slabs, bias_part, g);
+    return check_launch("conv3d_bwd_weight_h");
+}
+
+}  // namespace diqt

@@ -452,6 +452,23 @@ class _Conv3dFn(Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nh = _lib.query("diqt_conv3d_bwd_weight_h_workspace_bytes", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw) \
+                if ctx.lp == 1 else 0
+            if nh:
+                # bf16 training: the weight gradient on the bf16 MFMA too (x and dY rounded to bf16 while staged, fp32 accumulation; the
+                # reference's autocast backward runs in the forward's type); other shapes stay on the fp32 kernel
+                ws = _workspace(nh, x.device)
+                if TIMER.enabled:
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                _lib.call("diqt_conv3d_bwd_weight_h", x, dy, dw, db, ws, nh, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, 1,
+                          _stream())
+                if TIMER.enabled:
+                    e.record()
+                    Do, Ho, Wo = dy.shape[1:4]
+                    TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_wgrad_h_kernel",
+                                          (B, D, H, W, Cin, Cout, kd, kh, kw)))
+                return dx, dw, db, None, (dy if ctx.has_res else None), None, None, None
             n = _lib.query("diqt_conv3d_bwd_weight_workspace_bytes", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw)
             ws = _workspace(n, x.device)
             if TIMER.enabled:

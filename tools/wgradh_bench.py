@@ -1,0 +1,33 @@
+"""conv_wgrad_h_kernel vs conv_wgrad3_kernel on one shape.   python tools/wgradh_bench.py [B S Cin Cout]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffusioniqt_amd import _lib
+_lib.load()
+B, S, Cin, Cout = (int(v) for v in sys.argv[1:5]) if len(sys.argv) > 4 else (8, 32, 64, 64)
+geo = (B, S, S, S, Cin, Cout, 3, 3, 3, 1, 1, 1, 0, 0, 0)
+x = torch.randn(B, S, S, S, Cin, device="cuda"); dy = torch.randn(B, S, S, S, Cout, device="cuda")
+dw = torch.empty(Cout, Cin, 3, 3, 3, device="cuda"); db = torch.empty(Cout, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+fl = 2.0 * B * S ** 3 * Cin * Cout * 27
+
+
+def timeit(fn, n=30):
+    for _ in range(100):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+nh = _lib.query("diqt_conv3d_bwd_weight_h_workspace_bytes", *geo)
+wsh = torch.empty(max(nh, 4) // 4, device="cuda")
+n3 = _lib.query("diqt_conv3d_bwd_weight_workspace_bytes", *geo)
+ws3 = torch.empty(max(n3, 4) // 4, device="cuda")
+mh = timeit(lambda: _lib.call("diqt_conv3d_bwd_weight_h", x, dy, dw, db, wsh, nh, *geo, 1, st))
+m3 = timeit(lambda: _lib.call("diqt_conv3d_bwd_weight", x, dy, dw, db, ws3, n3, *geo, st))
+print(f"wgrad {B}x{S}^3 {Cin}->{Cout}: bf16 {mh * 1e3:.1f} us ({fl / mh / 1e9:.0f} TF/s)   fp32 {m3 * 1e3:.1f} us ({fl / m3 / 1e9:.0f} TF/s)  (each incl. the slab sum)")

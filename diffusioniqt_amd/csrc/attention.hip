@@ -804,6 +804,8 @@ __global__ __launch_bounds__(256, 2) void mqa_flash_bwd_dq_kernel(const float* _
         __builtin_amdgcn_s_waitcnt(0xc07f);                // this wave's own LDS updates are done (in-order LDS queue)
         for (int e = lane; e < TBL; e += 64) tbl_part[wrow * TBL + e] = tbl[e];
     }
+    // (a null key at index 4 .. 7 of its group of eight -- five or more extra keys -- sits in the accumulator rows of lane half 1)
+    dnb += __shfl_xor(dnb, 32, 64);
     if (dnull_part && hf == 0) dnull_part[wrow * 32 + l31] = dnb;
 }
 
@@ -858,7 +860,7 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
                                                                    const float* __restrict__ rel, const float* __restrict__ null_bias,
                                                                    const float* __restrict__ dout, const float* __restrict__ lse,
                                                                    const float* __restrict__ delta, float* __restrict__ dkv, int n, int h,
-                                                                   int E, int ns, int causal, float scale, int KW, int G, int relLds) {
+                                                                   int E, int ns, int causal, float scale, int KW, int G, int relLds, int EV) {
     constexpr int D = 32 * ND, ROW = D + 4, NPQ = 32 * D / 4 / 64;       // float4 pieces of a 32-row tile per lane
     extern __shared__ __attribute__((aligned(16))) float smem_dkv[];
     // XCD-aware block mapping: workgroups are dealt to the 8 XCDs round-robin by linear id.  All key-tile workgroups of a batch entry
@@ -895,8 +897,10 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
     }
     const int QW = perWave ? 1 : 4 / KW;                   // waves that share a key tile and split the query tiles
     const int kt = perWave ? bx : bx * KW + wave % KW, qw = perWave ? 0 : wave / KW;
-    // a lone null key (E == 1) is taken by the VALU (below) instead of costing a 32-key tile of its own
-    const int kbase = (E == 1) ? 1 : 0;
+    // EV (= E or 0) extra keys in front of the self keys -- the lone null key of the temporal attentions, context tokens + null key of the
+    // joint attentions -- are taken by the VALU (below), one by each of the first EV key tiles, instead of costing a 32-key tile of their
+    // own: 2048 + 5 keys were 65 tiles x 8 entries = 520 workgroups on 256 CUs, a third round for eight of them (2.84 vs 2.35 ms)
+    const int kbase = EV;
     const int j = kbase + kt * 32 + l31;                   // this lane's key (column)
     const bool jvalid = j < M;
     const int jc = jvalid ? j : M - 1;
@@ -922,8 +926,8 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
     for (int c = 0; c < ND; ++c)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dkt[c][i] = 0.f; dvt[c][i] = 0.f; }
-    const bool doNull = kbase && kt == 0;                  // wave-uniform: the waves of key tile 0 also own the null key row
-    const float* kv0 = kv + (size_t)g * M * 2 * D;         // the null key / value row
+    const bool doNull = kt < EV;                           // wave-uniform: the waves of key tile kt also own extra key row kt
+    const float* kv0 = kv + ((size_t)g * M + (doNull ? kt : 0)) * 2 * D;      // that key / value row
     // ... kept in the wave's LDS region: read from global memory inside the tile loop its loads queue BEHIND the next tile's prefetch,
     // and the `s_waitcnt vmcnt(0)` in front of their first use waits for that prefetch too (the temporal attentions, where every wave
     // owns the null key: 714 -> 505 us of this kernel were that wait and the scalar column sums below)
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
             s0 += __shfl_xor(s0, 32, 64);
             dp0 += __shfl_xor(dp0, 32, 64);
             const int rr = r0 + l31;
-            const float nbv0 = null_bias ? (tblLds ? NBs[min(rr, R - 1) % h] : null_bias[min(rr, R - 1) % h]) : 0.f;
+            const float nbv0 = (null_bias && kt == E - 1) ? (tblLds ? NBs[min(rr, R - 1) % h] : null_bias[min(rr, R - 1) % h]) : 0.f;      // (the null key is the last extra key)
             const float p0 = rr < R ? __expf(s0 * scale + nbv0 - Ls[l31]) : 0.f;
             const float ds0 = p0 * (dp0 - Dls[l31]);
             // lane = head-dim index: column sums over the 32 rows.  p0 / ds0 of row rq live in lane rq: broadcast through a scalar
@@ -1155,7 +1159,7 @@ __global__ __launch_bounds__(256, 1) void mqa_flash_bwd_dkv_kernel(const float* 
             }
     }
     if (qw == 0 && doNull && lane < D) {
-        float* og = dkv + (size_t)g * M * 2 * D;
+        float* og = dkv + ((size_t)g * M + kt) * 2 * D;
         og[lane] = dkn * scale;
         og[D + lane] = dvn;
     }
@@ -1541,7 +1545,7 @@ extern "C" int diqt_mqa_attention_bwd(const float* q, const float* kv, const flo
         const int relLds = rel ? TBL : 0;
         const int perw = (32 * d + 3 * 32 * (d + 4) + 64 + 2 * d + TBL + 255) / 256 * 256;
         const size_t lds = ((size_t)4 * perw + relLds + 64) * sizeof(float);
-        if (!noSeq && n_extra == 1 && n_self == n && n <= 32 && 32 % h == 0 && G >= 2048 && ob < (1ull << 31) && lds <= 160 * 1024) {
+        if (!noSeq && n_extra == 1 && n_self == n && n <= 32 && 32 % h == 0 && G >= 512 && ob < (1ull << 31) && lds <= 160 * 1024) {
             const int nwg = (G + 3) / 4 < 256 ? (G + 3) / 4 : 256;
             auto kern = d == 64 ? mqa_seq_bwd_kernel<2> : mqa_seq_bwd_kernel<1>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1584,7 +1588,9 @@ extern "C" int diqt_mqa_attention_bwd(const float* q, const float* kv, const flo
         if (rc) return rc;
     }
     {
-        const int Mt = M - (n_extra == 1 ? 1 : 0);              // keys that go through the MFMA tiles (a lone null key is VALU work)
+        // keys that go through the MFMA tiles: a lone null key, or a few extra keys in front of at least as many self-key tiles, are VALU work
+        const int EV = (n_extra == 1 || (n_extra >= 1 && n_extra <= 8 && n_extra <= (n_self + 31) / 32)) ? n_extra : 0;
+        const int Mt = M - EV;
         // key tiles per workgroup; the other 4 / KW waves split the query tiles.  Few batch entries (the joint 2048-token attentions:
         // G = 8) need the finer split to fill 256 CUs: every workgroup walks ALL query rows of its batch entry.
         int KW = Mt <= 32 ? 1 : (Mt <= 64 ? 2 : 4);
@@ -1605,7 +1611,7 @@ extern "C" int diqt_mqa_attention_bwd(const float* q, const float* kv, const flo
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "mqa_attention_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, kv, rel, null_bias, dout, lse, delta, dkv, n, h, n_extra, n_self, causal, scale, KW, G, relLds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, kv, rel, null_bias, dout, lse, delta, dkv, n, h, n_extra, n_self, causal, scale, KW, G, relLds, EV);
         return check_launch("mqa_attention_bwd(dkv)");
     }
 }

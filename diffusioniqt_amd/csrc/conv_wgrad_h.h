@@ -5,13 +5,13 @@
 namespace diqt {
 
 struct WHGeom {
-    int B, D, H, W, Cin, Cout, Do, Ho, Wo, pd, ph, pw;
+    int B, D, H, W, Cin, Cout, Do, Ho, Wo, pd, ph, pw, kd, kh, kw;
     int tilesD, tilesH, tilesW, MT, tilesPerSplit;
     int nCoB, nCiB, CoutPad;
     unsigned xBytes, yBytes;
 };
 
-// Does conv_wgrad_h_kernel take this shape (3x3x3, Cin % 32 == 0, tensors < 1 GiB)?  Fills the geometry and the split-K count (= slabs
+// Does conv_wgrad_h_kernel take this shape (3x3x3, 1x3x3 or 3x1x1; Cin % 32 == 0, tensors < 1 GiB)?  Fills the geometry and the split-K count (= slabs
 // written in the [slice][Cout][Cin][taps] layout that conv_reduce_dw3_kernel sums, + bias partials [slice][CoutPad]).
 bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                  int epd, int eph, int epw);

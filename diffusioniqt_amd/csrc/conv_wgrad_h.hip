@@ -1,4 +1,4 @@
-// Weight gradient of the stride-1 3x3x3 convolution with 16-bit MFMA operands (bf16 training, `ImagenTrainer(precision='bf16')`:
+// Weight gradient of the stride-1 3x3x3 / 1x3x3 / 3x1x1 convolutions with 16-bit MFMA operands (bf16 training, `ImagenTrainer(precision='bf16')`:
 // the reference's autocast backward computes the weight gradient in the forward's type, trainer.py:293-311):
 //   dW[co][ci][tap] = sum_v dY[v][co] * X[v + tap][ci]      M = co, N = ci, K = voxels, on v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate
 //
@@ -7,8 +7,8 @@
 // LDS images stay ROW-MAJOR [voxel][channel] -- exactly as staged from HBM, converted to 16 bit on the way -- and the fragments come out
 // of `ds_read_b64_tr_b16`: a 16-lane group reads 4 voxels x 16 channels and hands lane i channel i of the 4 voxels.  A filter tap is then a
 // whole-row offset in the halo image (no alignment constraints on the shifted reads).
-//   * 256 threads, one wave per SIMD; a workgroup owns 64 co x 32 ci x all 27 taps and walks a split-K range of 128-voxel tiles (2 x 4 x 16);
-//     wave w = (co half, tap parity): 14 / 13 accumulator tiles (224 AGPRs);
+//   * 256 threads, one wave per SIMD; a workgroup owns 64 co x 32 ci x all taps and walks a split-K range of 128-voxel tiles (2 x 4 x 16);
+//     wave w = (co half, tap parity): 14 / 13 accumulator tiles for 3x3x3 (224 AGPRs), 5 / 4 for 1x3x3, 2 / 1 for 3x1x1;
 //   * the next tile's dY rows and X halo rows are loaded global -> registers (range-checked buffer loads: zero padding, ragged tiles)
 //     before the current tile's MFMAs and converted + written to LDS behind them (two barriers per tile);
 //   * LDS rows: X 64 B (32 ci), dY 192 B (64 co + pad): the 4 rows x 2 channel blocks of a 32-lane half fall on disjoint bank groups;
@@ -31,12 +31,18 @@ typedef __attribute__((address_space(3))) s16x4w lds_s16x4w;
 
 constexpr unsigned WH_OOB = 0x80000000u;
 constexpr int WTD = 2, WTH = 4, WTW = 16, WMV = WTD * WTH * WTW;        // 128-voxel tile: 8 k-blocks of 16 voxels (one row of 16 along W)
-constexpr int WK = 3, WT = 27;
-constexpr int WHD = WTD + 2, WHH = WTH + 2, WHW = WTW + 2, WHV = WHD * WHH * WHW;    // 4 x 6 x 18 = 432 halo voxels
 constexpr int XROW = 64, YROW = 192;                                    // LDS row bytes
-constexpr int NPX = (WHV * 8 + 255) / 256, NPY = WMV * 16 / 256;        // float4 pieces per thread: 14 and 8
-constexpr int WH_LDS_TILE = WHV * XROW + WMV * YROW, WH_LDS_STAGE = 16 * 32 * WT * 4;
-constexpr int WH_LDS = WH_LDS_TILE > WH_LDS_STAGE ? WH_LDS_TILE : WH_LDS_STAGE;
+constexpr int NPY = WMV * 16 / 256;                                     // dY float4 pieces per thread: 8
+template <int KD, int KH, int KW>
+struct WHCfg {                                                          // 3x3x3: 4 x 6 x 18 = 432 halo voxels, 14 X pieces per thread
+    static constexpr int KD_ = KD, KH_ = KH, KW_ = KW;
+    static constexpr int T = KD * KH * KW, NA = (T + 1) / 2;            // taps, accumulator tiles of a wave (tap parity halves)
+    static constexpr int HD = WTD + KD - 1, HH = WTH + KH - 1, HW = WTW + KW - 1, HV = HD * HH * HW;
+    static constexpr int NPX = (HV * 8 + 255) / 256;
+    static constexpr int LDS_TILE = HV * XROW + WMV * YROW, LDS_STAGE = 16 * 32 * T * 4;
+    static constexpr int LDS = LDS_TILE > LDS_STAGE ? LDS_TILE : LDS_STAGE;
+    static constexpr int PD = NA < 5 ? NA : 5;                          // B fragments in flight ahead of their MFMA
+};
 
 // (by value: __builtin_bit_cast on a vector COMPONENT lvalue reads element 0 for every component on this hipcc, see conv_half.hip)
 __device__ __forceinline__ float wasf(unsigned u) { return __builtin_bit_cast(float, u); }
@@ -68,16 +74,17 @@ __device__ __forceinline__ u32x4w tr_frag(const unsigned char* p, int rowBytes) 
     return r;
 }
 
-template <bool BF>
+template <class C, bool BF>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ slabs, float* __restrict__ bias_part, WHGeom g) {
+    constexpr int WT = C::T, NA = C::NA, WHH = C::HH, WHW = C::HW, WHV = C::HV, NPX = C::NPX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
     unsigned char* Xs = smw;                         // [432][64 B]   halo voxels x 32 ci
     unsigned char* Ys = smw + WHV * XROW;            // [128][192 B]  tile voxels x 64 co
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hf = lane >> 5;
     const int ct = wave & 1, tpar = wave >> 1;       // co half, tap parity: taps tpar, tpar + 2, ...
-    const int NTW = tpar ? WT / 2 : (WT + 1) / 2;    // 13 / 14 taps
+    const int NTW = tpar ? WT / 2 : (WT + 1) / 2;    // 3x3x3: 13 / 14 taps
     int bx = blockIdx.x;
     const int cob = bx % g.nCoB; bx /= g.nCoB;
     const int cib = bx;
@@ -116,16 +123,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
     const unsigned char* aBase = Ys + (8 * hf + trq) * YROW + (32 * ct + 16 * trc + 4 * trp) * 2;
     const unsigned char* bBase = Xs + (8 * hf + trq) * XROW + (16 * trc + 4 * trp) * 2;
-    int tapOff[14];
+    int tapOff[NA];
 #pragma unroll
-    for (int i = 0; i < 14; ++i) {
+    for (int i = 0; i < NA; ++i) {
         const int t = min(2 * i + tpar, WT - 1);
-        tapOff[i] = (((t / 9) * WHH + (t / 3) % 3) * WHW + t % 3) * XROW;
+        tapOff[i] = (((t / (C::KH_ * C::KW_)) * WHH + (t / C::KW_) % C::KH_) * WHW + t % C::KW_) * XROW;
     }
 
-    f32x16 acc[14];
+    f32x16 acc[NA];
 #pragma unroll
-    for (int i = 0; i < 14; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -189,15 +196,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
             const unsigned char* bp = bBase + (((kb >> 2) * WHH + (kb & 3)) * WHW) * XROW;
             // the B fragments run PD taps ahead of their MFMA: an LDS read is ~150 cycles away, an MFMA 32 -- one tap ahead (what the
             // compiler makes of the plain loop) left every MFMA waiting for its own operands (57 % of the wave's cycles in s_waitcnt)
-            constexpr int PD = 5;
+            constexpr int PD = C::PD;
             u32x4w bq[PD];
 #pragma unroll
             for (int i = 0; i < PD; ++i) bq[i] = tr_frag(bp + tapOff[i], XROW);
 #pragma unroll
-            for (int i = 0; i < 14; ++i) {
-                if (i < NTW) {                                   // wave-uniform (13 or 14 taps)
+            for (int i = 0; i < NA; ++i) {
+                if (i < NTW) {                                   // wave-uniform (3x3x3: 13 or 14 taps)
                     const u32x4w b = bq[i % PD];
-                    if (i + PD < 14 && i + PD < NTW) bq[i % PD] = tr_frag(bp + tapOff[i + PD], XROW);
+                    if (i + PD < NA && i + PD < NTW) bq[i % PD] = tr_frag(bp + tapOff[(i + PD) % NA], XROW);
                     acc[i] = wmfma<BF>(a, b, acc[i]);
                 }
             }
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
     for (int r = 0; r < 4; ++r) {
         if (ct == (r >> 1)) {                               // wave-uniform: the two waves (tap parities) that hold these channels
 #pragma unroll
-            for (int i = 0; i < 14; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 if (i < NTW) {
                     const int tap = 2 * i + tpar;
 #pragma unroll
@@ -255,11 +262,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
 bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                  int epd, int eph, int epw) {
     static const bool off = [] { const char* e = getenv("DIQT_NO_WGRADH"); return e && e[0] == '1'; }();
-    if (off || kd != 3 || kh != 3 || kw != 3 || Cin % 32 != 0 || Cout % 4 != 0 || Cin < 32 || Cout < 32) return false;
+    const bool filt = (kd == 3 && kh == 3 && kw == 3) || (kd == 1 && kh == 3 && kw == 3) || (kd == 3 && kh == 1 && kw == 1);
+    if (off || !filt || Cin % 32 != 0 || Cout % 4 != 0 || Cin < 32 || Cout < 32) return false;
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || pd < 0 || ph < 0 || pw < 0 || pd > 16 || ph > 16 || pw > 16) return false;
     if (D > 255 || H > 255 || W > 255) return false;                   // packed 10-bit coordinate fields in the kernel
     g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.pd = pd; g.ph = ph; g.pw = pw;
-    g.Do = D + 2 * pd + epd - 2; g.Ho = H + 2 * ph + eph - 2; g.Wo = W + 2 * pw + epw - 2;
+    g.kd = kd; g.kh = kh; g.kw = kw;
+    g.Do = D + 2 * pd + epd - kd + 1; g.Ho = H + 2 * ph + eph - kh + 1; g.Wo = W + 2 * pw + epw - kw + 1;
     if (g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return false;
     g.tilesD = (g.Do + WTD - 1) / WTD; g.tilesH = (g.Ho + WTH - 1) / WTH; g.tilesW = (g.Wo + WTW - 1) / WTW;
     const long long mt = (long long)B * g.tilesD * g.tilesH * g.tilesW;
@@ -278,14 +287,21 @@ bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, in
     return true;
 }
 
-int wgradh_launch(const float* x, const float* dy, float* slabs, float* bias_part, const WHGeom& g, int ksplit, int bf16, void* stream) {
-    auto kern = bf16 ? conv_wgrad_h_kernel<true> : conv_wgrad_h_kernel<false>;
-    if (WH_LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS);
+template <class C>
+static int wgradh_launch_t(const float* x, const float* dy, float* slabs, float* bias_part, const WHGeom& g, int ksplit, int bf16, void* stream) {
+    auto kern = bf16 ? conv_wgrad_h_kernel<C, true> : conv_wgrad_h_kernel<C, false>;
+    if (C::LDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_bwd_weight_h: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, dim3(g.nCoB * g.nCiB, ksplit), dim3(256), WH_LDS, (hipStream_t)stream, x, dy, slabs, bias_part, g);
+    hipLaunchKernelGGL(kern, dim3(g.nCoB * g.nCiB, ksplit), dim3(256), C::LDS, (hipStream_t)stream, x, dy, slabs, bias_part, g);
     return check_launch("conv3d_bwd_weight_h");
+}
+
+int wgradh_launch(const float* x, const float* dy, float* slabs, float* bias_part, const WHGeom& g, int ksplit, int bf16, void* stream) {
+    if (g.kd == 3 && g.kh == 3) return wgradh_launch_t<WHCfg<3, 3, 3>>(x, dy, slabs, bias_part, g, ksplit, bf16, stream);
+    if (g.kd == 1) return wgradh_launch_t<WHCfg<1, 3, 3>>(x, dy, slabs, bias_part, g, ksplit, bf16, stream);
+    return wgradh_launch_t<WHCfg<3, 1, 1>>(x, dy, slabs, bias_part, g, ksplit, bf16, stream);
 }
 
 }  // namespace diqt

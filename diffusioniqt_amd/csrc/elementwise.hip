@@ -1224,6 +1224,26 @@ __global__ __launch_bounds__(256) void softmax_row_bwd_kernel(const float* __res
         for (int i = lane; i < n; i += 64) dx[r * n + i] = y[r * n + i] * (dy[r * n + i] - s);
     }
 }
+// few long rows (the backward of GlobalContext's softmax: 8 rows of 32768): one 1024-thread workgroup per row as in the forward -- a
+// wave per row took 250 us per call, four calls per Unet3D training micro-step
+__global__ __launch_bounds__(1024) void softmax_longrow_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                   float* __restrict__ dx, int n, float scale) {
+    __shared__ float sh[16];
+    const float* yr = y + (size_t)blockIdx.x * n;
+    const float* dr = dy + (size_t)blockIdx.x * n;
+    float* xr = dx + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float s = 0.f;
+    for (int i = tid; i < n; i += 1024) s += yr[i] * dr[i];
+    s = wave_sum(s);
+    if (lane == 0) sh[w] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += sh[k];
+    tot /= scale;
+    for (int i = tid; i < n; i += 1024) xr[i] = yr[i] * (dr[i] - tot);
+}
 // inner > 1 with few columns (LinearAttention's k.softmax(dim=-2): [b*h, n, d], imagen_pytorch3D.py:926-1016): one 1024-thread
 // workgroup per outer index, 1024/inner row groups stride over n with coalesced rows; column max / sum combined through LDS in a
 // fixed order.  (One thread per column left 512 threads walking 512 strided rows three times: 267 us per call on C4.)
@@ -2500,7 +2520,9 @@ extern "C" int diqt_softmax_bwd(const float* y, const float* dy, float* dx, size
     DIQT_REQUIRE(y && dy && dx, DIQT_E_ALIGN, "softmax_bwd: null pointer");
     DIQT_REQUIRE(n > 0 && inner > 0 && scale != 0.f, DIQT_E_SHAPE, "softmax_bwd: bad shape");
     if (outer == 0) return DIQT_OK;
-    if (inner == 1)
+    if (inner == 1 && outer <= 1024 && n >= 4096)
+        hipLaunchKernelGGL(softmax_longrow_bwd_kernel, dim3((unsigned)outer), dim3(1024), 0, STREAM, y, dy, dx, n, scale);
+    else if (inner == 1)
         hipLaunchKernelGGL(softmax_row_bwd_kernel, dim3(grid_for(outer, 4, 8192)), dim3(256), 0, STREAM, y, dy, dx, outer, n, scale);
     else
         hipLaunchKernelGGL(softmax_col_bwd_kernel, dim3(grid_for(outer * inner, 256)), dim3(256), 0, STREAM, y, dy, dx, outer, n, inner, scale);

@@ -460,8 +460,15 @@ def test_softmax_few_long_rows(ops):
     gen = torch.Generator().manual_seed(5)
     for rows, n in ((8, 32768), (3, 5000), (1, 4096)):
         x = torch.randn(rows, n, generator=gen) * 3
-        got = ops.softmax(x.to(DEV), dim=-1, scale=0.5)
-        close(got, 0.5 * torch.softmax(x.double(), dim=-1), tol=3e-5, what=f"softmax {rows}x{n}")
+        xd = x.to(DEV).requires_grad_()
+        got = ops.softmax(xd, dim=-1, scale=0.5)
+        xr = x.double().requires_grad_()
+        want = 0.5 * torch.softmax(xr, dim=-1)
+        close(got, want, tol=3e-5, what=f"softmax {rows}x{n}")
+        dy = torch.randn(rows, n, generator=gen)
+        want.backward(dy.double())
+        got.backward(dy.to(DEV))
+        close(xd.grad, xr.grad, tol=1e-4, what=f"softmax bwd {rows}x{n} (one workgroup per row)")
 
 
 def test_weighted_pool_global_context(ops):
@@ -533,11 +540,14 @@ def _mqa_ref(q, kv, rel, nb, n, h, d, E, causal, scale):
     (2, 33, 3, 32, 1, True, False),      # dim_head 32, heads that do not divide the wave, relative bias without mask
     (1, 150, 2, 32, 3, False, False),    # context tokens in front of the null key (E = 3): all keys through the tile loop; > 128 keys
     (2, 16, 8, 64, 2, True, True),       # E = 2 with bias and mask
+    (2, 170, 4, 64, 5, True, True),      # E = 5 in front of 6 key tiles: every extra key is VALU work of one of the first five tiles (null bias on the last)
+    (1, 70, 8, 64, 3, False, True),      # ... E = 3 = the number of key tiles, causal
     (300, 8, 2, 32, 1, True, True),      # more batch entries than resident workgroups: the persistent walk of the dQ kernel
     (2051, 12, 2, 32, 1, True, True),    # thousands of short sequences: the dK/dV kernel gives every WAVE a sequence (ragged last workgroup)
     (2048, 20, 4, 64, 1, False, False),  # ... dim_head 64, no bias / mask
     (2100, 32, 8, 64, 1, True, True),    # the temporal attention at its real shape: the one-pass short-sequence kernel (mqa_seq_bwd_kernel)
     (2300, 7, 2, 32, 1, True, False),    # ... ragged query tile (14 rows), bias without mask, dim_head 32
+    (515, 32, 8, 64, 1, True, True),     # ... the 8 x 8 level of Unet3D (512 sequences): fewer workgroups than CUs, ragged last workgroup
     (1, 1, 8, 64, 1, True, True)])
 def test_fused_mqa_attention_backward(ops, G, n, h, d, E, use_rel, causal):
     """diqt_mqa_attention_fwd_lse / diqt_mqa_attention_bwd (flash-style: no stored scores) against float64 autograd of the

@@ -451,39 +451,45 @@ def test_resnet_block_with_16_bit_tensors_between_its_blocks_is_bit_identical(mo
 
 
 @pytest.mark.parametrize("bf16", [1, 0])
-@pytest.mark.parametrize("B,D,H,W,Cin,Cout,pad,epad", [(2, 8, 8, 8, 32, 64, (1, 1, 1), (0, 0, 0)), (1, 9, 10, 19, 64, 72, (1, 1, 1), (0, 0, 0)),
-                                                        (3, 6, 8, 32, 96, 32, (1, 1, 1), (0, 0, 0)), (1, 10, 9, 18, 32, 40, (0, 0, 0), (0, 0, 0)),
-                                                        (8, 32, 32, 32, 64, 64, (1, 1, 1), (0, 0, 0))])
-def test_weight_gradient_on_the_16_bit_mfma(B, D, H, W, Cin, Cout, pad, epad, bf16):
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout,k,pad,epad", [
+    (2, 8, 8, 8, 32, 64, (3, 3, 3), (1, 1, 1), (0, 0, 0)), (1, 9, 10, 19, 64, 72, (3, 3, 3), (1, 1, 1), (0, 0, 0)),
+    (3, 6, 8, 32, 96, 32, (3, 3, 3), (1, 1, 1), (0, 0, 0)), (1, 10, 9, 18, 32, 40, (3, 3, 3), (0, 0, 0), (0, 0, 0)),
+    (8, 32, 32, 32, 64, 64, (3, 3, 3), (1, 1, 1), (0, 0, 0)),
+    # Family B's per-frame and temporal filters (imagen_video.py Conv3d: (1, k, k) then (k, 1, 1), the latter causal = one-sided padding)
+    (2, 5, 9, 18, 64, 64, (1, 3, 3), (0, 1, 1), (0, 0, 0)), (1, 3, 32, 32, 32, 96, (1, 3, 3), (0, 1, 1), (0, 0, 0)),
+    (2, 7, 6, 17, 64, 40, (3, 1, 1), (1, 0, 0), (0, 0, 0)), (1, 8, 16, 16, 96, 64, (3, 1, 1), (2, 0, 0), (-2, 0, 0)),
+    (1, 32, 64, 64, 64, 64, (1, 3, 3), (0, 1, 1), (0, 0, 0)), (1, 32, 64, 64, 64, 64, (3, 1, 1), (2, 0, 0), (-2, 0, 0))])
+def test_weight_gradient_on_the_16_bit_mfma(B, D, H, W, Cin, Cout, k, pad, epad, bf16):
     """diqt_conv3d_bwd_weight_h (conv_wgrad_h_kernel: row-major LDS images, transposing fragment reads): integer-valued operands are
     exact in bf16 / fp16 and their products sum exactly in fp32, so dW and dbias must be BIT-EXACT against float64 autograd -- this pins
-    the fragment layouts, tap offsets, padding, ragged tiles, the split-K slabs and the bias partials; random data: within the
-    rounding of the operands."""
+    the fragment layouts, tap offsets, padding (low = pad, high = pad + epad), ragged tiles, the split-K slabs and the bias partials;
+    random data: within the rounding of the operands."""
     from diffusioniqt_amd import ops, _lib
-    geo = (B, D, H, W, Cin, Cout, 3, 3, 3, *pad, *epad)
+    geo = (B, D, H, W, Cin, Cout, *k, *pad, *epad)
     nbytes = _lib.query("diqt_conv3d_bwd_weight_h_workspace_bytes", *geo)
     assert nbytes > 0
     g = torch.Generator().manual_seed(B * 7 + Cin)
     big = B * D * H * W > 100000
+    dy_shape = tuple([B] + [n + 2 * p + e - kk + 1 for n, p, e, kk in zip((D, H, W), pad, epad, k)] + [Cout])
+    fpad = (pad[2], pad[2] + epad[2], pad[1], pad[1] + epad[1], pad[0], pad[0] + epad[0])
     for kind in (("int",) if big else ("int", "rand")):
         if kind == "int":
             x = torch.randint(-3, 4, (B, D, H, W, Cin), generator=g).float()
-            dy_shape = (B, D + 2 * pad[0] - 2, H + 2 * pad[1] - 2, W + 2 * pad[2] - 2, Cout)
             dy = torch.randint(-2, 3, dy_shape, generator=g).float()
         else:
             x = torch.randn(B, D, H, W, Cin, generator=g)
-            dy = torch.randn(B, D + 2 * pad[0] - 2, H + 2 * pad[1] - 2, W + 2 * pad[2] - 2, Cout, generator=g)
+            dy = torch.randn(dy_shape, generator=g)
         dt = torch.bfloat16 if bf16 else torch.float16
         xr = x.to(dt).double().permute(0, 4, 1, 2, 3)
-        wr = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        wr = torch.zeros(Cout, Cin, *k, dtype=torch.float64, requires_grad=True)
         if big:      # float64 conv of 2 M voxels on the CPU is slow: check through linearity instead -- a random probe of dW
-            probe = torch.randint(-1, 2, (Cout, Cin, 3, 3, 3), generator=g).double()
-            yp = F.conv3d(F.pad(xr, (pad[2],) * 2 + (pad[1],) * 2 + (pad[0],) * 2), probe)
+            probe = torch.randint(-1, 2, (Cout, Cin, *k), generator=g).double()
+            yp = F.conv3d(F.pad(xr, fpad), probe)
             want_probe = (yp * dy.to(dt).double().permute(0, 4, 1, 2, 3)).sum().item()
         else:
-            yr = F.conv3d(F.pad(xr, (pad[2],) * 2 + (pad[1],) * 2 + (pad[0],) * 2), wr)
+            yr = F.conv3d(F.pad(xr, fpad), wr)
             yr.backward(dy.to(dt).double().permute(0, 4, 1, 2, 3))
-        dw = torch.empty(Cout, Cin, 3, 3, 3, device=DEV)
+        dw = torch.empty(Cout, Cin, *k, device=DEV)
         db = torch.empty(Cout, device=DEV)
         ws = torch.empty(nbytes // 4, device=DEV)
         _lib.call("diqt_conv3d_bwd_weight_h", x.to(DEV), dy.to(DEV), dw, db, ws, nbytes, *geo, bf16, torch.cuda.current_stream().cuda_stream)

@@ -1,15 +1,15 @@
-"""conv_wgrad_h_kernel vs conv_wgrad3_kernel on one shape.   python tools/wgradh_bench.py [B S Cin Cout]"""
+"""conv_wgrad_h_kernel vs conv_wgrad3_kernel on one shape.   python tools/wgradh_bench.py [B D S Cin Cout kd kh kw]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffusioniqt_amd import _lib
 _lib.load()
-B, S, Cin, Cout = (int(v) for v in sys.argv[1:5]) if len(sys.argv) > 4 else (8, 32, 64, 64)
-geo = (B, S, S, S, Cin, Cout, 3, 3, 3, 1, 1, 1, 0, 0, 0)
-x = torch.randn(B, S, S, S, Cin, device="cuda"); dy = torch.randn(B, S, S, S, Cout, device="cuda")
-dw = torch.empty(Cout, Cin, 3, 3, 3, device="cuda"); db = torch.empty(Cout, device="cuda")
+B, D, S, Cin, Cout, kd, kh, kw = (int(v) for v in sys.argv[1:9]) if len(sys.argv) > 8 else (8, 32, 32, 64, 64, 3, 3, 3)
+geo = (B, D, S, S, Cin, Cout, kd, kh, kw, kd // 2, kh // 2, kw // 2, 0, 0, 0)
+x = torch.randn(B, D, S, S, Cin, device="cuda"); dy = torch.randn(B, D, S, S, Cout, device="cuda")
+dw = torch.empty(Cout, Cin, kd, kh, kw, device="cuda"); db = torch.empty(Cout, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-fl = 2.0 * B * S ** 3 * Cin * Cout * 27
+fl = 2.0 * B * D * S * S * Cin * Cout * kd * kh * kw
 
 
 def timeit(fn, n=30):
@@ -30,4 +30,4 @@ n3 = _lib.query("diqt_conv3d_bwd_weight_workspace_bytes", *geo)
 ws3 = torch.empty(max(n3, 4) // 4, device="cuda")
 mh = timeit(lambda: _lib.call("diqt_conv3d_bwd_weight_h", x, dy, dw, db, wsh, nh, *geo, 1, st))
 m3 = timeit(lambda: _lib.call("diqt_conv3d_bwd_weight", x, dy, dw, db, ws3, n3, *geo, st))
-print(f"wgrad {B}x{S}^3 {Cin}->{Cout}: bf16 {mh * 1e3:.1f} us ({fl / mh / 1e9:.0f} TF/s)   fp32 {m3 * 1e3:.1f} us ({fl / m3 / 1e9:.0f} TF/s)  (each incl. the slab sum)")
+print(f"wgrad {B}x{D}x{S}^2 {Cin}->{Cout} ({kd},{kh},{kw}): bf16 {mh * 1e3:.1f} us ({fl / mh / 1e9:.0f} TF/s)   fp32 {m3 * 1e3:.1f} us ({fl / m3 / 1e9:.0f} TF/s)  (each incl. the slab sum)")

@@ -488,10 +488,17 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
         dts = timed(u3_edm, 1, 1)
         u3.train()
         dtt = timed(u3_train, 2, 4) / 4
+
+        def u3_train_bf16():      # what ImagenTrainer(precision='bf16') runs: autocast forward, backward in the forward's types
+            u3.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y3 = u3(hr, tb, lowres_cond_img=lr, lowres_noise_times=ltb)
+            y3.float().square().mean().backward()
+        dtb = timed(u3_train_bf16, 2, 4) / 4
         result["unet3d_edm"] = dict(eval_ms=1e3 * dte, eval_patches_per_s=world * B / dte,
                                     eval_tflops=GFLOP_U3_EVAL * B / (1e3 * dte), eval_frac_of_f32_mfma_peak=GFLOP_U3_EVAL * B / (1e3 * dte) / PEAK_F32_MFMA_TFLOPS,
                                     heun_steps=n3, unet_evals=2 * n3 - 1, ms_per_heun_step=1e3 * dts / n3, patch_steps_per_s=world * B * n3 / dts,
-                                    patch_evals_per_s=world * B * (2 * n3 - 1) / dts, fwd_bwd_ms=1e3 * dtt, fwd_bwd_patches_per_s=world * B / dtt,
+                                    patch_evals_per_s=world * B * (2 * n3 - 1) / dts, fwd_bwd_ms=1e3 * dtt, fwd_bwd_patches_per_s=world * B / dtt, fwd_bwd_bf16_ms=1e3 * dtb,
                                     fwd_bwd_frac_of_f32_mfma_peak=3 * GFLOP_U3_EVAL * B / (1e3 * dtt) / PEAK_F32_MFMA_TFLOPS)
         result["unet3d_roofline"] = roofline_of(summ3, PEAK_F32_MFMA_TFLOPS, step_ms=1e3 * dte, n_steps=2)
         del u3, elu3
@@ -583,8 +590,8 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
             out["train"]["ddp"] = ddp
     if "train_bf16" in result:
         out["train_bf16"] = r3(result["train_bf16"])
-        out["train_bf16"]["note"] = ("same micro-steps with ImagenTrainer(precision='bf16'): forward + backward-data on the bf16 MFMA kernel, "
-                                     "weight gradients / Adam / master weights fp32; reduced precision, NOT the headline")
+        out["train_bf16"]["note"] = ("same micro-steps with ImagenTrainer(precision='bf16'): forward, backward-data and weight gradients on the bf16 "
+                                     "MFMA kernels (fp32 accumulate), Adam / master weights fp32; reduced precision, NOT the headline")
     if "api_sample" in result:
         out["api_sample"] = r3(result["api_sample"])
         out["api_sample"]["note"] = "the same sampling through trainer.sample() (EMA swap, per-step host lists): the API delivers the hand-rolled loop's rate"

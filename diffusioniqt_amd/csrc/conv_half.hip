@@ -736,6 +736,129 @@ static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout
     return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Pointwise (1x1x1) convs with MANY output channels as a K-blocked GEMM (round 3).  The tap-oriented kernels above give a workgroup
+// 256 rows x 64 output channels: x is staged (and converted) once per 64 channels -- eight times for the 256 -> 512 query projection of
+// the joint attentions -- and a step has 4-8 MFMAs of a wave per barrier pair (106-157 TFLOP/s inside the C5 cascade).  Here a
+// workgroup of four waves (one per SIMD, accumulators in AGPRs) owns 256 rows x 32 NCT channels (128 or 256): wave w = rows 64 w .. + 63,
+// every channel tile; per 32-channel K chunk 4 NCT MFMAs of a wave (32 for NCT = 8) between two barriers; x (fp32 rows, converted while
+// staged) and the packed weight panel [chunk][co][32] are double-buffered in LDS, the next chunk's pieces in registers during the MFMAs.
+// The channel tiles of a row tile go to the SAME XCD (workgroup ids 8 apart), so x comes from HBM once.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct PwhGeom {
+    long long R;                 // rows (voxels)
+    int Cin, Cout, CoutPad, nChunks, nRowTiles, nCoTiles, roundOut;
+    unsigned xBytes, yBytes, wBytes;
+};
+
+template <bool BF, int NCT>
+__global__ __launch_bounds__(256, 1) void conv_pw_h_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
+                                                           const float* __restrict__ bias, const float* __restrict__ residual,
+                                                           float* __restrict__ y, PwhGeom g) {
+    constexpr int NTC = 32 * NCT, ABYTES = 256 * HROWB, BBYTES = NTC * HROWB;
+    constexpr int NPA = 8, NPB = NTC * 4 / 256;      // 16-byte pieces per thread and chunk: x (256 rows x 32 fp32), weights (NTC rows x 32 16-bit)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smpw[];
+    unsigned char* const As = smpw;                  // [2][256 rows][80 B]
+    unsigned char* const Bs = smpw + 2 * ABYTES;     // [2][NTC co][80 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const unsigned id = blockIdx.x;
+    const int coT = (int)((id >> 3) % (unsigned)g.nCoTiles);
+    const int rowT = (int)((id / (8u * (unsigned)g.nCoTiles)) * 8u + (id & 7u));
+    if (rowT >= g.nRowTiles) return;                 // (the whole workgroup: the grid is padded to eight row tiles per XCD round)
+    const long long r0 = (long long)rowT * 256;
+    const int n0 = coT * NTC;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.xBytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wp), 0, (int)g.wBytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)g.yBytes, 0x00020000);
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
+
+    unsigned aoff[NPA], boff[NPB];
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+        const int idx = u * 256 + tid, row = idx >> 3, q = idx & 7;
+        aoff[u] = r0 + row < g.R ? (unsigned)((r0 + row) * g.Cin * 4 + q * 16) : HBUF_OOB;
+    }
+#pragma unroll
+    for (int u = 0; u < NPB; ++u) {
+        const int idx = u * 256 + tid, co = idx >> 2, q = idx & 3;
+        boff[u] = n0 + co < g.CoutPad ? (unsigned)(((n0 + co) * HCK + q * 8) * 2) : HBUF_OOB;
+    }
+    const unsigned wChunk = (unsigned)g.CoutPad * HCK * 2;      // bytes of one chunk's weight panel
+
+    f32x16 acc[2][NCT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+
+    u32x4 pa[NPA], pb[NPB];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < NPA; ++u) pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, aoff[u] + (unsigned)c * (HCK * 4), 0, 0);
+#pragma unroll
+        for (int u = 0; u < NPB; ++u) pb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, boff[u] + (unsigned)c * wChunk, 0, 0);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NPA; ++u) {
+            const int idx = u * 256 + tid, row = idx >> 3, q = idx & 7;
+            u32x2 p;
+            p.x = pack2<BF>(asf(pa[u].x), asf(pa[u].y));
+            p.y = pack2<BF>(asf(pa[u].z), asf(pa[u].w));
+            *reinterpret_cast<u32x2*>(As + buf * ABYTES + row * HROWB + q * 8) = p;
+        }
+#pragma unroll
+        for (int u = 0; u < NPB; ++u) {
+            const int idx = u * 256 + tid, co = idx >> 2, q = idx & 3;
+            *reinterpret_cast<u32x4*>(Bs + buf * BBYTES + co * HROWB + q * 16) = pb[u];
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < g.nChunks; ++c) {
+        const bool more = c + 1 < g.nChunks;
+        if (more) gload(c + 1);                      // in flight behind this chunk's MFMAs
+        const unsigned char* ap = As + (c & 1) * ABYTES + (64 * wave + l31) * HROWB + h * 16;
+        const unsigned char* bp = Bs + (c & 1) * BBYTES + l31 * HROWB + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + ks * 32), a1 = *reinterpret_cast<const u32x4*>(ap + 32 * HROWB + ks * 32);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const u32x4 b = *reinterpret_cast<const u32x4*>(bp + ct * 32 * HROWB + ks * 32);
+                acc[0][ct] = mfma16<BF>(a0, b, acc[0][ct]);
+                acc[1][ct] = mfma16<BF>(a1, b, acc[1][ct]);
+            }
+        }
+        if (more) lstore((c + 1) & 1);               // the other buffer: every wave left it before the previous barrier
+        __syncthreads();
+    }
+    // ---- epilogue: D[row = voxel][col = co], row = (r & 3) + 8 (r >> 2) + 4 h of the wave's row tile ----
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int co = n0 + 32 * ct + l31;
+        const bool cok = co < g.Cout;
+        const float bv = (bias && cok) ? bias[co] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = r0 + 64 * wave + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const unsigned off = (cok && row < g.R) ? (unsigned)((row * g.Cout + co) * 4) : HBUF_OOB;
+                float v = acc[rt][ct][r] + bv;
+                if (g.roundOut) v = round_through<BF>(v);
+                if (residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off, 0, 0));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, off, 0, 0);
+            }
+        }
+    }
+}
+
 }  // namespace diqt
 
 using namespace diqt;
@@ -835,6 +958,38 @@ extern "C" int diqt_conv3d_fwd_h_stats_blocks(int B, int D, int H, int W, int Ci
     return convh_persistent_takes(g, nwg) ? g.tilesD * g.tilesH * g.tilesW * (convh_four_waves(g, x_half != 0) ? 4 : 8) : 0;
 }
 
+
+// pointwise convs with more than 64 output channels, fp32 rows at both ends: the K-blocked GEMM (conv_pw_h_kernel)
+static bool pwh_takes(const HalfGeom& g, bool xh, bool yh, const float* stats) {
+    static const bool off = [] { const char* e = getenv("DIQT_NO_PWH"); return e && e[0] == '1'; }();
+    if (off || xh || yh || stats) return false;
+    if (g.kd * g.kh * g.kw != 1 || g.pd || g.ph || g.pw || g.Do != g.D || g.Ho != g.H || g.Wo != g.W) return false;
+    if (g.Cin % HCK != 0 || g.Cin < 64 || g.Cout <= HNT) return false;
+    const long long rows = (long long)g.B * g.D * g.H * g.W;
+    return rows >= 2048 && rows * g.Cin * 4 < (1ll << 31) && rows * g.Cout * 4 < (1ll << 31);
+}
+static int pwh_launch(const float* x, const unsigned short* wp, const float* bias, const float* residual, float* y, const HalfGeom& g, int bf16,
+                      hipStream_t s) {
+    PwhGeom p;
+    p.R = (long long)g.B * g.D * g.H * g.W;
+    p.Cin = g.Cin; p.Cout = g.Cout; p.CoutPad = g.CoutPad; p.nChunks = g.Cin / HCK; p.roundOut = g.roundOut;
+    p.xBytes = (unsigned)(p.R * g.Cin * 4); p.yBytes = (unsigned)(p.R * g.Cout * 4);
+    p.wBytes = (unsigned)((size_t)p.nChunks * g.CoutPad * HCK * 2);
+    const int nct = g.Cout >= 256 ? 8 : 4;
+    p.nRowTiles = (int)((p.R + 255) / 256);
+    p.nCoTiles = (g.Cout + 32 * nct - 1) / (32 * nct);
+    const unsigned grid = (unsigned)((p.nRowTiles + 7) / 8 * 8) * (unsigned)p.nCoTiles;
+    const size_t lds = (size_t)2 * 256 * HROWB + (size_t)2 * 32 * nct * HROWB;
+    typedef void (*KP)(const float*, const unsigned short*, const float*, const float*, float*, PwhGeom);
+    const KP kp = nct == 8 ? (bf16 ? conv_pw_h_kernel<true, 8> : conv_pw_h_kernel<false, 8>) : (bf16 ? conv_pw_h_kernel<true, 4> : conv_pw_h_kernel<false, 4>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h(pointwise): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kp, dim3(grid), dim3(256), lds, s, x, wp, bias, residual, y, p);
+    return check_launch("conv3d_fwd_h(pointwise)");
+}
+
 static int convh_launch(const void* x, const void* packed_h, const float* bias, const float* residual, void* y, int B, int D, int H, int W,
                         int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, int bf16,
                         int round_out, bool xh, bool yh, float* stats, void* stream) {
@@ -844,6 +999,8 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
     DIQT_REQUIRE(half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, xh ? 2 : 4, yh ? 2 : 4), DIQT_E_UNSUPPORTED,
                  "conv3d_fwd_h: shape not supported by the low-precision kernel (diqt_conv3d_fwd_h_supported == 0)");
     g.roundOut = round_out ? 1 : 0;
+    if (pwh_takes(g, xh, yh, stats))
+        return pwh_launch(static_cast<const float*>(x), static_cast<const unsigned short*>(packed_h), bias, residual, static_cast<float*>(y), g, bf16, (hipStream_t)stream);
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
     static const bool dbg_on = [] { const char* e = getenv("DIQT_CONVH_DBG"); return e && e[0] == '1'; }();
     if (dbg_on && nwg <= 65536 && !xh && !yh) {

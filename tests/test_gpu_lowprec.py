@@ -503,3 +503,31 @@ def test_weight_gradient_on_the_16_bit_mfma(B, D, H, W, Cin, Cout, k, pad, epad,
         else:
             assert (dw.cpu().double() - wr.grad).abs().max().item() <= 2e-5 * wr.grad.abs().max().item()
             assert (db.cpu().double() - db_ref).abs().max().item() <= 1e-5 * db_ref.abs().max().item()
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("rows,Cin,Cout,res", [(2048 + 77, 64, 128, False), (4096, 256, 512, True), (2500, 96, 192, False),
+                                               (3000, 128, 384, True), (2304, 512, 256, False)])
+def test_pointwise_conv_with_many_output_channels_as_a_gemm(rows, Cin, Cout, res, bf16):
+    """conv_pw_h_kernel (behind diqt_conv3d_fwd_h: 1x1x1, Cin % 32 == 0, Cout > 64, >= 2048 rows): 256 rows x 128 / 256 channels per
+    workgroup, K-blocked.  Integer-valued operands are exact in fp16 / bf16 and sum exactly in fp32, so the result -- rounded once to the
+    operand type, then the fp32 residual added -- must be BIT-EXACT against float64: pins the fragment layouts, the double-buffered
+    staging, ragged row tiles, channel tiles past Cout / CoutPad and the XCD-aware tile mapping."""
+    from diffusioniqt_amd import _lib
+    g = torch.Generator().manual_seed(rows + Cin)
+    dt = torch.bfloat16 if bf16 else torch.float16
+    x = torch.randint(-3, 4, (1, 1, 1, rows, Cin), generator=g).float()
+    w = torch.randint(-2, 3, (Cout, Cin, 1, 1, 1), generator=g).float()
+    b = torch.randint(-4, 5, (Cout,), generator=g).float()
+    r = torch.randn(1, 1, 1, rows, Cout, generator=g) if res else None
+    st = torch.cuda.current_stream().cuda_stream
+    n = _lib.query("diqt_conv_packed_h_elems", Cout, Cin, 1, 1, 1)
+    packed = torch.empty(n, dtype=torch.int16, device=DEV)
+    _lib.call("diqt_conv_pack_weight_h", w.to(DEV), packed, Cout, Cin, 1, 1, 1, 0, bf16, st)
+    y = torch.full((1, 1, 1, rows, Cout), float('nan'), device=DEV)
+    _lib.call("diqt_conv3d_fwd_h", x.to(DEV), packed, b.to(DEV), r.to(DEV) if res else None, y, 1, 1, 1, rows, Cin, Cout, 1, 1, 1,
+              0, 0, 0, 0, 0, 0, bf16, 1, st)
+    want = (x.double().reshape(rows, Cin) @ w.double().reshape(Cout, Cin).T + b.double()).to(dt).float()
+    if res:
+        want = want + r.reshape(rows, Cout)
+    assert torch.equal(y.cpu().reshape(rows, Cout), want), (y.cpu().reshape(rows, Cout) - want).abs().max()

@@ -741,8 +741,8 @@ static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout
 // Pointwise (1x1x1) convs with MANY output channels as a K-blocked GEMM (round 3).  The tap-oriented kernels above give a workgroup
 // 256 rows x 64 output channels: x is staged (and converted) once per 64 channels -- eight times for the 256 -> 512 query projection of
 // the joint attentions -- and a step has 4-8 MFMAs of a wave per barrier pair (106-157 TFLOP/s inside the C5 cascade).  Here a
-// workgroup of four waves (one per SIMD, accumulators in AGPRs) owns 256 rows x 32 NCT channels (128 or 256): wave w = rows 64 w .. + 63,
-// every channel tile; per 32-channel K chunk 4 NCT MFMAs of a wave (32 for NCT = 8) between two barriers; x (fp32 rows, converted while
+// workgroup of four waves (two workgroups per CU) owns 256 rows x 32 NCT = 128 channels: wave w = rows 64 w .. + 63, every channel
+// tile; per 32-channel K chunk 4 NCT = 16 MFMAs of a wave between two barriers; x (fp32 rows, converted while
 // staged) and the packed weight panel [chunk][co][32] are double-buffered in LDS, the next chunk's pieces in registers during the MFMAs.
 // The channel tiles of a row tile go to the SAME XCD (workgroup ids 8 apart), so x comes from HBM once.
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -753,7 +753,7 @@ struct PwhGeom {
 };
 
 template <bool BF, int NCT>
-__global__ __launch_bounds__(256, 1) void conv_pw_h_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
+__global__ __launch_bounds__(256, 2) void conv_pw_h_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
                                                            const float* __restrict__ bias, const float* __restrict__ residual,
                                                            float* __restrict__ y, PwhGeom g) {
     constexpr int NTC = 32 * NCT, ABYTES = 256 * HROWB, BBYTES = NTC * HROWB;
@@ -975,13 +975,16 @@ static int pwh_launch(const float* x, const unsigned short* wp, const float* bia
     p.Cin = g.Cin; p.Cout = g.Cout; p.CoutPad = g.CoutPad; p.nChunks = g.Cin / HCK; p.roundOut = g.roundOut;
     p.xBytes = (unsigned)(p.R * g.Cin * 4); p.yBytes = (unsigned)(p.R * g.Cout * 4);
     p.wBytes = (unsigned)((size_t)p.nChunks * g.CoutPad * HCK * 2);
-    const int nct = g.Cout >= 256 ? 8 : 4;
+    // 128 channels per workgroup, TWO workgroups per CU (230 registers): one's loads and stores run under the other's MFMAs.  256 channels at
+    // one workgroup per CU (accumulators in AGPRs) stage x half as often but measure slower on every shape of the cascade (121 vs 117 us
+    // for 256 -> 512 on 131072 rows, 264 vs 208 us for 128 -> 128 on 1 M rows): a chunk step there lasts as long as its loads' latency
+    constexpr int nct = 4;
     p.nRowTiles = (int)((p.R + 255) / 256);
     p.nCoTiles = (g.Cout + 32 * nct - 1) / (32 * nct);
     const unsigned grid = (unsigned)((p.nRowTiles + 7) / 8 * 8) * (unsigned)p.nCoTiles;
     const size_t lds = (size_t)2 * 256 * HROWB + (size_t)2 * 32 * nct * HROWB;
     typedef void (*KP)(const float*, const unsigned short*, const float*, const float*, float*, PwhGeom);
-    const KP kp = nct == 8 ? (bf16 ? conv_pw_h_kernel<true, 8> : conv_pw_h_kernel<false, 8>) : (bf16 ? conv_pw_h_kernel<true, 4> : conv_pw_h_kernel<false, 4>);
+    const KP kp = bf16 ? conv_pw_h_kernel<true, nct> : conv_pw_h_kernel<false, nct>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h(pointwise): hipFuncSetAttribute: %s", hipGetErrorString(e));

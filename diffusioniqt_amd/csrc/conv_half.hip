@@ -749,15 +749,22 @@ static bool half_geom(HalfGeom& g, int B, int D, int H, int W, int Cin, int Cout
 struct PwhGeom {
     long long R;                 // rows (voxels)
     int Cin, Cout, CoutPad, nChunks, nRowTiles, nCoTiles, roundOut;
+    int T, pd, HW, D;            // taps along the frame axis (1 or kd), their low pad, rows per frame, frames
     unsigned xBytes, yBytes, wBytes;
 };
 
-template <bool BF, int NCT>
+// The same kernel takes the (kd,1,1) TEMPORAL convs of the pseudo-3D blocks (imagen_video.py Conv3d: kernel (k,1,1) after the per-frame
+// conv): in channels-last rows a frame shift is a shift by H W rows, so K = taps x Cin with the A rows of K step (chunk, tap) read
+// (tap - pad) H W rows away (zero where the frame index leaves the volume: causal / symmetric padding); the packed weights
+// [chunk][tap][co][32] are already in that K order.  XH: x rows are 16-bit (copied verbatim).
+template <bool BF, int NCT, bool XH>
 __global__ __launch_bounds__(256, 2) void conv_pw_h_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
                                                            const float* __restrict__ bias, const float* __restrict__ residual,
                                                            float* __restrict__ y, PwhGeom g) {
     constexpr int NTC = 32 * NCT, ABYTES = 256 * HROWB, BBYTES = NTC * HROWB;
-    constexpr int NPA = 8, NPB = NTC * 4 / 256;      // 16-byte pieces per thread and chunk: x (256 rows x 32 fp32), weights (NTC rows x 32 16-bit)
+    constexpr int XE = XH ? 2 : 4;
+    constexpr int NPA = XH ? 4 : 8, NPB = NTC * 4 / 256;      // 16-byte pieces per thread and K step: x (256 rows x 32 ci), weights (NTC rows x 32 ci)
+    constexpr int PSH = XH ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smpw[];
     unsigned char* const As = smpw;                  // [2][256 rows][80 B]
     unsigned char* const Bs = smpw + 2 * ABYTES;     // [2][NTC co][80 B]
@@ -775,17 +782,21 @@ __global__ __launch_bounds__(256, 2) void conv_pw_h_kernel(const float* __restri
     const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0, residual ? (int)g.yBytes : 0, 0x00020000);
 
     unsigned aoff[NPA], boff[NPB];
+    int afr[NPA];                                    // frame index of the piece's row (-1000: no row)
 #pragma unroll
     for (int u = 0; u < NPA; ++u) {
-        const int idx = u * 256 + tid, row = idx >> 3, q = idx & 7;
-        aoff[u] = r0 + row < g.R ? (unsigned)((r0 + row) * g.Cin * 4 + q * 16) : HBUF_OOB;
+        const int idx = u * 256 + tid, row = idx >> PSH, q = idx & ((1 << PSH) - 1);
+        const bool ok = r0 + row < g.R;
+        aoff[u] = ok ? (unsigned)((r0 + row) * g.Cin * XE + q * 16) : HBUF_OOB;
+        afr[u] = ok ? (int)(((r0 + row) / g.HW) % g.D) : -1000;
     }
 #pragma unroll
     for (int u = 0; u < NPB; ++u) {
         const int idx = u * 256 + tid, co = idx >> 2, q = idx & 3;
         boff[u] = n0 + co < g.CoutPad ? (unsigned)(((n0 + co) * HCK + q * 8) * 2) : HBUF_OOB;
     }
-    const unsigned wChunk = (unsigned)g.CoutPad * HCK * 2;      // bytes of one chunk's weight panel
+    const unsigned wStep = (unsigned)g.CoutPad * HCK * 2;      // bytes of one (chunk, tap) weight panel
+    const int frameBytes = g.HW * g.Cin * XE;
 
     f32x16 acc[2][NCT];
 #pragma unroll
@@ -796,20 +807,29 @@ __global__ __launch_bounds__(256, 2) void conv_pw_h_kernel(const float* __restri
             for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
 
     u32x4 pa[NPA], pb[NPB];
-    auto gload = [&](int c) {
+    auto gload = [&](int st, int chunk, int tap) {
+        const int sh = tap - g.pd;                   // frames
 #pragma unroll
-        for (int u = 0; u < NPA; ++u) pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, aoff[u] + (unsigned)c * (HCK * 4), 0, 0);
+        for (int u = 0; u < NPA; ++u) {
+            const int f = afr[u] + sh;
+            const unsigned off = (f >= 0 && f < g.D) ? aoff[u] + (unsigned)(sh * frameBytes) + (unsigned)chunk * (HCK * XE) : HBUF_OOB;
+            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+        }
 #pragma unroll
-        for (int u = 0; u < NPB; ++u) pb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, boff[u] + (unsigned)c * wChunk, 0, 0);
+        for (int u = 0; u < NPB; ++u) pb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, boff[u] + (unsigned)st * wStep, 0, 0);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < NPA; ++u) {
-            const int idx = u * 256 + tid, row = idx >> 3, q = idx & 7;
-            u32x2 p;
-            p.x = pack2<BF>(asf(pa[u].x), asf(pa[u].y));
-            p.y = pack2<BF>(asf(pa[u].z), asf(pa[u].w));
-            *reinterpret_cast<u32x2*>(As + buf * ABYTES + row * HROWB + q * 8) = p;
+            const int idx = u * 256 + tid, row = idx >> PSH, q = idx & ((1 << PSH) - 1);
+            if constexpr (XH) {
+                *reinterpret_cast<u32x4*>(As + buf * ABYTES + row * HROWB + q * 16) = pa[u];
+            } else {
+                u32x2 p;
+                p.x = pack2<BF>(asf(pa[u].x), asf(pa[u].y));
+                p.y = pack2<BF>(asf(pa[u].z), asf(pa[u].w));
+                *reinterpret_cast<u32x2*>(As + buf * ABYTES + row * HROWB + q * 8) = p;
+            }
         }
 #pragma unroll
         for (int u = 0; u < NPB; ++u) {
@@ -817,14 +837,19 @@ __global__ __launch_bounds__(256, 2) void conv_pw_h_kernel(const float* __restri
             *reinterpret_cast<u32x4*>(Bs + buf * BBYTES + co * HROWB + q * 16) = pb[u];
         }
     };
-    gload(0);
+    const int nSteps = g.nChunks * g.T;
+    int nchunk = 0, ntap = 0;                        // (chunk, tap) of the step being prefetched
+    gload(0, 0, 0);
     lstore(0);
     __syncthreads();
-    for (int c = 0; c < g.nChunks; ++c) {
-        const bool more = c + 1 < g.nChunks;
-        if (more) gload(c + 1);                      // in flight behind this chunk's MFMAs
-        const unsigned char* ap = As + (c & 1) * ABYTES + (64 * wave + l31) * HROWB + h * 16;
-        const unsigned char* bp = Bs + (c & 1) * BBYTES + l31 * HROWB + h * 16;
+    for (int st = 0; st < nSteps; ++st) {
+        const bool more = st + 1 < nSteps;
+        if (more) {                                  // in flight behind this step's MFMAs
+            if (++ntap == g.T) { ntap = 0; ++nchunk; }
+            gload(st + 1, nchunk, ntap);
+        }
+        const unsigned char* ap = As + (st & 1) * ABYTES + (64 * wave + l31) * HROWB + h * 16;
+        const unsigned char* bp = Bs + (st & 1) * BBYTES + l31 * HROWB + h * 16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const u32x4 a0 = *reinterpret_cast<const u32x4*>(ap + ks * 32), a1 = *reinterpret_cast<const u32x4*>(ap + 32 * HROWB + ks * 32);
@@ -835,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_h_kernel(const float* __restri
                 acc[1][ct] = mfma16<BF>(a1, b, acc[1][ct]);
             }
         }
-        if (more) lstore((c + 1) & 1);               // the other buffer: every wave left it before the previous barrier
+        if (more) lstore((st + 1) & 1);              // the other buffer: every wave left it before the previous barrier
         __syncthreads();
     }
     // ---- epilogue: D[row = voxel][col = co], row = (r & 3) + 8 (r >> 2) + 4 h of the wave's row tile ----
@@ -846,14 +871,25 @@ __global__ __launch_bounds__(256, 2) void conv_pw_h_kernel(const float* __restri
         const float bv = (bias && cok) ? bias[co] : 0.f;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
+            // residual: the 16 loads of a tile in flight before the first add (a load + wait + add per element serialises 16 L2 round trips)
+            unsigned offs[16];
+            float rr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long row = r0 + 64 * wave + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const unsigned off = (cok && row < g.R) ? (unsigned)((row * g.Cout + co) * 4) : HBUF_OOB;
+                offs[r] = (cok && row < g.R) ? (unsigned)((row * g.Cout + co) * 4) : HBUF_OOB;
+                rr[r] = 0.f;
+            }
+            if (residual) {                          // kernel-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, offs[r], 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 float v = acc[rt][ct][r] + bv;
                 if (g.roundOut) v = round_through<BF>(v);
-                if (residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off, 0, 0));
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, off, 0, 0);
+                v += rr[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, offs[r], 0, 0);
             }
         }
     }
@@ -962,35 +998,38 @@ extern "C" int diqt_conv3d_fwd_h_stats_blocks(int B, int D, int H, int W, int Ci
 // pointwise convs with more than 64 output channels, fp32 rows at both ends: the K-blocked GEMM (conv_pw_h_kernel)
 static bool pwh_takes(const HalfGeom& g, bool xh, bool yh, const float* stats) {
     static const bool off = [] { const char* e = getenv("DIQT_NO_PWH"); return e && e[0] == '1'; }();
-    if (off || xh || yh || stats) return false;
-    if (g.kd * g.kh * g.kw != 1 || g.pd || g.ph || g.pw || g.Do != g.D || g.Ho != g.H || g.Wo != g.W) return false;
-    if (g.Cin % HCK != 0 || g.Cin < 64 || g.Cout <= HNT) return false;
+    static const bool notemporal = [] { const char* e = getenv("DIQT_NO_PWH_T"); return e && e[0] == '1'; }();
+    if (off || yh || stats) return false;
+    if (g.kh != 1 || g.kw != 1 || g.ph || g.pw || g.Do != g.D || g.Ho != g.H || g.Wo != g.W) return false;
+    if (g.Cin % HCK != 0 || g.Cin < 64) return false;
     const long long rows = (long long)g.B * g.D * g.H * g.W;
-    return rows >= 2048 && rows * g.Cin * 4 < (1ll << 31) && rows * g.Cout * 4 < (1ll << 31);
+    if (rows < 2048 || rows * g.Cin * (xh ? 2 : 4) >= (1ll << 31) || rows * g.Cout * 4 >= (1ll << 31)) return false;
+    if (g.kd == 1) return !xh && g.pd == 0 && g.Cout > HNT;          // pointwise: fp32 rows, more than one 64-channel block
+    return !notemporal && xh && g.kd <= 4 && g.pd < g.kd && g.Cout >= 32;      // temporal: the 16-bit output of the per-frame conv
 }
-static int pwh_launch(const float* x, const unsigned short* wp, const float* bias, const float* residual, float* y, const HalfGeom& g, int bf16,
-                      hipStream_t s) {
+static int pwh_launch(const void* x, const unsigned short* wp, const float* bias, const float* residual, float* y, const HalfGeom& g, int bf16,
+                      bool xh, hipStream_t s) {
     PwhGeom p;
     p.R = (long long)g.B * g.D * g.H * g.W;
     p.Cin = g.Cin; p.Cout = g.Cout; p.CoutPad = g.CoutPad; p.nChunks = g.Cin / HCK; p.roundOut = g.roundOut;
-    p.xBytes = (unsigned)(p.R * g.Cin * 4); p.yBytes = (unsigned)(p.R * g.Cout * 4);
-    p.wBytes = (unsigned)((size_t)p.nChunks * g.CoutPad * HCK * 2);
+    p.T = g.kd; p.pd = g.pd; p.HW = g.kd == 1 ? 1 : g.H * g.W; p.D = g.kd == 1 ? 1 : g.D;
+    p.xBytes = (unsigned)(p.R * g.Cin * (xh ? 2 : 4)); p.yBytes = (unsigned)(p.R * g.Cout * 4);
+    p.wBytes = (unsigned)((size_t)p.nChunks * p.T * g.CoutPad * HCK * 2);
     // 128 channels per workgroup, TWO workgroups per CU (230 registers): one's loads and stores run under the other's MFMAs.  256 channels at
     // one workgroup per CU (accumulators in AGPRs) stage x half as often but measure slower on every shape of the cascade (121 vs 117 us
     // for 256 -> 512 on 131072 rows, 264 vs 208 us for 128 -> 128 on 1 M rows): a chunk step there lasts as long as its loads' latency
-    constexpr int nct = 4;
+    const int nct = g.Cout > 64 ? 4 : 2;
     p.nRowTiles = (int)((p.R + 255) / 256);
     p.nCoTiles = (g.Cout + 32 * nct - 1) / (32 * nct);
     const unsigned grid = (unsigned)((p.nRowTiles + 7) / 8 * 8) * (unsigned)p.nCoTiles;
     const size_t lds = (size_t)2 * 256 * HROWB + (size_t)2 * 32 * nct * HROWB;
     typedef void (*KP)(const float*, const unsigned short*, const float*, const float*, float*, PwhGeom);
-    const KP kp = bf16 ? conv_pw_h_kernel<true, nct> : conv_pw_h_kernel<false, nct>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h(pointwise): hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(kp, dim3(grid), dim3(256), lds, s, x, wp, bias, residual, y, p);
-    return check_launch("conv3d_fwd_h(pointwise)");
+    const KP kp = xh ? (nct == 4 ? (bf16 ? conv_pw_h_kernel<true, 4, true> : conv_pw_h_kernel<false, 4, true>)
+                                 : (bf16 ? conv_pw_h_kernel<true, 2, true> : conv_pw_h_kernel<false, 2, true>))
+                     : (nct == 4 ? (bf16 ? conv_pw_h_kernel<true, 4, false> : conv_pw_h_kernel<false, 4, false>)
+                                 : (bf16 ? conv_pw_h_kernel<true, 2, false> : conv_pw_h_kernel<false, 2, false>));
+    hipLaunchKernelGGL(kp, dim3(grid), dim3(256), lds, s, static_cast<const float*>(x), wp, bias, residual, y, p);
+    return check_launch("conv3d_fwd_h(gemm)");
 }
 
 static int convh_launch(const void* x, const void* packed_h, const float* bias, const float* residual, void* y, int B, int D, int H, int W,
@@ -1003,7 +1042,7 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
                  "conv3d_fwd_h: shape not supported by the low-precision kernel (diqt_conv3d_fwd_h_supported == 0)");
     g.roundOut = round_out ? 1 : 0;
     if (pwh_takes(g, xh, yh, stats))
-        return pwh_launch(static_cast<const float*>(x), static_cast<const unsigned short*>(packed_h), bias, residual, static_cast<float*>(y), g, bf16, (hipStream_t)stream);
+        return pwh_launch(x, static_cast<const unsigned short*>(packed_h), bias, residual, static_cast<float*>(y), g, bf16, xh, (hipStream_t)stream);
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
     static const bool dbg_on = [] { const char* e = getenv("DIQT_CONVH_DBG"); return e && e[0] == '1'; }();
     if (dbg_on && nwg <= 65536 && !xh && !yh) {

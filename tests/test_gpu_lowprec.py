@@ -531,3 +531,31 @@ def test_pointwise_conv_with_many_output_channels_as_a_gemm(rows, Cin, Cout, res
     if res:
         want = want + r.reshape(rows, Cout)
     assert torch.equal(y.cpu().reshape(rows, Cout), want), (y.cpu().reshape(rows, Cout) - want).abs().max()
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout,pd,epd,res", [(2, 5, 16, 16, 64, 64, 2, -2, False), (1, 8, 16, 20, 96, 160, 1, 0, True),
+                                                          (2, 3, 32, 32, 128, 128, 2, -2, True), (1, 7, 20, 19, 64, 32, 2, -2, False)])
+def test_temporal_conv_as_a_gemm_over_shifted_rows(B, D, H, W, Cin, Cout, pd, epd, res, bf16):
+    """The (3,1,1) temporal conv of a pseudo-3D block on conv_pw_h_kernel (16-bit x rows from the per-frame conv, fp32 y): K = taps x Cin,
+    the rows of tap t read (t - pad) H W rows away, zero outside the volume (causal: pad (2, 0); symmetric: (1, 1)).  Integer-valued data:
+    BIT-EXACT against float64 conv3d, rounded once to the operand type, fp32 residual added after."""
+    from diffusioniqt_amd import _lib
+    g = torch.Generator().manual_seed(B * 100 + D)
+    dt = torch.bfloat16 if bf16 else torch.float16
+    x = torch.randint(-3, 4, (B, D, H, W, Cin), generator=g).float()
+    w = torch.randint(-2, 3, (Cout, Cin, 3, 1, 1), generator=g).float()
+    b = torch.randint(-4, 5, (Cout,), generator=g).float()
+    r = torch.randn(B, D, H, W, Cout, generator=g) if res else None
+    st = torch.cuda.current_stream().cuda_stream
+    geo = (B, D, H, W, Cin, Cout, 3, 1, 1, pd, 0, 0, epd, 0, 0)
+    n = _lib.query("diqt_conv_packed_h_elems", Cout, Cin, 3, 1, 1)
+    packed = torch.empty(n, dtype=torch.int16, device=DEV)
+    _lib.call("diqt_conv_pack_weight_h", w.to(DEV), packed, Cout, Cin, 3, 1, 1, 0, bf16, st)
+    y = torch.full((B, D, H, W, Cout), float('nan'), device=DEV)
+    _lib.call("diqt_conv3d_fwd_h_io", x.to(DEV).to(dt), packed, b.to(DEV), r.to(DEV) if res else None, y, *geo, bf16, 1, 1, 0, None, st)
+    xr = F.pad(x.double().permute(0, 4, 1, 2, 3), (0, 0, 0, 0, pd, pd + epd))
+    want = (F.conv3d(xr, w.double()) + b.double().view(1, -1, 1, 1, 1)).permute(0, 2, 3, 4, 1).to(dt).float()
+    if res:
+        want = want + r
+    assert torch.equal(y.cpu(), want), (y.cpu() - want).abs().max()

@@ -507,7 +507,7 @@ def test_weight_gradient_on_the_16_bit_mfma(B, D, H, W, Cin, Cout, k, pad, epad,
 
 @pytest.mark.parametrize("bf16", [0, 1])
 @pytest.mark.parametrize("rows,Cin,Cout,res", [(2048 + 77, 64, 128, False), (4096, 256, 512, True), (2500, 96, 192, False),
-                                               (3000, 128, 384, True), (2304, 512, 256, False)])
+                                               (3000, 128, 384, True), (2304, 512, 256, False), (2100, 128, 64, True), (4000, 64, 40, False)])
 def test_pointwise_conv_with_many_output_channels_as_a_gemm(rows, Cin, Cout, res, bf16):
     """conv_pw_h_kernel (behind diqt_conv3d_fwd_h: 1x1x1, Cin % 32 == 0, Cout > 64, >= 2048 rows): 256 rows x 128 channels per
     workgroup, K-blocked.  Integer-valued operands are exact in fp16 / bf16 and sum exactly in fp32, so the result -- rounded once to the

@@ -23,6 +23,9 @@ P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_longlong
 PROTOTYPES = {
     "diqt_version": (I, []),
     "diqt_last_error": (c_char_p, []),
+    "diqt_census_enable": (I, [I]),
+    "diqt_census_count": (L, [c_char_p]),
+    "diqt_get_last_launch": (c_char_p, []),
     "diqt_conv_packed_elems": (Z, [I, I, I, I, I]),
     "diqt_conv_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),
     "diqt_conv3d_fwd": (I, [P, P, P, P, P] + [I] * 15 + [P]),
@@ -93,6 +96,9 @@ PROTOTYPES = {
     "diqt_mse_clamp_fwd": (I, [P, P, P, P, F, I, P, P, I, Z, P]),
     "diqt_mse_clamp_bwd": (I, [P, P, P, F, I, F, P, I, Z, P]),
     "diqt_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, F, F, I, P]),
+    "diqt_grad_norm_workspace_bytes": (Z, []),
+    "diqt_grad_norm_clip": (I, [P, Z, F, P, P, P]),
+    "diqt_adam_step_scaled": (I, [P, P, P, P, Z] + [F] * 7 + [I, P, P]),
     "diqt_ema_lerp": (I, [P, P, Z, F, P]),
     "diqt_softmax_fwd": (I, [P, P, Z, I, I, F, P]),
     "diqt_softmax_bwd": (I, [P, P, P, Z, I, I, F, P]),
@@ -200,6 +206,7 @@ def call(name, *args):
 
 
 _memo = {}
+SWITCH_EPOCH = 0      # counts diqt_set_* calls: a captured hipGraph froze the kernels the switches selected (graphs.py keys on it)
 
 
 def query(name, *args):
@@ -208,6 +215,8 @@ def query(name, *args):
     three or four of them, and launch-bound steps (744 launches per bf16 training micro-step) pay for every ctypes round trip.  Any
     ``diqt_set_*`` call (a switch changes) empties the memo; ``diqt_get_*`` is never cached."""
     if name.startswith("diqt_set_"):
+        global SWITCH_EPOCH
+        SWITCH_EPOCH += 1
         _memo.clear()
         return getattr(load(), name)(*args)
     if name.startswith("diqt_get_"):
@@ -220,3 +229,28 @@ def query(name, *args):
         return v
     except TypeError:                                    # an unhashable argument: not a shape query
         return getattr(load(), name)(*args)
+
+
+class census:
+    """``with _lib.census() as c: ...; c.count("conv3d_fwd_h(persistent)")`` -- launches of the library inside the block, by tag
+    substring (diqt_census_*): the parity suite asserts which kernels a network really dispatched."""
+
+    def __enter__(self):
+        self._was = load().diqt_census_enable(1)
+        self._frozen = None
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        self._frozen = {}
+        lib.diqt_census_enable(0)
+        self._lib = lib
+        return False
+
+    def count(self, substr=None):
+        # counters stay readable after the block (enable(0) stops counting, it does not clear)
+        return int(load().diqt_census_count(substr.encode() if substr is not None else None))
+
+
+def last_launch():
+    return load().diqt_get_last_launch().decode()

@@ -9,8 +9,12 @@
 namespace diqt {
 
 void set_error(const char* fmt, ...);
+// launch census (lib.cpp): every launch passes its tag here -- remembered per thread (diqt_get_last_launch) and, while
+// diqt_census_enable(1), counted per tag (diqt_census_count): the parity suite asserts which kernels a network really dispatched
+void census_note(const char* what);
 
 inline int check_launch(const char* what) {
+    census_note(what);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("%s: %s", what, hipGetErrorString(e));

@@ -1125,12 +1125,45 @@ __global__ __launch_bounds__(256) void mse_clamp_bwd_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // optimiser
 // ---------------------------------------------------------------------------------------------
+// global gradient-norm clipping (accelerator.clip_grad_norm_ = torch.nn.utils.clip_grad_norm_, trainer.py:1054) over the flat gradient
+// arena: stage 1 = per-workgroup sums of squares in a fixed order (fp32 per thread, fp64 across the workgroup), stage 2 = one workgroup
+// sums the partials in fp64 and writes out[0] = total L2 norm, out[1] = min(1, max_norm / (norm + 1e-6)) -- the factor adam_kernel
+// multiplies every gradient with (torch multiplies the gradients in place; they are consumed and zeroed by the same Adam pass here)
+constexpr int kNormBlocks = 1024;
+__global__ __launch_bounds__(256) void gradnorm_stage1_kernel(const float* __restrict__ g, size_t n, double* __restrict__ part) {
+    __shared__ double sh[4];
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+    double d = (double)acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void gradnorm_stage2_kernel(const double* __restrict__ part, int nb, float max_norm, float* __restrict__ out) {
+    __shared__ double sh[4];
+    double d = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) d += part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        out[0] = norm;
+        out[1] = fminf(max_norm / (norm + 1e-6f), 1.f);
+    }
+}
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2,
-                                                   float eps, float wd, float bc1, float bc2_sqrt, int zero_grad) {
+                                                   float eps, float wd, float bc1, float bc2_sqrt, int zero_grad,
+                                                   const float* __restrict__ gscale) {
     const float step = lr / bc1;
+    const float gs = gscale ? gscale[0] : 1.f;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float gi = g[i];
+        if (gscale) gi *= gs;
         const float pi = p[i];
         if (wd != 0.f) gi += wd * pi;
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // lerp, as torch's exp_avg.lerp_
@@ -2484,8 +2517,27 @@ extern "C" int diqt_adam_step(float* param, float* grad, float* exp_avg, float* 
     if (n == 0) return DIQT_OK;
     DIQT_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, DIQT_E_SHAPE, "adam_step: bad bias correction");
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, STREAM, param, grad, exp_avg, exp_avg_sq, n,
-                       lr, beta1, beta2, eps, weight_decay, bias_correction1, sqrtf(bias_correction2), zero_grad);
+                       lr, beta1, beta2, eps, weight_decay, bias_correction1, sqrtf(bias_correction2), zero_grad, (const float*)nullptr);
     return check_launch("adam_step");
+}
+extern "C" int diqt_adam_step_scaled(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                                     float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
+                                     int zero_grad, const float* grad_scale, void* stream) {
+    DIQT_REQUIRE(param && grad && exp_avg && exp_avg_sq && grad_scale, DIQT_E_ALIGN, "adam_step_scaled: null pointer");
+    if (n == 0) return DIQT_OK;
+    DIQT_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, DIQT_E_SHAPE, "adam_step_scaled: bad bias correction");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, STREAM, param, grad, exp_avg, exp_avg_sq, n,
+                       lr, beta1, beta2, eps, weight_decay, bias_correction1, sqrtf(bias_correction2), zero_grad, grad_scale);
+    return check_launch("adam_step(scaled)");
+}
+extern "C" size_t diqt_grad_norm_workspace_bytes(void) { return (size_t)kNormBlocks * sizeof(double); }
+extern "C" int diqt_grad_norm_clip(const float* grad, size_t n, float max_norm, void* workspace, float* out2, void* stream) {
+    DIQT_REQUIRE(grad && workspace && out2, DIQT_E_ALIGN, "grad_norm_clip: null pointer");
+    DIQT_REQUIRE(max_norm > 0.f, DIQT_E_SHAPE, "grad_norm_clip: max_norm must be positive");
+    const int nb = (int)grid_for(n ? n : 1, 256, kNormBlocks);
+    hipLaunchKernelGGL(gradnorm_stage1_kernel, dim3(nb), dim3(256), 0, STREAM, grad, n, static_cast<double*>(workspace));
+    hipLaunchKernelGGL(gradnorm_stage2_kernel, dim3(1), dim3(256), 0, STREAM, static_cast<const double*>(workspace), nb, max_norm, out2);
+    return check_launch("grad_norm_clip");
 }
 extern "C" int diqt_multi_accumulate(float* dst, const long long* table, int count, int blocks_per_tensor, void* stream) {
     DIQT_REQUIRE(dst && table, DIQT_E_ALIGN, "multi_accumulate: null pointer");

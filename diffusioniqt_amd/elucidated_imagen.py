@@ -173,15 +173,16 @@ class ElucidatedImagen(nn.Module):
         return kw
 
     def preconditioned_network_forward(self, unet_forward, noised_images, sigma, *, sigma_data, clamp=False,
-                                       dynamic_threshold=True, **kwargs):
-        """:329-358 with per-batch sigma as a host float or a CPU/GPU [B] tensor."""
+                                       dynamic_threshold=True, _replay=True, **kwargs):
+        """:329-358 with per-batch sigma as a host float or a CPU/GPU [B] tensor.  ``_replay=False``: never through the hipGraph cache
+        (the no-grad self-conditioning pre-pass of a TRAINING step: its weights change every optimiser step, a capture would be retired at once)."""
         B = noised_images.shape[0]
         dev = noised_images.device
         sig = torch.full((B,), float(sigma)) if isinstance(sigma, float) else sigma.detach().float().cpu()
         cin, cskip, cout = (f(sigma_data, sig).to(dev) for f in (self.c_in, self.c_skip, self.c_out))
         x_in = ops.axpby3(noised_images.contiguous(), None, None, cin, None, None)
         owner = getattr(unet_forward, '__self__', None)
-        if owner is not None and not torch.is_grad_enabled():
+        if _replay and owner is not None and not torch.is_grad_enabled():
             # sampling: after two eager calls the U-Net evaluation replays as a hipGraph (the small stages of a cascade are launch-bound)
             net_out = self._graphs.run(owner, unet_forward, (x_in, self.c_noise(sig).to(dev)), kwargs)
         else:
@@ -359,10 +360,15 @@ class ElucidatedImagen(nn.Module):
         ukw = {**self._unet_kwargs(unet, lowres_cond_img, lowres_noise_cond), **kwargs}
         if exists(cond_images):                                                   # image conditioning of the U-Net (:718, 844)
             ukw['cond_images'] = cond_images.to(device).float()
-        if getattr(inner, 'self_cond', False) and random() < 0.5:
-            # self-conditioning (:847-860): half of the steps first estimate x0 without gradients and feed it back
+        # self-conditioning (:847-860): half of the steps first estimate x0 without gradients and feed it back.  The reference's gate
+        # `self_cond = unet.module.self_cond if DDP else unet` (:849) is always truthy for an un-wrapped U-Net, so it consumes one
+        # `random()` per call whether or not the U-Net self-conditions (a U-Net without the option ignores the estimate): the draw is
+        # mirrored so Python's RNG stream matches, the wasted pre-pass is not
+        draw = random() if (not hasattr(unet, 'module') or getattr(inner, 'self_cond', False)) else 1.
+        if getattr(inner, 'self_cond', False) and draw < 0.5:
             with torch.no_grad():
-                pred_x0 = self.preconditioned_network_forward(unet.forward, noised, sig, sigma_data=hp.sigma_data, **ukw).detach()
+                pred_x0 = self.preconditioned_network_forward(unet.forward, noised, sig, sigma_data=hp.sigma_data, _replay=False,
+                                                              **ukw).detach()
             ukw['self_cond'] = pred_x0
         net_out = unet.forward(x_in, self.c_noise(sig).to(device), **ukw)
         target = ops.axpby3(images, noised, None, (1. / cout).to(device), (-cskip / cout).to(device), None)

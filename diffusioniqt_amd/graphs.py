@@ -16,10 +16,14 @@ import time
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 ENABLED = os.environ.get("DIQT_GRAPHS", "1") != "0"
 FORCE = os.environ.get("DIQT_GRAPHS") == "2"       # capture whether or not the evaluation is launch-bound (tests)
+
+
+class _Uncapturable(Exception):
+    """An argument the key cannot describe by value (an arbitrary object): such a call stays eager -- ``id()`` can be reused after GC."""
 
 
 def _sig(v):
@@ -27,7 +31,9 @@ def _sig(v):
         return ("T", tuple(v.shape), v.dtype, v.device.index)
     if isinstance(v, (list, tuple)):
         return tuple(_sig(x) for x in v)
-    return v if isinstance(v, (int, float, bool, str, type(None))) else ("O", id(v))
+    if isinstance(v, (int, float, bool, str, type(None))):
+        return v
+    raise _Uncapturable(type(v).__name__)
 
 
 class GraphCache:
@@ -36,21 +42,42 @@ class GraphCache:
         self.warm, self.max_entries = warm, max_entries
         self.replays = 0                                 # diagnostics / tests
 
+    def _drop(self, keys):
+        n = sum(1 for k in keys if self.entries.pop(k)["graph"] is not None)
+        if n:
+            ops.graphs_alive(-n)                         # the last graph gone: ops releases what the host caches retired meanwhile
+
     def clear(self):
-        self.entries.clear()
+        self._drop(list(self.entries))
+
+    def __del__(self):
+        try:
+            self.clear()
+        except Exception:                                # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def run(self, owner, fn, args, kwargs):
         """``fn(*args, **kwargs)`` -- eagerly the first ``warm`` times a (module, shapes, precision, parameter versions) combination is seen,
         through a captured graph afterwards.  ``owner``: the nn.Module whose parameters ``fn`` reads."""
-        if not ENABLED or torch.is_grad_enabled() or not args[0].is_cuda:
+        if not ENABLED or torch.is_grad_enabled() or not args[0].is_cuda or ops.TIMER.enabled:   # timer on: its events must not be captured
             return fn(*args, **kwargs)
         params = list(owner.parameters())
-        key = (id(owner), ops.lp_mode(), ops._WEIGHT_EPOCH, sum(p._version for p in params), params[0].data_ptr() if params else 0,
-               _sig(args), tuple(sorted((k, _sig(v)) for k, v in kwargs.items())))
+        bufs = list(owner.buffers())
+        # what the captured launches depend on besides the inputs: the parameters (version counters; the fused optimiser and any raw-pointer
+        # write bump ops._WEIGHT_EPOCH), train / eval mode, buffers, the compute type and the library's run-time switches
+        state = (ops.lp_mode(), ops._WEIGHT_EPOCH, _lib.SWITCH_EPOCH, bool(owner.training), sum(p._version for p in params),
+                 sum(b._version for b in bufs), params[0].data_ptr() if params else 0)
+        try:
+            key = (id(owner), state, _sig(args), tuple(sorted((k, _sig(v)) for k, v in kwargs.items())))
+        except _Uncapturable:
+            return fn(*args, **kwargs)
         ent = self.entries.get(key)
         if ent is None:
-            if len(self.entries) >= self.max_entries:    # stale keys (older parameter versions, other shapes): drop them and their pools
-                self.entries.clear()
+            # entries of this module captured under another state (older weights, other switches) can never be hit again: drop them now,
+            # so their pools and whatever ops.retire() parked for them are released
+            self._drop([k for k in self.entries if k[0] == key[0] and k[1] != state])
+            if len(self.entries) >= self.max_entries:
+                self.clear()
             ent = self.entries[key] = dict(calls=0, graph=None, failed=False)
         if ent["failed"]:
             return fn(*args, **kwargs)
@@ -104,6 +131,7 @@ class GraphCache:
             with torch.cuda.graph(g):
                 out = fn(*s_args, **s_kwargs)
             ent.update(graph=g, args=s_args, kwargs=s_kwargs, out=out)
+            ops.graphs_alive(+1)
         except Exception as e:                           # noqa: BLE001 -- capture refused (an op that synchronises): stay eager for this key
             torch.cuda.synchronize()
             ent["failed"] = True

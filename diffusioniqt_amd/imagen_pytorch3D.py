@@ -386,6 +386,7 @@ class BatchedTimeMLPs:
         key = tuple((l.weight.data_ptr(), l.weight._version, l.bias._version if l.bias is not None else -1) for l in self.linears) \
             + (ops._WEIGHT_EPOCH,)
         if key != self.key:
+            ops.retire(self.w, self.b)
             with torch.no_grad():
                 self.w = torch.cat([l.weight for l in self.linears], dim=0).contiguous()
                 self.b = torch.cat([l.bias if l.bias is not None else torch.zeros(l.weight.shape[0], device=l.weight.device)

@@ -196,15 +196,23 @@ class DynamicPositionBias(nn.Module):
         # parameter changes (the reference re-runs the MLP in every attention call of every U-Net evaluation: 7 small kernels each)
         cache = not torch.is_grad_enabled()
         if cache:
-            key = (n, str(device), ops._WEIGHT_EPOCH) + tuple((p.data_ptr(), p._version) for p in self.parameters())
-            hit = getattr(self, '_table', None)
-            if hit is not None and hit[0] == key:
-                return hit[1]
+            # one table per (n, device) for as long as the parameters are unchanged: a captured hipGraph holds a table's address, so a
+            # call with another frame count must not replace (and free) the one an earlier capture reads
+            wkey = (ops._WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+            tabs = getattr(self, '_tables', None)
+            if tabs is None or tabs[0] != wkey:
+                if tabs is not None:
+                    ops.retire(*tabs[1].values())
+                tabs = self._tables = (wkey, {})
+            key = (n, str(device))
+            hit = tabs[1].get(key)
+            if hit is not None:
+                return hit
         pos = torch.arange(-n + 1, n, device=device, dtype=torch.float32).unsqueeze(-1)
         for layer in self.mlp:
             pos = layer(pos)
         if cache:
-            self._table = (key, pos)
+            tabs[1][key] = pos
         return pos
 
 
@@ -250,10 +258,12 @@ class Attention(nn.Module):
         lp = ops.lp_mode()
         ws = (self.to_q.weight, self.to_kv.weight, self.to_out[0].weight)
         key = (lp, ops._WEIGHT_EPOCH) + tuple((w.data_ptr(), w._version) for w in ws)
-        hit = getattr(self, '_packed_h', None)
+        packs = self.__dict__.setdefault('_packed_h', {})                      # one pack per operand type (a graph may hold either)
+        hit = packs.get(lp)
         if hit is None or hit[0] != key:
-            hit = (key, ops.pack_temporal_attention_h(*ws, self.heads, self.dim_head, self.scale, lp))
-            self._packed_h = hit
+            if hit is not None:
+                ops.retire(*hit[1])
+            hit = packs[lp] = (key, ops.pack_temporal_attention_h(*ws, self.heads, self.dim_head, self.scale, lp))
         rel = null_bias = None
         if exists(self.rel_pos_bias):
             rel = self.rel_pos_bias(x.shape[1], x.device).contiguous()

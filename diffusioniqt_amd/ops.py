@@ -21,6 +21,27 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH += 1
 
 
+# A captured hipGraph (graphs.py) holds raw device addresses of everything its launches read: besides the tensors of its private pool
+# also what the host side had cached BEFORE the capture (packed weights, position-bias tables, the scratch arena).  When such a cache
+# replaces its tensor while a graph is alive the old one is parked here instead of being freed, until the last graph is gone.
+_GRAPH_PINS = []
+_LIVE_GRAPHS = 0
+
+
+def retire(*tensors):
+    """A host-side cache is dropping these device tensors: keep them alive while any captured graph may still address them."""
+    if _LIVE_GRAPHS > 0:
+        _GRAPH_PINS.extend(t for t in tensors if t is not None)
+
+
+def graphs_alive(delta):
+    """graphs.py: ``delta`` graphs were captured (+) or dropped (-)."""
+    global _LIVE_GRAPHS
+    _LIVE_GRAPHS = max(_LIVE_GRAPHS + delta, 0)
+    if _LIVE_GRAPHS == 0:
+        _GRAPH_PINS.clear()
+
+
 def set_gnbwd_fuse(on: bool) -> bool:
     """Switches the GroupNorm-backward reduction between its own pass (False, the default) and the epilogue of the conv's
     backward-data launch (True; ``diqt_conv3d_fwd_gnbwd``).  Returns the previous setting.  Both are product paths and the parity
@@ -131,6 +152,7 @@ def _workspace(nbytes, device):
     key = device.index
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
+        retire(ws)                                        # a captured graph may hold the old arena's address
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = ws
     return ws
@@ -163,6 +185,8 @@ def _packed(weight5, mode):
     n = _lib.query("diqt_conv_packed_elems", eff[0], eff[1], kd, kh, kw)
     packed = torch.empty(n, dtype=torch.float32, device=weight5.device)
     _lib.call("diqt_conv_pack_weight", weight5.detach(), packed, Cout, Cin, kd, kh, kw, mode, _stream())
+    if hit is not None:
+        retire(hit[1])
     cache[mode] = (key, packed)
     return packed
 
@@ -187,6 +211,8 @@ def _packed_h(weight5, bf16, mode=0):
     n = _lib.query("diqt_conv_packed_h_elems", eff[0], eff[1], kd, kh, kw)
     packed = torch.empty(n, dtype=torch.int16, device=weight5.device)
     _lib.call("diqt_conv_pack_weight_h", weight5.detach(), packed, Cout, Cin, kd, kh, kw, mode, bf16, _stream())
+    if hit is not None:
+        retire(hit[1])
     cache[slot] = (key, packed)
     return packed
 
@@ -1867,13 +1893,31 @@ def mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=None, kind='l2'):
 # --------------------------------------------------------------------------------------------
 # optimiser
 # --------------------------------------------------------------------------------------------
-def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, zero_grad=True):
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, zero_grad=True, grad_scale=None):
+    """Fused Adam over a flat arena.  ``grad_scale``: device scalar every gradient is multiplied with first (the clip coefficient of
+    ``grad_norm_clip``)."""
     _chk(param, grad, exp_avg, exp_avg_sq)
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
-    _lib.call("diqt_adam_step", param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),
-              float(eps), float(weight_decay), float(bc1), float(bc2), int(zero_grad), _stream())
+    if grad_scale is None:
+        _lib.call("diqt_adam_step", param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),
+                  float(eps), float(weight_decay), float(bc1), float(bc2), int(zero_grad), _stream())
+    else:
+        _chk(grad_scale)
+        _lib.call("diqt_adam_step_scaled", param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),
+                  float(eps), float(weight_decay), float(bc1), float(bc2), int(zero_grad), grad_scale, _stream())
     bump_weight_epoch()
+
+
+def grad_norm_clip(grad_flat, max_norm):
+    """torch.nn.utils.clip_grad_norm_ over a flat gradient arena WITHOUT touching it: returns a device tensor [total L2 norm,
+    min(1, max_norm / (norm + 1e-6))]; the coefficient goes to ``adam_step(grad_scale=out[1:])``, which consumes the gradients."""
+    _chk(grad_flat)
+    nb = _lib.query("diqt_grad_norm_workspace_bytes")
+    ws = _workspace(nb, grad_flat.device)
+    out = torch.empty(2, dtype=torch.float32, device=grad_flat.device)
+    _lib.call("diqt_grad_norm_clip", grad_flat, grad_flat.numel(), float(max_norm), ws, out, _stream())
+    return out
 
 
 def multi_accumulate(dst_flat, srcs, offsets):

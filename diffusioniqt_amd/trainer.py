@@ -20,6 +20,7 @@ from collections.abc import Iterable
 import numpy as np
 import torch
 from torch import nn
+from torch.optim.lr_scheduler import CosineAnnealingLR, LambdaLR
 from torch.utils.data import DataLoader, random_split
 
 from . import ops
@@ -181,13 +182,27 @@ class FusedAdam:
             self._load_into_arena(self._pending_state)
             self._pending_state = None
 
-    def step(self):
+    def step(self, max_grad_norm=None):
+        """One Adam step over the arena, fused with zero_grad.  ``max_grad_norm``: the reference's clip in front of the step
+        (trainer.py:1054, torch's clip_grad_norm_): one norm reduction over the flat gradients, the coefficient is applied inside the
+        Adam pass (the gradients are consumed and zeroed there, so scaling them in place would be a wasted pass)."""
         assert self.arena is not None, 'optimizer used before the trainer prepared the unet'
         g = self.param_groups[0]
         self.step_count += 1
         self.stateful |= self.arena.touched
+        coef = None
+        if max_grad_norm is not None:
+            self.last_grad_norm = ops.grad_norm_clip(self.arena.grad, max_grad_norm)     # [norm, coefficient] on the device
+            coef = self.last_grad_norm[1:]
         ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0],
-                      g['betas'][1], g['eps'], g['weight_decay'], self.step_count, zero_grad=True)
+                      g['betas'][1], g['eps'], g['weight_decay'], self.step_count, zero_grad=True, grad_scale=coef)
+
+    def clip_accumulated(self, max_grad_norm):
+        """The reference clips in EVERY ``update`` call (trainer.py:1054 has no sync check): on an accumulation micro-step that rescales
+        the gradients accumulated so far, in place, before the next micro-step adds to them (pinned by trainerA_trace_opts.npz)."""
+        self.last_grad_norm = ops.grad_norm_clip(self.arena.grad, max_grad_norm)
+        g = self.arena.grad
+        g.copy_(ops.axpby3(g.view(1, -1), None, None, self.last_grad_norm[1:], None, None).view(-1))
 
     def zero_grad(self, set_to_none=False):
         if self.arena is not None:
@@ -227,6 +242,52 @@ class FusedAdam:
             self._pending_state = sd
         else:
             self._load_into_arena(sd)
+
+
+class _LrCarrier(torch.optim.SGD):
+    """A real ``torch.optim.Optimizer`` whose only job is to hold the learning rate: torch's own ``CosineAnnealingLR`` / ``LambdaLR``
+    (what the reference constructs, trainer.py:368-375) run on it unchanged, and ``ImagenTrainer.update`` copies its lr into the fused
+    Adam's param group.  It owns one dummy parameter and never steps it."""
+
+    def __init__(self, lr):
+        super().__init__([torch.nn.Parameter(torch.zeros(1))], lr=lr)
+
+
+class _LinearWarmup:
+    """``pytorch_warmup.LinearWarmup`` 0.1.1 (trainer.py:372, 1065) restated from its published algorithm -- the package is absent from
+    this image and from the reference tree, so this part is **parity unpinned**: the learning rate is damped by
+    ``omega(step) = min(1, (step + 1) / warmup_period)``; construction damps once (step 0); ``dampening()`` restores the undamped rates,
+    lets the wrapped scheduler act, remembers the new rates and damps them for the next step."""
+
+    def __init__(self, optimizer, warmup_period):
+        assert isinstance(warmup_period, int) and warmup_period > 0
+        self.optimizer, self.warmup_period = optimizer, warmup_period
+        self.last_step = -1
+        self.lrs = [g['lr'] for g in optimizer.param_groups]
+        self.dampen()
+
+    def warmup_factor(self, step):
+        return min(1.0, (step + 1) / self.warmup_period)
+
+    def dampen(self, step=None):
+        step = self.last_step + 1 if step is None else step
+        self.last_step = step
+        for g in self.optimizer.param_groups:
+            g['lr'] *= self.warmup_factor(step)
+
+    @contextmanager
+    def dampening(self):
+        for g, lr in zip(self.optimizer.param_groups, self.lrs):
+            g['lr'] = lr
+        yield
+        self.lrs = [g['lr'] for g in self.optimizer.param_groups]
+        self.dampen()
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != 'optimizer'}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)
 
 
 class _NullScaler:
@@ -333,8 +394,6 @@ class ImagenTrainer(nn.Module):
         self.mixed_precision = default(precision, 'fp16' if fp16 else 'no')
         assert self.mixed_precision in ('no', 'fp16', 'bf16'), self.mixed_precision
         self.cast_half_at_training = self.mixed_precision == 'fp16'
-        assert max_grad_norm is None and warmup_steps is None and cosine_decay_max_steps is None, \
-            'grad clipping / LR schedules are off in the reference scripts (trainer.py:245-252) and not built'
         self.configs = configs
         ema_kwargs, kwargs = groupby_prefix_and_trim('ema_', kwargs)
         _, kwargs = groupby_prefix_and_trim('accelerate_', kwargs)
@@ -359,14 +418,28 @@ class ImagenTrainer(nn.Module):
         assert 0 <= split_valid_fraction <= 1, 'split valid fraction must be between 0 and 1'
         self.split_valid_fraction, self.split_random_seed = split_valid_fraction, split_random_seed
 
-        lr, eps = cast_tuple(lr, self.num_unets), cast_tuple(eps, self.num_unets)
-        for ind, (unet, unet_lr, unet_eps) in enumerate(zip(self.imagen.unets, lr, eps)):
-            setattr(self, f'optim{ind}', FusedAdam(unet.parameters(), lr=unet_lr, eps=unet_eps, betas=(beta1, beta2), **kwargs))
+        lr, eps, warmup_steps, cosine_decay_max_steps = (cast_tuple(v, self.num_unets) for v in (lr, eps, warmup_steps, cosine_decay_max_steps))
+        for ind, (unet, unet_lr, unet_eps, unet_warmup, unet_cosine) in enumerate(zip(self.imagen.unets, lr, eps, warmup_steps,
+                                                                                       cosine_decay_max_steps)):
+            optimizer = FusedAdam(unet.parameters(), lr=unet_lr, eps=unet_eps, betas=(beta1, beta2), **kwargs)
+            setattr(self, f'optim{ind}', optimizer)
             if self.use_ema:
                 self.ema_unets.append(EMA(unet, **ema_kwargs))
+            # LR schedules (trainer.py:366-375): torch's own schedulers on an lr carrier; `eta_min = lr[1] * 0.001` is the reference's
+            # expression (the SECOND U-Net's rate, whichever U-Net the scheduler belongs to)
+            scheduler = warmup_scheduler = None
+            if exists(unet_cosine) or exists(unet_warmup):
+                optimizer.lr_carrier = _LrCarrier(unet_lr)
+            if exists(unet_cosine):
+                scheduler = CosineAnnealingLR(optimizer.lr_carrier, T_max=unet_cosine, eta_min=lr[1] * 0.001)
+            if exists(unet_warmup):
+                warmup_scheduler = _LinearWarmup(optimizer.lr_carrier, warmup_period=unet_warmup)
+                if not exists(scheduler):
+                    scheduler = LambdaLR(optimizer.lr_carrier, lr_lambda=lambda step: 1.0)
+                optimizer.param_groups[0]['lr'] = optimizer.lr_carrier.param_groups[0]['lr']     # damped from the first step on
             setattr(self, f'scaler{ind}', _NullScaler())
-            setattr(self, f'scheduler{ind}', None)
-            setattr(self, f'warmup{ind}', None)
+            setattr(self, f'scheduler{ind}', scheduler)
+            setattr(self, f'warmup{ind}', warmup_scheduler)
         self.max_grad_norm = max_grad_norm
         self.register_buffer('steps', torch.tensor([0] * self.num_unets))
         self.verbose = verbose
@@ -619,6 +692,11 @@ class ImagenTrainer(nn.Module):
         self.reset_ema_unets_all_one_device()
         save_obj = dict(model=self.imagen.state_dict(), version=CHECKPOINT_VERSION, steps=self.steps.cpu(), **kwargs)
         for ind in (range(0, self.num_unets) if not without_optim_and_sched else tuple()):
+            scheduler, warmup_scheduler = getattr(self, f'scheduler{ind}'), getattr(self, f'warmup{ind}')
+            if exists(scheduler):                                                    # key order of trainer.py:851-857
+                save_obj = {**save_obj, f'scheduler{ind}': scheduler.state_dict()}
+            if exists(warmup_scheduler):
+                save_obj = {**save_obj, f'warmup{ind}': warmup_scheduler.state_dict()}
             save_obj = {**save_obj, f'scaler{ind}': getattr(self, f'scaler{ind}').state_dict(),
                         f'optim{ind}': getattr(self, f'optim{ind}').state_dict()}
         if self.use_ema:
@@ -650,9 +728,16 @@ class ImagenTrainer(nn.Module):
             return loaded_obj
         self.steps.copy_(loaded_obj['steps'])
         for ind in range(0, self.num_unets):
+            scheduler, warmup_scheduler = getattr(self, f'scheduler{ind}'), getattr(self, f'warmup{ind}')
+            if exists(scheduler) and f'scheduler{ind}' in loaded_obj:                # trainer.py:922-926
+                scheduler.load_state_dict(loaded_obj[f'scheduler{ind}'])
+            if exists(warmup_scheduler) and f'warmup{ind}' in loaded_obj:
+                warmup_scheduler.load_state_dict(loaded_obj[f'warmup{ind}'])
             try:
                 getattr(self, f'optim{ind}').load_state_dict(loaded_obj[f'optim{ind}'])
                 getattr(self, f'scaler{ind}').load_state_dict(loaded_obj[f'scaler{ind}'])
+                if exists(scheduler):                # the optimiser's param group carries the rate in effect (torch restores it there)
+                    getattr(self, f'optim{ind}').lr_carrier.param_groups[0]['lr'] = getattr(self, f'optim{ind}').param_groups[0]['lr']
             except Exception:
                 self.print('could not load optimizer and scaler, possibly because you have turned on mixed precision training since the last run. resuming with new optimizer and scalers')
         if self.use_ema:
@@ -732,11 +817,24 @@ class ImagenTrainer(nn.Module):
         self.validate_and_set_unet_being_trained(unet_number)
         index = unet_number - 1
         optimizer = getattr(self, f'optim{index}')
-        if getattr(self, '_sync_now', False):
-            optimizer.step()            # fused Adam + zero_grad
+        scheduler, warmup_scheduler = getattr(self, f'scheduler{index}'), getattr(self, f'warmup{index}')
+        stepped = getattr(self, '_sync_now', False)
+        if stepped:
+            optimizer.step(max_grad_norm=self.max_grad_norm)      # (clip ->) fused Adam + zero_grad (trainer.py:1054-1057)
             self._sync_now = False
+        elif exists(self.max_grad_norm) and self.training:
+            optimizer.clip_accumulated(self.max_grad_norm)
         if self.use_ema:
             self.ema_unets[index].update()
+        # trainer.py:1063-1069: the warm-up's dampening() context runs on EVERY update call; the scheduler inside it is the one
+        # accelerator.prepare() wrapped (trainer.py:492), which steps only when the gradients were synchronised -- i.e. with the Adam
+        # step (pinned by tests/golden/trainerA_trace_opts.npz: the rate moves every gradient_accumulation_steps-th micro-step)
+        if exists(scheduler):
+            with (warmup_scheduler.dampening() if exists(warmup_scheduler) else nullcontext()):
+                if stepped:
+                    optimizer.lr_carrier.step()          # no gradients: a no-op that keeps torch's step-order bookkeeping quiet
+                    scheduler.step()
+            optimizer.param_groups[0]['lr'] = optimizer.lr_carrier.param_groups[0]['lr']
         self.steps[index] += 1
         if exists(self.checkpoint_path) and int(self.steps.sum().item()) % self.checkpoint_every == 0:
             self.save_to_checkpoint_folder()

@@ -47,6 +47,15 @@ extern "C" {
 int         diqt_version(void);
 const char* diqt_last_error(void);
 
+/* Launch census (test / measurement infrastructure, no reference counterpart: the reference dispatches through ATen and can be
+ * watched with torch.profiler).  Every kernel launch of the library carries a tag (the names diqt_last_error reports, e.g.
+ * "conv3d_fwd_h(persistent)", "conv3d_fwd(v9)", "temporal_attention_h").  diqt_census_enable(1) zeroes the per-tag counters and
+ * starts counting, (0) stops; both return the previous state.  diqt_census_count(s) = launches since then whose tag contains s
+ * (NULL: all).  diqt_get_last_launch() = tag of the calling thread's most recent launch.  Thread-safe. */
+int         diqt_census_enable(int on);
+long long   diqt_census_count(const char* substr);
+const char* diqt_get_last_launch(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution (stride 1, zero padding) as an im2col-free implicit GEMM on v_mfma_f32_32x32x2_f32.
  * Replaces nn.Conv3d / nn.Linear / nn.Conv1d at: Block.project imagen_pytorch3D.py:551-553,566;
@@ -470,6 +479,15 @@ int diqt_mse_clamp_bwd(const float* pred_clamped, const float* target, const flo
 int diqt_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_correction1, float bias_correction2, int zero_grad, void* stream);
+/* Global gradient-norm clipping (ImagenTrainer(max_grad_norm=...): accelerator.clip_grad_norm_ -> torch.nn.utils.clip_grad_norm_,
+ * trainer.py:1054) over the flat gradient arena.  diqt_grad_norm_clip writes out2[0] = L2 norm of grad[0..n) (fixed-order, fp64
+ * combine) and out2[1] = min(1, max_norm / (norm + 1e-6)); `workspace`: diqt_grad_norm_workspace_bytes() bytes, 8-byte aligned.
+ * diqt_adam_step_scaled is diqt_adam_step with every gradient multiplied by *grad_scale (a device scalar, e.g. out2 + 1) first. */
+size_t diqt_grad_norm_workspace_bytes(void);
+int diqt_grad_norm_clip(const float* grad, size_t n, float max_norm, void* workspace, float* out2, void* stream);
+int diqt_adam_step_scaled(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                          float lr, float beta1, float beta2, float eps, float weight_decay,
+                          float bias_correction1, float bias_correction2, int zero_grad, const float* grad_scale, void* stream);
 /* Dynamic thresholding of the predicted x0 (imagen_pytorch3D.py:2006-2021; elucidated_imagen.py:340-358):
  * out[b] = torch.quantile(|x[b, :]|, q) with linear interpolation.  The caller passes the fp32 rank split the way
  * torch does: rank = q * (per - 1) in fp32, k_lo = floor(rank), weight = rank - k_lo.                              */

@@ -31,7 +31,8 @@ def make_gpu_trainer(**kw):
                     channels=1, pred_objectives='x_start', timesteps=4, dynamic_thresholding=False,
                     p2_loss_weight_gamma=0.0, cond_drop_prob=0.0).to(DEV)
     ImagenTrainer.locked = False
-    trainer = ImagenTrainer(configs=configs, imagen=imagen, gradient_accumulation_steps=4, verbose=False, **kw)
+    kw.setdefault('gradient_accumulation_steps', 4)
+    trainer = ImagenTrainer(configs=configs, imagen=imagen, verbose=False, **kw)
     return trainer, imagen.unets[1]
 
 
@@ -241,3 +242,47 @@ def test_reference_layout_checkpoint_resumes_on_hip(tmp_path):
         assert np.isfinite(loss)
     assert trainer.steps.tolist() == [0, man['steps'][1] + 3]
     assert torch.isfinite(unet.final_conv.weight).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# constructor options of T2: max_grad_norm / cosine_decay_max_steps (/root/reference/trainer.py:350-382, 1054, 1063-1069)
+# ------------------------------------------------------------------------------------------------------------------------------------
+OPT_CASES = {'clip': dict(max_grad_norm=0.02), 'cosine': dict(cosine_decay_max_steps=3),
+             'clip_cosine': dict(max_grad_norm=0.02, cosine_decay_max_steps=3, lr=3e-4)}
+
+
+@pytest.mark.parametrize("tag", list(OPT_CASES))
+def test_trainer_grad_clip_and_cosine_schedule_match_reference_trace_on_hip(tag):
+    """The traces of the REAL reference trainer with gradient clipping / the cosine schedule on (tests/golden/trainerA_trace_opts.npz),
+    replayed through the HIP path: the norm reduction over the flat gradient arena (diqt_grad_norm_clip), the coefficient applied
+    inside the fused Adam (diqt_adam_step_scaled), torch's CosineAnnealingLR on the lr carrier."""
+    g = load_golden('trainerA_trace_opts')
+    trainer, unet = make_gpu_trainer(gradient_accumulation_steps=2, **OPT_CASES[tag])
+    trainer.training = True
+    unet.train()
+    w = unet.final_conv.weight
+    for i in range(g['hr'].shape[0]):
+        times = T(g['times'][i])
+        trainer.imagen.noise_schedulers[1].sample_random_times = lambda b, device, t=times: t.clone().to(device)
+        loss, *_ = trainer.forward(T(g['hr'][i]), lowres_img=T(g['lowres'][i]), unet_number=2, max_batch_size=2, noise=T(g['noise'][i]))
+        assert int(trainer.steps[1].item()) == int(g[f'{tag}:steps'][i])
+        ref_lr = float(g[f'{tag}:lrs'][i])
+        assert abs(trainer.get_lr(2) - ref_lr) <= 1e-12 + 1e-9 * ref_lr, (i, trainer.get_lr(2), ref_lr)
+        ref_l = float(g[f'{tag}:losses'][i])
+        assert abs(loss - ref_l) <= 5e-5 * abs(ref_l), (i, loss, ref_l)
+        wv, ref_w = w.detach().flatten().cpu(), T(g[f'{tag}:w'][i])
+        assert torch.allclose(wv, ref_w, atol=5e-6, rtol=1e-3), f'{tag}: weights after micro-step {i}: {(wv - ref_w).abs().max().item():.3e}'
+
+
+def test_grad_norm_clip_kernel_equals_torch_clip_grad_norm():
+    from diffusioniqt_amd import ops
+    g = torch.Generator().manual_seed(3)
+    flat = (torch.randn(1_300_037, generator=g) * 0.01).to(DEV)
+    for max_norm in (0.5, 50.0):
+        out = ops.grad_norm_clip(flat, max_norm).cpu()
+        p = torch.nn.Parameter(torch.zeros_like(flat))
+        p.grad = flat.clone()
+        total = torch.nn.utils.clip_grad_norm_([p], max_norm).cpu()
+        assert abs(out[0] - total) <= 2e-6 * total, (out, total)
+        want = min(1.0, max_norm / (float(total) + 1e-6))
+        assert abs(float(out[1]) - want) <= 2e-6, (out, want)

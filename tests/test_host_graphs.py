@@ -33,5 +33,25 @@ def test_signature_distinguishes_shapes_dtypes_and_plain_values():
     assert graphs._sig(a) != graphs._sig(a.double())
     assert graphs._sig((a, 1.5, None)) == graphs._sig((torch.ones(2, 3), 1.5, None))
     assert graphs._sig(0.5) == 0.5 and graphs._sig("x") == "x"
-    o = object()
-    assert graphs._sig(o) == ("O", id(o))
+    import pytest
+    with pytest.raises(graphs._Uncapturable):                                    # id() can be reused after GC: such calls stay eager
+        graphs._sig(object())
+
+
+def test_retired_cache_tensors_are_pinned_while_a_graph_is_alive():
+    """A captured graph holds raw addresses of host-cached tensors (scratch arena, packed weights, position-bias tables): a cache that
+    replaces one hands the old tensor to ops.retire(), which keeps it until the last graph is dropped (two use-after-frees)."""
+    from diffusioniqt_amd import ops
+    ops.graphs_alive(-10 ** 6)
+    a, b = torch.zeros(4), torch.zeros(5)
+    ops.retire(a)
+    assert not ops._GRAPH_PINS                                                   # no graph alive: nothing to pin
+    ops.graphs_alive(+2)
+    ops.retire(a, None, b)
+    assert [t.numel() for t in ops._GRAPH_PINS] == [4, 5]
+    ops.graphs_alive(-1)
+    assert len(ops._GRAPH_PINS) == 2                                             # one graph left
+    cache = graphs.GraphCache()
+    cache.entries[(1, 'old')] = dict(graph=object(), failed=False, calls=9)
+    cache._drop([(1, 'old')])
+    assert not ops._GRAPH_PINS and ops._LIVE_GRAPHS == 0

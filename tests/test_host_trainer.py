@@ -32,7 +32,8 @@ def make_trainer(tmp_path=None, **kw):
                     channels=1, pred_objectives='x_start', timesteps=4, dynamic_thresholding=False,
                     p2_loss_weight_gamma=0.0, cond_drop_prob=0.0)
     ImagenTrainer.locked = False
-    trainer = ImagenTrainer(configs=configs, imagen=imagen, gradient_accumulation_steps=4, verbose=False, **kw)
+    kw.setdefault('gradient_accumulation_steps', 4)
+    trainer = ImagenTrainer(configs=configs, imagen=imagen, verbose=False, **kw)
     return trainer, unet
 
 
@@ -226,3 +227,60 @@ def test_load_accepts_a_checkpoint_with_the_reference_layout(tmp_path):
     assert names == [n for n, _ in trainer.imagen.unets[1].named_parameters()]
     stateless = {names[i] for i in range(len(names)) if str(i) not in man['optim']['optim1']['state']}
     assert stateless and all(n.startswith(('mid_block.', 'norm_cond.')) for n in stateless), stateless
+
+
+OPT_CASES = {'clip': dict(max_grad_norm=0.02), 'cosine': dict(cosine_decay_max_steps=3),
+             'clip_cosine': dict(max_grad_norm=0.02, cosine_decay_max_steps=3, lr=3e-4)}
+
+
+@pytest.mark.parametrize("tag", list(OPT_CASES))
+def test_trainer_grad_clip_and_cosine_schedule_match_reference_trace(tag):
+    """ImagenTrainer(max_grad_norm=, cosine_decay_max_steps=) against traces of the REAL reference trainer with those options on
+    (oracle/make_golden_trainer_opts.py -> trainerA_trace_opts.npz; /root/reference/trainer.py:350-382, 1054, 1063-1069): the learning
+    rate after every micro-step (the scheduler moves with the Adam step, every 2nd micro-step here), losses and final_conv.weight."""
+    g = load_golden('trainerA_trace_opts')
+    with cpu_op_doubles():
+        trainer, unet = make_trainer(gradient_accumulation_steps=2, **OPT_CASES[tag])
+        trainer.training = True
+        idx = unet.names.index('final_conv.weight')
+        for i in range(g['hr'].shape[0]):
+            times = T(g['times'][i])
+            trainer.imagen.noise_schedulers[1].sample_random_times = lambda b, device, t=times: t.clone()
+            loss, *_ = trainer.forward(T(g['hr'][i]), lowres_img=T(g['lowres'][i]), unet_number=2, max_batch_size=2, noise=T(g['noise'][i]))
+            assert int(trainer.steps[1].item()) == int(g[f'{tag}:steps'][i])
+            assert abs(trainer.get_lr(2) - float(g[f'{tag}:lrs'][i])) <= 1e-12 + 1e-9 * float(g[f'{tag}:lrs'][i]), (i, trainer.get_lr(2))
+            ref_l = float(g[f'{tag}:losses'][i])
+            assert abs(loss - ref_l) <= 5e-5 * abs(ref_l), (i, loss, ref_l)
+            w = unet.plist[idx].detach().flatten()
+            assert torch.allclose(w, T(g[f'{tag}:w'][i]), atol=5e-6, rtol=1e-3), (i, float((w - T(g[f'{tag}:w'][i])).abs().max()))
+
+
+def test_linear_warmup_restatement_and_checkpoint_keys(tmp_path):
+    """warmup_steps (pytorch_warmup 0.1.1 LinearWarmup + dampening(), restated: parity unpinned -- the package is absent): the rate is
+    damped by min(1, (k + 1) / period) with k advancing on EVERY update call, around a cosine schedule that moves with the Adam step;
+    scheduler / warmup states are saved under the reference's keys (trainer.py:851-855) and restored."""
+    import math
+    with cpu_op_doubles():
+        trainer, unet = make_trainer(gradient_accumulation_steps=2, warmup_steps=5, cosine_decay_max_steps=4, lr=2e-4)
+        trainer.training = True
+        g = load_golden('trainerA_trace_opts')
+        assert abs(trainer.get_lr(2) - 2e-4 / 5) < 1e-15                                    # damped at construction (step 0)
+        eta_min = 2e-4 * 0.001
+        for i in range(6):
+            times = T(g['times'][i])
+            trainer.imagen.noise_schedulers[1].sample_random_times = lambda b, device, t=times: t.clone()
+            trainer.forward(T(g['hr'][i]), lowres_img=T(g['lowres'][i]), unet_number=2, max_batch_size=2, noise=T(g['noise'][i]))
+            adam_steps = (i + 1) // 2
+            undamped = eta_min + (2e-4 - eta_min) * (1 + math.cos(math.pi * adam_steps / 4)) / 2
+            want = undamped * min(1.0, (i + 2) / 5)
+            assert abs(trainer.get_lr(2) - want) <= 1e-9 * want, (i, trainer.get_lr(2), want)
+        path = str(tmp_path / 'ck.pt')
+        trainer.save(path)
+        ck = torch.load(path, weights_only=False)
+        keys = list(ck.keys())
+        assert keys.index('scheduler1') < keys.index('warmup1') < keys.index('scaler1') < keys.index('optim1')
+        assert ck['warmup1']['last_step'] == 6 and ck['scheduler1']['last_epoch'] == 3
+        lr_now = trainer.get_lr(2)
+        trainer.warmup1.last_step, trainer.optim1.param_groups[0]['lr'] = 0, 1.0
+        trainer.load(path)
+        assert trainer.warmup1.last_step == 6 and trainer.scheduler1.last_epoch == 3 and trainer.get_lr(2) == lr_now

@@ -125,6 +125,7 @@ PROTOTYPES = {
     "diqt_mqa_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "diqt_mqa_attention_fwd_frames": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P]),
     "diqt_set_convh_workgroups": (I, [I]),
+    "diqt_set_conv_f9h_mode": (I, [I]),
     "diqt_conv3d_bwd_weight_h_workspace_bytes": (Z, [I] * 15),
     "diqt_conv3d_bwd_weight_h": (I, [P, P, P, P, P, Z] + [I] * 15 + [I, P]),
     "diqt_conv3d_fwd_h_io16_supported": (I, [I] * 17),

@@ -27,7 +27,7 @@ stamp_of() { cat $(deps_of "$1") | cat - <(echo "$FLAGS $HIPCC $2") | sha256sum 
 OBJS=""
 PIDS=""
 BUILT=""
-for f in conv_fwd9 conv_fwd9_d conv_fwd9_b conv_fwd9_c conv_fwd9_e conv_fwd9_f conv_fwd9_g conv_fwd9_h conv_fwd9_i conv_mfma conv_wgrad conv_wgrad_h conv_pw conv_half conv_smallcout elementwise bgemm conv_direct attention attn_temporal datapath lib; do
+for f in conv_fwd9 conv_fwd9_d conv_fwd9_b conv_fwd9_c conv_fwd9_e conv_fwd9_f conv_fwd9_g conv_fwd9_h conv_fwd9_i conv_mfma conv_wgrad conv_wgrad_h conv_pw conv_half conv_f9h conv_f9h_b conv_f9h_c conv_smallcout elementwise bgemm conv_direct attention attn_temporal datapath lib; do
   src=$f.hip; xflag=""
   if [ $f = lib ]; then src=lib.cpp; xflag="-x hip"; fi
   # the GroupNorm-apply instantiations of conv_fwd9_kernel: their fully unrolled step loop exceeds LLVM's default size limit for

@@ -1,0 +1,100 @@
+// Planner and launcher of conv_f9h_kernel (conv_f9h_kernel.h has the description) + its 3x3x3 instantiations.
+#include "conv_f9h_kernel.h"
+#include <stdlib.h>
+#include <atomic>
+
+// 0: conv_f9h_kernel never takes a launch, 1 (default; env DIQT_CONV_F9H): launches that fill the chip, 2: any tile count (tests run the
+// kernel on small shapes this way).  mode >= 0 sets it, mode < 0 only queries; returns the previous value.
+static std::atomic<int> g_f9h_mode{-1};
+extern "C" int diqt_set_conv_f9h_mode(int mode) {
+    int cur = g_f9h_mode.load();
+    if (cur < 0) {
+        const char* e = getenv("DIQT_CONV_F9H");
+        const int v = e ? atoi(e) : 1;
+        g_f9h_mode.compare_exchange_strong(cur, v < 0 ? 1 : v);
+        cur = g_f9h_mode.load();
+    }
+    if (mode >= 0) g_f9h_mode.store(mode);
+    return cur;
+}
+
+static unsigned long long* g_f9dbg = nullptr;   // diagnostic only (DIQT_F9H_DBG=1)
+static unsigned g_f9dbg_n = 0;
+// diagnostic only (not part of include/diqt.h): the cycle stamps of the last DIQT_F9H_DBG=1 launch, 32 per wave, 4 waves per workgroup
+extern "C" int diqt_debug_f9h_stamps(unsigned long long* host_out, unsigned max_waves) {
+    if (!g_f9dbg || !g_f9dbg_n) return 0;
+    const unsigned n = g_f9dbg_n < max_waves ? g_f9dbg_n : max_waves;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    if (hipMemcpy(host_out, g_f9dbg, (size_t)n * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return (int)n;
+}
+
+namespace diqt {
+
+template <class C> static bool f9h_try(H9Geom& g, size_t& lds, unsigned& grid, int mode) {
+    g.tilesD = (g.Do + C::TD - 1) / C::TD; g.tilesH = (g.Ho + C::TH - 1) / C::TH; g.tilesW = (g.Wo + C::TW - 1) / C::TW;
+    const long long mt = (long long)g.B * g.tilesD * g.tilesH * g.tilesW;
+    if (mt >= (1ll << 30)) return false;
+    g.MT = (int)mt;
+    const double useful = (double)g.Do * g.Ho * g.Wo / ((double)g.tilesD * g.tilesH * g.tilesW * (double)(C::TD * C::TH * C::TW));
+    const long long nwg = mt * g.nNt;
+    // one workgroup per CU: whole rounds of 256 (a ragged last round idles the rest of the chip for a tile's time)
+    if (mode != 2 && (useful < 0.85 || nwg < 200 || (double)nwg / (double)((nwg + 255) / 256 * 256) < 0.78)) return false;
+    // persistent walk: a workgroup keeps its 64-channel block (its weight stream)
+    unsigned gr = nwg > 256 ? 256u : (unsigned)nwg;
+    if (nwg > 256) gr -= gr % (unsigned)g.nNt;
+    if (gr == 0) return false;
+    grid = gr;
+    lds = C::LDS_BYTES;
+    return true;
+}
+
+bool f9h_plan(H9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
+              int pw, int epd, int eph, int epw, bool yHalf) {
+    const int mode = diqt_set_conv_f9h_mode(-1);
+    const bool k333 = kd == 3 && kh == 3 && kw == 3, k133 = kd == 1 && kh == 3 && kw == 3;
+    if (!mode || !(k333 || k133) || Cin % h9::CK != 0 || Cout % 8 != 0 || Cout < 8) return false;
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || D > 1000 || H > 1000 || W > 1000) return false;      // packed 10-bit halo coordinates
+    if (pd < 0 || ph < 0 || pw < 0 || pd > 16 || ph > 16 || pw > 16) return false;
+    g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.pd = pd; g.ph = ph; g.pw = pw;
+    g.Do = D + 2 * pd + epd - kd + 1; g.Ho = H + 2 * ph + eph - kh + 1; g.Wo = W + 2 * pw + epw - kw + 1;
+    if (g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return false;
+    g.nNt = (Cout + 63) / 64; g.CoutPad = g.nNt * 64; g.nChunks = Cin / h9::CK;
+    const unsigned long long xb = (unsigned long long)B * D * H * W * Cin * 2ull;
+    const unsigned long long vox = (unsigned long long)B * g.Do * g.Ho * g.Wo;
+    const unsigned long long yb = vox * Cout * (yHalf ? 2ull : 4ull), rb = vox * Cout * 4ull;
+    const unsigned long long wb = (unsigned long long)g.nChunks * kd * kh * kw * g.CoutPad * h9::CK * 2ull;
+    if (xb >= (1ull << 30) || rb >= (1ull << 31) || wb >= (1ull << 30)) return false;
+    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.rBytes = (unsigned)rb; g.wBytes = (unsigned)wb; g.stats = nullptr; g.dbg = nullptr;
+    if (k333) {
+        if (f9h_try<h9::H9_333_512>(g, lds, grid, mode)) { g.variant = 0; return true; }
+        if (f9h_try<h9::H9_333_256>(g, lds, grid, mode)) { g.variant = 1; return true; }
+    } else {
+        if (f9h_try<h9::H9_133_A>(g, lds, grid, mode)) { g.variant = 2; return true; }
+        if (f9h_try<h9::H9_133_B>(g, lds, grid, mode)) { g.variant = 3; return true; }
+        if (f9h_try<h9::H9_133_C>(g, lds, grid, mode)) { g.variant = 4; return true; }
+    }
+    return false;
+}
+
+int f9h_stats_blocks(const H9Geom& g) { return g.tilesD * g.tilesH * g.tilesW * 2; }
+
+int f9h_launch(const void* x, const unsigned short* packed_h, const float* bias, const float* residual, void* y, const H9Geom& g0, size_t lds,
+               unsigned grid, int bf16, bool yHalf, void* stream) {
+    H9Geom g = g0;
+    static const bool dbg_on = [] { const char* e = getenv("DIQT_F9H_DBG"); return e && e[0] == '1'; }();
+    if (dbg_on) {
+        if (!g_f9dbg) DIQT_REQUIRE(hipMalloc(&g_f9dbg, (size_t)1024 * 32 * sizeof(unsigned long long)) == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h(v9h): debug buffer");
+        DIQT_REQUIRE(hipMemsetAsync(g_f9dbg, 0, (size_t)1024 * 32 * sizeof(unsigned long long), (hipStream_t)stream) == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h(v9h): debug buffer");
+        g.dbg = g_f9dbg; g_f9dbg_n = grid * 4;
+    }
+    switch (g.variant) {
+        case 0: return h9::launch_cfg<h9::H9_333_512>(x, packed_h, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
+        case 1: return h9::launch_b(x, packed_h, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
+        case 2: case 3: case 4: return h9::launch_c(x, packed_h, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
+    }
+    set_error("conv3d_fwd_h(v9h): no variant %d", g.variant);
+    return DIQT_E_UNSUPPORTED;
+}
+
+}  // namespace diqt

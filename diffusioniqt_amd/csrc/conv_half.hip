@@ -15,6 +15,7 @@
 //   * per tap and wave: 6 ds_read_b128 (A k-steps 0/1, B for both channel halves) feed 4 MFMAs.
 // Packed weights: half/bf16 [chunk = ci/32][tap][co padded to 64][32 ci]  (conv_pack_weight_h_kernel).
 #include "common.h"
+#include "conv_f9h.h"
 #include <stdlib.h>
 #include <atomic>
 #include <type_traits>
@@ -977,6 +978,10 @@ static bool convh_four_waves(const HalfGeom& g, bool xh) {
 extern "C" int diqt_conv3d_fwd_h_io16_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
                                                 int pw, int epd, int eph, int epw, int x_half, int y_half) {
     HalfGeom g;
+    if (x_half) {                 // the LDS-DMA kernel (conv_f9h_kernel): 3x3x3 and (1,3,3) filters over 16-bit x
+        H9Geom g9; size_t l9; unsigned gr9;
+        if (f9h_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, y_half != 0)) return 1;
+    }
     if (Cin % 8 != 0 || Cout % 8 != 0 ||
         !half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, x_half ? 2 : 4, y_half ? 2 : 4))
         return 0;
@@ -988,6 +993,10 @@ extern "C" int diqt_conv3d_fwd_h_io16_supported(int B, int D, int H, int W, int 
 extern "C" int diqt_conv3d_fwd_h_stats_blocks(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
                                               int pw, int epd, int eph, int epw, int x_half, int y_half) {
     HalfGeom g;
+    if (x_half) {
+        H9Geom g9; size_t l9; unsigned gr9;
+        if (f9h_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, y_half != 0)) return f9h_stats_blocks(g9);
+    }
     if (!half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, x_half ? 2 : 4, y_half ? 2 : 4)) return 0;
     if ((kd == 1 && kh == 1 && kw == 1) || !x_half) return 0;          // flattened rows: tiles straddle batch entries
     const unsigned nwg = (unsigned)((long long)g.B * g.tilesD * g.tilesH * g.tilesW * g.nNt);
@@ -1037,6 +1046,15 @@ static int convh_launch(const void* x, const void* packed_h, const float* bias, 
                         int round_out, bool xh, bool yh, float* stats, void* stream) {
     DIQT_REQUIRE(x && packed_h && y, DIQT_E_ALIGN, "conv3d_fwd_h: null pointer");
     DIQT_REQUIRE(aligned16(x) && aligned16(packed_h), DIQT_E_ALIGN, "conv3d_fwd_h: x and the packed weights must be 16-byte aligned");
+    if (xh && round_out && !(yh && residual)) {
+        // 16-bit x, 3x3x3 / (1,3,3): the LDS-DMA kernel on conv_fwd9_kernel's structure (conv_f9h_kernel.h)
+        H9Geom g9; size_t l9; unsigned gr9;
+        if (f9h_plan(g9, l9, gr9, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, yh)) {
+            DIQT_REQUIRE(aligned16(y) && (!residual || aligned16(residual)), DIQT_E_ALIGN, "conv3d_fwd_h_io: y / residual must be 16-byte aligned");
+            g9.stats = stats;
+            return f9h_launch(x, static_cast<const unsigned short*>(packed_h), bias, residual, y, g9, l9, gr9, bf16, yh, stream);
+        }
+    }
     HalfGeom g;
     DIQT_REQUIRE(half_geom(g, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, xh ? 2 : 4, yh ? 2 : 4), DIQT_E_UNSUPPORTED,
                  "conv3d_fwd_h: shape not supported by the low-precision kernel (diqt_conv3d_fwd_h_supported == 0)");

@@ -308,16 +308,22 @@ class Block(nn.Module):
         self.factor = factor
         self.project = Conv3d(dim, dim_out, 3) if boundary else Conv3d(dim, dim_out, 3, padding=1)
 
-    def forward(self, x, scale_shift=None, residual=None, emit_stats=False, tap=False):
+    def forward(self, x, scale_shift=None, residual=None, emit_stats=False, tap=False, out_half=False):
         """``emit_stats``: the conv epilogue also writes per-tile column sums of its output for the next GroupNorm / SE pool.
-        ``tap``: also returns an alias of the input for its other consumer (ops.groupnorm_act): ``(y, x_alias)``."""
+        ``tap``: also returns an alias of the input for its other consumer (ops.groupnorm_act): ``(y, x_alias)``.
+        ``out_half`` (sampling under autocast): y only feeds the next Block's GroupNorm and may be stored in the operand type."""
         gn = self.groupnorm
         x_in = x
         if isinstance(gn, nn.GroupNorm) and not self.boundary and not torch.is_grad_enabled():
             # sampling: GroupNorm-apply + Mish inside the conv's input staging (one launch, no elementwise pass); None: shape not taken
             pr = self.project
-            y = ops.gn_conv3d(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps, pr.weight, pr.bias, pr.padding,
-                              residual, want_stats=emit_stats) if pr.groups == 1 and tuple(pr.stride) == (1, 1, 1) else None
+            y = None
+            if pr.groups == 1 and tuple(pr.stride) == (1, 1, 1):
+                y = ops.gn_conv3d(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps, pr.weight, pr.bias, pr.padding,
+                                  residual, want_stats=emit_stats)
+                if y is None:       # under autocast: GroupNorm-apply writes the operand type, the conv runs on the LDS-DMA 16-bit kernel
+                    y = ops.gn_conv3d_h(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps, pr.weight, pr.bias,
+                                        pr.padding, residual, want_stats=emit_stats, out_half=out_half)
             if y is not None:
                 return (y, x_in) if tap else y
         if isinstance(gn, nn.GroupNorm):
@@ -431,7 +437,11 @@ class ResnetBlock(nn.Module):
                 scale_shift = self.time_mlp(time_emb)
         # block2's GroupNorm statistics come from block1's conv epilogue; the residual branch reads x through block1's alias so that
         # its gradient is added inside the GroupNorm backward (ops.groupnorm_act, tap)
-        h, x = self.block1(x, emit_stats=True, tap=True)
+        # (sampling under autocast: h only feeds block2's GroupNorm -- 16-bit when block2's conv takes a 16-bit input)
+        b2 = self.block2.project
+        oh = (not self.block2.boundary and isinstance(self.block2.groupnorm, nn.GroupNorm) and b2.groups == 1 and tuple(b2.stride) == (1, 1, 1)
+              and x.dim() == 5 and ops.conv_half_out_ok((*x.shape[:4], b2.weight.shape[1]), b2.weight, b2.padding))
+        h, x = self.block1(x, emit_stats=True, tap=True, out_half=oh)
         res = self.res_conv(x)
         if isinstance(self.se, SE3D):
             h = self.block2(h, scale_shift=scale_shift, emit_stats=True)     # ... and the SE pooling from this one's

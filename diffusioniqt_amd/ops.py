@@ -255,7 +255,9 @@ def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0, x_half=F
     if TIMER.enabled:
         e.record()
         # rocprofv3's name of the kernel that ran: launches of >= 2 x 256 units take the persistent form
-        tag = "conv_fwd_hp_kernel" if io16 or _lib.query("diqt_conv3d_fwd_h_io16_supported", *geo, 0, 0) else "conv_fwd_h_kernel"
+        last = _lib.last_launch()
+        tag = ("conv_f9h_kernel" if "v9h" in last else "conv_pw_h_kernel" if "gemm" in last
+               else "conv_fwd_hp_kernel" if "persistent" in last else "conv_fwd_h_kernel")
         TIMER.records.append((s, e, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, tag, (B, D, H, W, Cin, Cout, kd, kh, kw)))
     return y
 
@@ -289,6 +291,48 @@ def _groupnorm_act_h(x, gamma, beta, ss, groups, act, eps, lp):
     y = torch.empty(x.shape, dtype=torch.bfloat16 if lp == 1 else torch.float16, device=x.device)
     _lib.call("diqt_gn_act_fwd_h", x, mean, rstd, gamma, beta, scale, shift, cs, y, B, rows, C, groups, act, lp, int(x_half), s)
     return y
+
+
+def gn_conv3d_h(x, gamma, beta, scale_shift, groups, act, eps, weight, bias, padding, residual=None, want_stats=False, out_half=False):
+    """Sampling path under autocast: ``conv3d(act(GN(x) * (scale + 1) + shift))`` with the GroupNorm-apply pass writing the conv's input in
+    the operand type and the conv on the LDS-DMA 16-bit kernel (``conv_f9h_kernel``: the 3x3x3 Blocks of Family A, imagen_pytorch3D.py:535-566).
+    x: fp32, or the 16-bit output of such a conv (``out_half``: it carries its GroupNorm statistics).  ``out_half``: y only feeds the next
+    Block's GroupNorm (ResnetBlock: block1 -> block2) -- stored in the operand type, the values autocast's conv output tensor holds anyway.
+    None when not under autocast or the shape is not taken by a 16-bit-input kernel."""
+    lp = lp_mode()
+    if lp is None or torch.is_grad_enabled() or x.dim() != 5:
+        return None
+    B, D, H, W, C = x.shape
+    Cout, Cin, kd, kh, kw = weight.shape
+    padding = tuple(int(p) for p in ((padding,) * 3 if isinstance(padding, int) else padding))
+    x_is_half = x.dtype != torch.float32
+    yh = bool(out_half and want_stats and residual is None)
+    geo = (B, D, H, W, C, Cout, kd, kh, kw, *padding, 0, 0, 0)
+    ok = Cin == C and C % groups == 0 and C % 4 == 0 and _lib.query("diqt_conv3d_fwd_h_io16_supported", *geo, 1, int(yh))
+    if ok and yh:
+        ok = _lib.query("diqt_conv3d_fwd_h_stats_blocks", *geo, 1, 1) > 0
+    if not ok:
+        if x_is_half:
+            raise RuntimeError("gn_conv3d_h: a 16-bit block output reached a conv that does not take 16-bit input")
+        return None
+    _chk(None if x_is_half else x, gamma, beta, weight, bias, residual, scale_shift.base if isinstance(scale_shift, SSView) else None)
+    xin = _groupnorm_act_h(x, gamma, beta, scale_shift, groups, act, eps, lp)
+    holder = [] if want_stats else None
+    y = _conv_fwd_half(xin, weight, bias, residual, padding, (0, 0, 0), lp, x_half=True, y_half=yh, stats_out=holder)
+    if holder:
+        y._diqt_stats = holder[0]
+    assert not yh or holder
+    return y
+
+
+def conv_half_out_ok(shape5, weight, padding):
+    """May a Block hand its conv output on in the operand type?  (the NEXT Block's conv has to take a 16-bit input of that shape)"""
+    if lp_mode() is None or torch.is_grad_enabled():
+        return False
+    B, D, H, W, C = shape5
+    Cout, Cin, kd, kh, kw = weight.shape
+    padding = tuple(int(p) for p in ((padding,) * 3 if isinstance(padding, int) else padding))
+    return bool(Cin == C and _lib.query("diqt_conv3d_fwd_h_io16_supported", B, D, H, W, C, Cout, kd, kh, kw, *padding, 0, 0, 0, 1, 0))
 
 
 def conv_pair_nograd_h(x, w1, b1, pad1, w2, b2, pad2, epad2, residual=None, gn=None, want_stats=False, out_half=False):

@@ -114,6 +114,11 @@ int diqt_conv3d_fwd_h_io(const void* x, const void* packed_h, const float* bias,
  * env DIQT_CONVH_WGS; DIQT_CONVH_PERSIST=0 disables it) when a launch has at least twice as many units and the halo tile fits the
  * register prefetch; n > 0 sets the count, n <= 0 only queries; returns the previous value.  Results do not depend on it.      */
 int diqt_set_convh_workgroups(int n);
+/* diqt_conv3d_fwd_h_io with x_half = 1 on a 3x3x3 or (1,3,3) filter (Cin % 32 == 0, Cout % 8 == 0) runs conv_f9h_kernel -- halo images by
+ * LDS-DMA, one wave per SIMD, weight fragments streamed into registers -- when mode = 1 (default; env DIQT_CONV_F9H) and the tiles fill the
+ * chip, for any tile count when mode = 2, never when 0.  mode >= 0 sets it, mode < 0 only queries; returns the previous value.  Results
+ * agree with the other 16-bit kernels bit for bit on integer-valued data (different K order otherwise).                          */
+int diqt_set_conv_f9h_mode(int mode);
 int diqt_conv3d_fwd_h(const float* x, const void* packed_h, const float* bias, const float* residual, float* y, int B, int D, int H,
                       int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw, int epd, int eph, int epw, int bf16,
                       int round_out, void* stream);

@@ -8,6 +8,7 @@ struct H9Geom {
     int B, D, H, W, Cin, Cout, Do, Ho, Wo, pd, ph, pw;
     int tilesD, tilesH, tilesW, MT, nNt, CoutPad, nChunks, variant;
     unsigned xBytes, yBytes, wBytes, rBytes;
+    int dbgSkip;                 // diagnostic: first stamp slot recorded
     unsigned long long* dbg;     // diagnostic cycle stamps per wave (DIQT_F9H_DBG=1), NULL in production
     float* stats;                // optional column sums (sum, sum of squares) of the stored values: [B][tiles per batch * 2][2][Cout]
 };

@@ -39,10 +39,13 @@ template <class C> static bool f9h_try(H9Geom& g, size_t& lds, unsigned& grid, i
     const double useful = (double)g.Do * g.Ho * g.Wo / ((double)g.tilesD * g.tilesH * g.tilesW * (double)(C::TD * C::TH * C::TW));
     const long long nwg = mt * g.nNt;
     // one workgroup per CU: whole rounds of 256 (a ragged last round idles the rest of the chip for a tile's time)
-    if (mode != 2 && (useful < 0.85 || nwg < 200 || (double)nwg / (double)((nwg + 255) / 256 * 256) < 0.78)) return false;
+    const long long slots = 256 * C::OCC;
+    // fill: one round needs at least 200 workgroups (one per CU; the second slot of a two-workgroup build may stay empty); more rounds have to
+    // be mostly full (a ragged last round idles the chip for a tile's time)
+    if (mode != 2 && (useful < 0.85 || nwg < 200 || (nwg > slots && (double)nwg / (double)((nwg + slots - 1) / slots * slots) < 0.78))) return false;
     // persistent walk: a workgroup keeps its 64-channel block (its weight stream)
-    unsigned gr = nwg > 256 ? 256u : (unsigned)nwg;
-    if (nwg > 256) gr -= gr % (unsigned)g.nNt;
+    unsigned gr = nwg > slots ? (unsigned)slots : (unsigned)nwg;
+    if (nwg > slots) gr -= gr % (unsigned)g.nNt;
     if (gr == 0) return false;
     grid = gr;
     lds = C::LDS_BYTES;
@@ -65,15 +68,23 @@ bool f9h_plan(H9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W
     const unsigned long long yb = vox * Cout * (yHalf ? 2ull : 4ull), rb = vox * Cout * 4ull;
     const unsigned long long wb = (unsigned long long)g.nChunks * kd * kh * kw * g.CoutPad * h9::CK * 2ull;
     if (xb >= (1ull << 30) || rb >= (1ull << 31) || wb >= (1ull << 30)) return false;
-    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.rBytes = (unsigned)rb; g.wBytes = (unsigned)wb; g.stats = nullptr; g.dbg = nullptr;
+    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.rBytes = (unsigned)rb; g.wBytes = (unsigned)wb; g.stats = nullptr; g.dbg = nullptr; g.dbgSkip = 0;
+    static const int force = [] { const char* e = getenv("DIQT_F9H_VARIANT"); return e ? atoi(e) : -1; }();      // experiments: this variant only
+#define F9H_TRY(CFG, V) if ((force < 0 || force == V) && f9h_try<h9::CFG>(g, lds, grid, mode)) { g.variant = V; return true; }
+    // order = measured preference (MI355X, round 4): the 256-voxel tiles at two workgroups per CU are 0-8 % faster than the 512-voxel ones on
+    // the 3x3x3 shapes of C2 (58.7 vs 63.4 us on 64 -> 64 @ 8 x 32^3 with an fp32 y) and on the 64-channel per-frame convs (208 vs 219 us @
+    // 8 x 64^3), 4 % slower at 128 channels; a start skew between the two workgroups of a CU changed nothing
     if (k333) {
-        if (f9h_try<h9::H9_333_512>(g, lds, grid, mode)) { g.variant = 0; return true; }
-        if (f9h_try<h9::H9_333_256>(g, lds, grid, mode)) { g.variant = 1; return true; }
+        F9H_TRY(H9_333_256, 1)
+        F9H_TRY(H9_333_512, 0)
     } else {
-        if (f9h_try<h9::H9_133_A>(g, lds, grid, mode)) { g.variant = 2; return true; }
-        if (f9h_try<h9::H9_133_B>(g, lds, grid, mode)) { g.variant = 3; return true; }
-        if (f9h_try<h9::H9_133_C>(g, lds, grid, mode)) { g.variant = 4; return true; }
+        if (Cin <= 64) { F9H_TRY(H9_133_D, 5) }
+        F9H_TRY(H9_133_A, 2)
+        F9H_TRY(H9_133_B, 3)
+        F9H_TRY(H9_133_D, 5)
+        F9H_TRY(H9_133_C, 4)
     }
+#undef F9H_TRY
     return false;
 }
 
@@ -82,7 +93,9 @@ int f9h_stats_blocks(const H9Geom& g) { return g.tilesD * g.tilesH * g.tilesW * 
 int f9h_launch(const void* x, const unsigned short* packed_h, const float* bias, const float* residual, void* y, const H9Geom& g0, size_t lds,
                unsigned grid, int bf16, bool yHalf, void* stream) {
     H9Geom g = g0;
-    static const bool dbg_on = [] { const char* e = getenv("DIQT_F9H_DBG"); return e && e[0] == '1'; }();
+    static const int dbg_mode = [] { const char* e = getenv("DIQT_F9H_DBG"); return e ? atoi(e) : 0; }();
+    const bool dbg_on = dbg_mode > 0;
+    g.dbgSkip = dbg_mode == 2 ? 80 : 0;
     if (dbg_on) {
         if (!g_f9dbg) DIQT_REQUIRE(hipMalloc(&g_f9dbg, (size_t)1024 * 32 * sizeof(unsigned long long)) == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h(v9h): debug buffer");
         DIQT_REQUIRE(hipMemsetAsync(g_f9dbg, 0, (size_t)1024 * 32 * sizeof(unsigned long long), (hipStream_t)stream) == hipSuccess, DIQT_E_LAUNCH, "conv3d_fwd_h(v9h): debug buffer");
@@ -91,7 +104,7 @@ int f9h_launch(const void* x, const unsigned short* packed_h, const float* bias,
     switch (g.variant) {
         case 0: return h9::launch_cfg<h9::H9_333_512>(x, packed_h, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
         case 1: return h9::launch_b(x, packed_h, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
-        case 2: case 3: case 4: return h9::launch_c(x, packed_h, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
+        case 2: case 3: case 4: case 5: return h9::launch_c(x, packed_h, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
     }
     set_error("conv3d_fwd_h(v9h): no variant %d", g.variant);
     return DIQT_E_UNSUPPORTED;

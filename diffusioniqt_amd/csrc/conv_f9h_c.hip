@@ -9,6 +9,7 @@ int launch_c(const void* x, const unsigned short* wp, const float* bias, const f
     switch (g.variant) {
         case 2: return launch_cfg<H9_133_A>(x, wp, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
         case 3: return launch_cfg<H9_133_B>(x, wp, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
+        case 5: return launch_cfg<H9_133_D>(x, wp, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
         default: return launch_cfg<H9_133_C>(x, wp, bias, residual, y, g, lds, grid, bf16, yHalf, stream);
     }
 }

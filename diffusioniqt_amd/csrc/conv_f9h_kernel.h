@@ -49,21 +49,20 @@ typedef __attribute__((address_space(3))) void lds_void;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int CK = 32, ROWB = 64;        // channels per chunk, bytes per halo row / weight row
 constexpr int PD = 9;                    // slots of the weight-fragment ring (prefetch distance PD - 1 taps)
-constexpr int SCRG = 528;                // bytes per (accumulator quad, lane half) group of the statistics scratch (32 lanes x 16 B + skew)
-constexpr int SCRW = 8 * SCRG;           // per wave
+constexpr int SCRW = 32 * 144;           // epilogue transpose scratch per wave: 32 voxel rows x (128 B of fp32 channels + 16 B pad)
 
-template <int KD_, int KH_, int KW_, int TD_, int TH_, int TW_, int NIMG_>
+template <int KD_, int KH_, int KW_, int TD_, int TH_, int TW_, int NIMG_, int OCC_ = 1>
 struct Cfg {
-    static constexpr int KD = KD_, KH = KH_, KW = KW_, TD = TD_, TH = TH_, TW = TW_, NIMG = NIMG_;
+    static constexpr int KD = KD_, KH = KH_, KW = KW_, TD = TD_, TH = TH_, TW = TW_, NIMG = NIMG_, OCC = OCC_;      // OCC: workgroups per CU
     static constexpr int T = KD * KH * KW;
     static constexpr int HD = TD + KD - 1, HH = TH + KH - 1, HWd = TW + KW - 1, HV = HD * HH * HWd;
     static constexpr int HB = (HV * ROWB + 4095) / 4096 * 4096;        // image in whole 1-KiB DMA instructions, the same count per wave
     static constexpr int NPH = HB / 4096;                             // DMA pieces per wave and chunk
     static constexpr int NBH = TH / 4, NBW = TW / 8, NBLK = TD * NBH * NBW, NVB = NBLK / 2;
-    static constexpr int LDS_BYTES = NIMG * HB + 4 * SCRW;
+    static constexpr int LDS_BYTES = NIMG * HB;                        // (the epilogue's transpose scratch lives in the image that is free then)
     static_assert(TH % 4 == 0 && TW % 8 == 0 && NBLK % 2 == 0 && HWd % 2 == 0, "tile = 2 voxel halves x NVB blocks of 4 x 8 voxels; even halo pitch");
     static_assert(T % PD == 0, "the ring slot of a tap is static: T is a multiple of the ring length");
-    static_assert(LDS_BYTES <= 160 * 1024 && NPH <= 16, "LDS budget; halo piece descriptors live in registers");
+    static_assert(LDS_BYTES * OCC <= 160 * 1024 && NPH <= 16 && HB >= 4 * SCRW, "LDS budget; halo piece descriptors live in registers; scratch fits an image");
     __host__ __device__ static constexpr int tapoff(int t) { return ((t / (KW * KH)) * HH + (t / KW) % KH) * HWd + t % KW; }
     __host__ __device__ static constexpr int blockrow(int id) { return ((id / (NBH * NBW)) * HH + ((id / NBW) % NBH) * 4) * HWd + (id % NBW) * 8; }
     __host__ __device__ static constexpr bool blocks_regular() {
@@ -97,7 +96,7 @@ template <bool BF> __device__ __forceinline__ float round_through(float a) { ret
 
 // x: 16-bit NDHWC; wp: the packed 16-bit weights of conv_pack_weight_h_kernel, [chunk][tap][co pad 64][32 ci]; y: fp32 or (YH) 16-bit
 template <class C, bool BF, bool YH>
-__global__ __launch_bounds__(256, 1) void conv_f9h_kernel(const void* __restrict__ xv, const unsigned short* __restrict__ wp,
+__global__ __launch_bounds__(256, C::OCC) void conv_f9h_kernel(const void* __restrict__ xv, const unsigned short* __restrict__ wp,
                                                           const float* __restrict__ bias, const float* __restrict__ residual,
                                                           void* __restrict__ yv, H9Geom g) {
     constexpr int T = C::T, HB = C::HB, NPH = C::NPH, NVB = C::NVB, HH = C::HH, HWd = C::HWd, HV = C::HV, NIMG = C::NIMG;
@@ -130,22 +129,27 @@ __global__ __launch_bounds__(256, 1) void conv_f9h_kernel(const void* __restrict
     auto stamp = [&]() __attribute__((always_inline)) {
         if (g.dbg) {
             const unsigned long long tnow = __builtin_readcyclecounter();
-            if (lane == 0 && dslot < 32) g.dbg[((size_t)blockIdx.x * 4 + wave) * 32 + dslot] = tnow;
+            // (DIQT_F9H_DBG=2: the stamps from slot 80 on instead of the first 32 -- steady state of a long tile walk)
+            const int ds_ = dslot - g.dbgSkip;
+            if (lane == 0 && dslot == 0) g.dbg[((size_t)blockIdx.x * 4 + wave) * 32 + 28] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+            if (lane == 0) g.dbg[((size_t)blockIdx.x * 4 + wave) * 32 + 29] = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0 && ds_ >= 0 && ds_ < 28) g.dbg[((size_t)blockIdx.x * 4 + wave) * 32 + ds_] = tnow;
+            if (lane == 0 && dslot == 0) g.dbg[((size_t)blockIdx.x * 4 + wave) * 32 + 30] = tnow;      // slot 30: the wave's start, 31: its latest stamp
+            if (lane == 0) g.dbg[((size_t)blockIdx.x * 4 + wave) * 32 + 31] = tnow;
             ++dslot;
         }
     };
     stamp();
 
     // ---- tile-independent description of this lane's halo DMA pieces ----
-    unsigned posH[NPH], relH[NPH];
+    unsigned posH[NPH];              // hz | hy << 10 | hx << 20 | source octet << 30 (its slot ^ swizzle); rows past the image: hx = 1023 (never inside)
 #pragma unroll
     for (int r = 0; r < NPH; ++r) {
         const int p = (wave + 4 * r) * 64 + lane;                  // 16-byte slot of the image: row p / 4, slot p % 4
         const int row = p >> 2;
         const int hx = row % HWd, hy = (row / HWd) % HH, hz = row / (HWd * HH);
         const int gsw = ((hx >> 2) & 1) | (((hy >> 1) & 1) << 1);
-        posH[r] = (unsigned)hz | ((unsigned)hy << 10) | ((unsigned)hx << 20) | (row < HV ? 0u : 1u << 30);
-        relH[r] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin) * 2u + (unsigned)((p & 3) ^ gsw) * 16u;
+        posH[r] = (unsigned)hz | ((unsigned)hy << 10) | ((unsigned)(row < HV ? hx : 1023) << 20) | ((unsigned)((p & 3) ^ gsw) << 30);
     }
     const int Dm1 = g.D - 1, Hm1 = g.H - 1, Wm1 = g.W - 1;
     int tb, d0, h0, w0;                                    // tile being computed
@@ -166,11 +170,14 @@ __global__ __launch_bounds__(256, 1) void conv_f9h_kernel(const void* __restrict
         baseX = (unsigned)((((b_ * g.D + bz) * g.H + by) * g.W + bxx) * g.Cin) * 2u;
         deadX = live ? 0u : OOB;
     };
+    const int HWs = g.W * g.Cin * 2, HHs = g.H * HWs, Cs = g.Cin * 2;       // byte strides of x along H, D, W
     auto dma_h = [&](int r, unsigned imgBase, int chunk) __attribute__((always_inline)) {     // r static
         const unsigned p = posH[r];
-        const int iz = bz + (int)(p & 1023u), iy = by + (int)((p >> 10) & 1023u), ix = bxx + (int)((p >> 20) & 1023u);
-        const unsigned m = (unsigned)(iz | iy | ix) | (unsigned)((Dm1 - iz) | (Hm1 - iy) | (Wm1 - ix)) | (p << 1) | deadX;
-        const unsigned voff = (baseX + relH[r] + (unsigned)chunk * ROWB) | (m & OOB);
+        const int hz = (int)(p & 1023u), hy = (int)((p >> 10) & 1023u), hx = (int)((p >> 20) & 1023u);
+        const int iz = bz + hz, iy = by + hy, ix = bxx + hx;
+        const unsigned m = (unsigned)(iz | iy | ix) | (unsigned)((Dm1 - iz) | (Hm1 - iy) | (Wm1 - ix)) | deadX;
+        const unsigned rel = (unsigned)(hz * HHs + hy * HWs + hx * Cs) + ((p >> 30) << 4);
+        const unsigned voff = (baseX + rel + (unsigned)chunk * ROWB) | (m & OOB);
         dma16(rs_x, imgBase + (unsigned)(wave + 4 * r) * 1024u, voff);
     };
 
@@ -191,31 +198,32 @@ __global__ __launch_bounds__(256, 1) void conv_f9h_kernel(const void* __restrict
     // ---- voxel fragments: B operand, column = this lane's voxel (lj, li) of a block ----
     const int tq = l31 >> 2;
     const int lj = 2 * (tq >> 2) + ((tq ^ (tq >> 1) ^ (tq >> 2)) & 1), li = 4 * ((tq >> 1) & 1) + (l31 & 3);
-    int xa[KH][KW][2];                                        // LDS byte address of tap (ky, kx), k-half q at block 0 of this wave's voxel half, image `img`
-#pragma unroll
+    int xa[KH][KW];                                           // LDS byte address of tap (ky, kx), k-half 0 at block 0 of this wave's voxel half, image `img`
+#pragma unroll                                                // (k-half 1: the same ^ 32 -- bit 5 of the address is (q ^ gy), nothing carries into it)
     for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int gx = ((li + kx) >> 2) & 1, gy = ((lj + ky) >> 1) & 1;
-                xa[ky][kx][q] = (C::blockrow(0) + (wa ? C::blockrow(NVB) : 0) + lj * HWd + li) * ROWB + ((hf ^ gx) << 4) + ((q ^ gy) << 5);
-            }
+        for (int kx = 0; kx < KW; ++kx) {
+            const int gx = ((li + kx) >> 2) & 1, gy = ((lj + ky) >> 1) & 1;
+            xa[ky][kx] = (C::blockrow(0) + (wa ? C::blockrow(NVB) : 0) + lj * HWd + li) * ROWB + ((hf ^ gx) << 4) + (gy << 5);
+        }
 
-    f32x16 acc[NVB];
-#pragma unroll
-    for (int vb = 0; vb < NVB; ++vb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[vb][i] = 0.f;
-
-    // output channels of this lane: cb + 8 (r >> 2) + (r & 3)
+    // output channels of this lane's accumulator rows: cb + 8 (r >> 2) + (r & 3); the accumulators START from the bias (re-loaded per
+    // tile instead of held in 16 registers: the 256-register builds need them)
     const int cb = n0 + 32 * wb + 4 * hf;
-    float bia[16];
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? g.Cout * 4 : 0, 0x00020000);
+    f32x16 acc[NVB];
+    auto acc_init = [&](int vb0, int vb1) __attribute__((always_inline)) {
+        f32x4v b4[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = cb + 8 * (r >> 2) + (r & 3);
-        bia[r] = (bias && co < g.Cout) ? bias[co] : 0.f;
-    }
+        for (int g4 = 0; g4 < 4; ++g4)
+            b4[g4] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (unsigned)(cb + 8 * g4) * 4u, 0, 0));
+#pragma unroll
+        for (int vb = 0; vb < NVB; ++vb)
+            if (vb >= vb0 && vb < vb1)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[vb][i] = b4[i >> 2][i & 3];
+    };
+    acc_init(0, NVB);
 
     // ---- prologue: the first NIMG - 1 units' halo images, the first PD - 1 weight panels ----
     int fit = 0, fc = 0;                                   // (tile iteration, chunk) of the unit being fetched
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void conv_f9h_kernel(const void* __restrict
             u32x4 X0[NVB], X1[NVB];
             auto rd = [&](u32x4 (&X)[NVB], int t, int q) __attribute__((always_inline)) {       // t, q static
                 const int kz = t / (KH * KW), ky = (t / KW) % KH, kx = t % KW;
-                const char* base = smem + xa[ky][kx][q];
+                const char* base = smem + (xa[ky][kx] ^ (q << 5));
 #pragma unroll
                 for (int vb = 0; vb < NVB; ++vb)
                     X[vb] = *reinterpret_cast<const u32x4*>(base + (C::blockrow(vb) - C::blockrow(0) + (kz * HH + ky) * HWd + kx) * ROWB);
@@ -251,29 +259,33 @@ __global__ __launch_bounds__(256, 1) void conv_f9h_kernel(const void* __restrict
             auto mm = [&](u32x4 (&X)[NVB], int t, int q) __attribute__((always_inline)) {
 #pragma unroll
                 for (int vb = 0; vb < NVB; ++vb) acc[vb] = mfma16<BF>(Wr[t % PD][q], X[vb], acc[vb]);
-                // one fragment read of the next half-tap (issued above in program order) behind every MFMA of this one
-#pragma unroll
-                for (int u = 0; u < NVB; ++u) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
             };
             stamp();
             rd(X0, 0, 0);                                  // cold read of the chunk's first half-tap (the image was published by the barrier)
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                // ---- this tap's memory instructions, in THIS order (fenced): halo pieces of the unit NIMG - 1 ahead, then the weight
-                //      panel PD - 1 taps ahead into the slot the previous tap has just left ----
+                // ---- a tap = one scheduling region (fenced at its start: the memory instructions keep their order ACROSS taps -- halo pieces
+                //      of the unit NIMG - 1 ahead before the weight panel PD - 1 taps ahead, which goes into the slot the previous tap has
+                //      left).  Inside, the pipeline below: behind every MFMA one fragment read of the next half-tap, and the tap's (at most
+                //      two + two) memory instructions one per MFMA gap instead of back to back in front of the first MFMA (where the matrix
+                //      pipe drained behind their address arithmetic: 2.4k of a chunk's 17.6k cycles) ----
                 __builtin_amdgcn_sched_barrier(0);
+                rd(X1, t, 1);
+                mm(X0, t, 0);
+                // (in program order BEHIND the first half's fragment reads and in front of the second half's: to the compiler a halo DMA is
+                // a store into the LDS that no fragment read may cross)
 #pragma unroll
                 for (int r = 0; r < NPH; ++r)
                     if (r * NSP / NPH == t) dma_h(r, fbase, fc);
                 w_load((t + PD - 1) % PD);
-                __builtin_amdgcn_sched_barrier(0);
-                rd(X1, t, 1);
-                mm(X0, t, 0);
                 if (t + 1 < T) rd(X0, t + 1, 0);
                 mm(X1, t, 1);
+#pragma unroll
+                for (int u = 0; u < 2 * NVB; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (u >= NVB && u < NVB + 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
             (void)nh_in_tap;
             // End of the unit.  The image of the next unit is complete: its pieces were issued before the weight load whose fragment the
@@ -288,100 +300,118 @@ __global__ __launch_bounds__(256, 1) void conv_f9h_kernel(const void* __restrict
 #pragma unroll
                 for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < KW; ++kx)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) xa[ky][kx][q] += delta;
+                    for (int kx = 0; kx < KW; ++kx) xa[ky][kx] += delta;
                 fimg = img;
                 img = nimg;
             }
         }
-        // ---- epilogue of the tile: D^T[row = co][col = voxel]; this lane: voxel (lj, li) of block vb, channels cb + 8 (r >> 2) + (r & 3) ----
+        // ---- epilogue of the tile.  The accumulators hold D^T[row = co][col = voxel] + bias: lane (l31, hf) has, for voxel (lj, li) of block
+        //      vb, channels cb + 8 g4 + e (four quads).  They are rounded to the operand type and TRANSPOSED through this wave's LDS scratch so
+        //      that the lanes of a store instruction cover WHOLE 64-byte (16-bit y) / 128-byte (fp32 y) channel rows of 16 / 8 voxels: as 8- /
+        //      16-byte pieces of 32 different rows per instruction the stores were bound by the L2's request rate (one per clock and channel:
+        //      64 KB per tile and CU took 7k cycles, every CU in its epilogue at the same time).  Residual and statistics ride on the
+        //      transposed layout: coalesced residual loads, 2 x PW partial sums per lane, shuffles over the lanes that share a piece ----
         {
-            float ssum[16], ssq[16];
+            constexpr int NK = YH ? 2 : 4, PW = YH ? 8 : 4, LPV = YH ? 4 : 8;       // store instructions per block, channels per piece, lanes per voxel
+            constexpr int SROW = YH ? 80 : 144;                                      // scratch row bytes (64 / 128 + pad)
+            // scratch: the image the last unit was computed from (`fimg` after the rotation) -- free until the next unit's taps issue the
+            // halo pieces of the unit NIMG - 1 ahead into it, which the barrier behind the epilogue holds back
+            char* const scrb = smem + fimg * HB + wave * SCRW;
+            const int piece = lane & (LPV - 1);
+            const int cop = n0 + 32 * wb + piece * PW;                               // first channel of this lane's piece
+            const bool cok = cop < g.Cout;
+            const bool wantStats = g.stats != nullptr;                               // kernel-uniform
+            float ssum[PW], ssq[PW];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
-            const bool wantStats = g.stats != nullptr;     // kernel-uniform
+            for (int e = 0; e < PW; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
 #pragma unroll
             for (int vb = 0; vb < NVB; ++vb) {
                 const int id = wa * NVB + vb;
-                const int od = d0 + id / (C::NBH * C::NBW), oh = h0 + ((id / C::NBW) % C::NBH) * 4 + lj, ow = w0 + (id % C::NBW) * 8 + li;
-                const bool ok = od < g.Do && oh < g.Ho && ow < g.Wo;
-                const unsigned vox = (unsigned)(((tb * g.Do + od) * g.Ho + oh) * g.Wo + ow);
-                const unsigned offY = ok ? vox * (unsigned)g.Cout * YE : OOB;
-                f32x4v rr[4];
-                if constexpr (!YH) {
-                    if (residual) {                        // kernel-uniform; the four loads of a block in flight together
-                        const unsigned offR = ok ? vox * (unsigned)g.Cout * 4u : OOB;
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int co = cb + 8 * g4;
-                            rr[g4] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_r, co < g.Cout ? offR + (unsigned)co * 4u : OOB, 0, 0));
-                        }
-                    }
-                }
-                const float okf = ok ? 1.f : 0.f;
+                const int od = d0 + id / (C::NBH * C::NBW), ohb = h0 + ((id / C::NBW) % C::NBH) * 4, owb = w0 + (id % C::NBW) * 8;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int co = cb + 8 * g4;
-                    float v[4];
+                    if constexpr (YH) {
+                        u32x2 p;
+                        p.x = pack2<BF>(acc[vb][4 * g4], acc[vb][4 * g4 + 1]);
+                        p.y = pack2<BF>(acc[vb][4 * g4 + 2], acc[vb][4 * g4 + 3]);
+                        *reinterpret_cast<u32x2*>(scrb + l31 * SROW + 16 * g4 + 8 * hf) = p;
+                    } else {
+                        f32x4v p;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = round_through<BF>(acc[vb][4 * g4 + e] + bia[4 * g4 + e]);
-                        acc[vb][4 * g4 + e] = 0.f;
+                        for (int e = 0; e < 4; ++e) p[e] = round_through<BF>(acc[vb][4 * g4 + e]);
+                        *reinterpret_cast<f32x4v*>(scrb + l31 * SROW + 32 * g4 + 16 * hf) = p;
                     }
-                    if constexpr (!YH) {
-                        if (residual) {
+                }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += rr[g4][e];
+                for (int k = 0; k < NK; ++k) {
+                    const int vloc = (64 / LPV) * k + lane / LPV;                  // voxel of the block this lane stores in instruction k
+                    const int tqr = vloc >> 2;
+                    const int rj = 2 * (tqr >> 2) + ((tqr ^ (tqr >> 1) ^ (tqr >> 2)) & 1), ri = 4 * ((tqr >> 1) & 1) + (vloc & 3);
+                    const int oh = ohb + rj, ow = owb + ri;
+                    const bool ok = od < g.Do && oh < g.Ho && ow < g.Wo;
+                    const unsigned vox = (unsigned)(((tb * g.Do + od) * g.Ho + oh) * g.Wo + ow);
+                    const unsigned off = (ok && cok) ? (vox * (unsigned)g.Cout + (unsigned)cop) * YE : OOB;
+                    u32x4 d = *reinterpret_cast<const u32x4*>(scrb + vloc * SROW + piece * 16);
+                    if constexpr (!YH) {
+                        if (residual) {                    // kernel-uniform
+                            const f32x4v r = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_r, off, 0, 0));
+                            f32x4v f = __builtin_bit_cast(f32x4v, d);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) f[e] += r[e];
+                            d = __builtin_bit_cast(u32x4, f);
                         }
                     }
                     if (wantStats) {
+                        const float okf = ok ? 1.f : 0.f;
+                        float v[PW];
+                        if constexpr (YH) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned wd = d[e];
+                                if (BF) {
+                                    v[2 * e] = __builtin_bit_cast(float, wd << 16);
+                                    v[2 * e + 1] = __builtin_bit_cast(float, wd & 0xffff0000u);
+                                } else {
+                                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                                    const h2 hv = __builtin_bit_cast(h2, wd);
+                                    v[2 * e] = (float)hv[0];
+                                    v[2 * e + 1] = (float)hv[1];
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const unsigned wd = d[e]; v[e] = __builtin_bit_cast(float, wd); }   // (by value: see conv_half.hip asf)
+                        }
+#pragma unroll
+                        for (int e = 0; e < PW; ++e) {
                             const float mv = okf * v[e];
-                            ssum[4 * g4 + e] += mv;
-                            ssq[4 * g4 + e] = fmaf(mv, v[e], ssq[4 * g4 + e]);
+                            ssum[e] += mv;
+                            ssq[e] = fmaf(mv, v[e], ssq[e]);
                         }
                     }
-                    const unsigned off = co < g.Cout ? offY + (unsigned)co * YE : OOB;
-                    if constexpr (YH) {
-                        u32x2 p;
-                        p.x = pack2<BF>(v[0], v[1]);
-                        p.y = pack2<BF>(v[2], v[3]);
-                        __builtin_amdgcn_raw_buffer_store_b64(p, rs_y, off, 0, 0);
-                    } else {
-                        u32x4 p;
-                        p.x = __builtin_bit_cast(unsigned, v[0]); p.y = __builtin_bit_cast(unsigned, v[1]);
-                        p.z = __builtin_bit_cast(unsigned, v[2]); p.w = __builtin_bit_cast(unsigned, v[3]);
-                        __builtin_amdgcn_raw_buffer_store_b128(p, rs_y, off, 0, 0);
-                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, off, 0, 0);
                 }
             }
+            acc_init(0, NVB);
             if (wantStats) {
-                // per-lane partials -> sums over the 32 voxel lanes, through this wave's scratch; fixed order, no workgroup barrier
-                float* scr = reinterpret_cast<float*>(smem + NIMG * HB + wave * SCRW);
-                const int cidx = lane & 31, half = lane >> 5;                    // reader: channel cb' = 8 g4 + 4 hf' + e <-> group cidx >> 2, element cidx & 3
+                // sums over the lanes that share a piece (lane bits above log2 LPV), fixed order; the piece's first lane writes the row
                 const int tpb = g.tilesD * g.tilesH * g.tilesW, mtile = (int)(L / g.nNt);
                 float* srow = g.stats + ((size_t)(mtile / tpb) * (2 * tpb) + (size_t)(mtile % tpb) * 2 + wa) * 2 * g.Cout;
-                const int cor = n0 + 32 * wb + cidx;
 #pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
+                for (int e = 0; e < PW; ++e) {
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        f32x4v o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = pass ? ssq[4 * g4 + e] : ssum[4 * g4 + e];
-                        *reinterpret_cast<f32x4v*>(reinterpret_cast<char*>(scr) + (g4 * 2 + hf) * SCRG + l31 * 16) = o;
+                    for (int o = LPV; o < 64; o <<= 1) {
+                        ssum[e] += __shfl_xor(ssum[e], o, 64);
+                        ssq[e] += __shfl_xor(ssq[e], o, 64);
                     }
-                    float v = 0.f;
+                }
+                if (lane < LPV && cok) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        v += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(scr) + (cidx >> 2) * SCRG + (16 * half + k) * 16 + (cidx & 3) * 4);
-                    v += __shfl_xor(v, 32, 64);
-                    if (half == 0 && cor < g.Cout) srow[pass * g.Cout + cor] = v;
+                    for (int e = 0; e < PW; ++e) { srow[cop + e] = ssum[e]; srow[g.Cout + cop + e] = ssq[e]; }
                 }
             }
         }
+        asm volatile("s_barrier" ::: "memory");              // every wave's scratch reads are done (their stores have been issued)
         stamp();
         L += Gn;
         if (it + 1 < nMine) tile_of(L, tb, d0, h0, w0);
@@ -392,10 +422,11 @@ __global__ __launch_bounds__(256, 1) void conv_f9h_kernel(const void* __restrict
 
 // the variants (filter, tile, images); H9Geom::variant indexes this list
 using H9_333_512 = Cfg<3, 3, 3, 8, 8, 8, 2>;
-using H9_333_256 = Cfg<3, 3, 3, 4, 8, 8, 2>;
+using H9_333_256 = Cfg<3, 3, 3, 4, 8, 8, 2, 2>;      // 256-voxel tiles, TWO workgroups per CU (256 registers per wave): one's epilogue / barrier waits under the other's MFMAs
 using H9_133_A = Cfg<1, 3, 3, 1, 16, 32, 3>;
 using H9_133_B = Cfg<1, 3, 3, 2, 16, 16, 3>;
 using H9_133_C = Cfg<1, 3, 3, 4, 8, 8, 3>;
+using H9_133_D = Cfg<1, 3, 3, 1, 8, 32, 3, 2>;       // 256-voxel tiles, two workgroups per CU
 
 template <class C> static int launch_cfg(const void* x, const unsigned short* wp, const float* bias, const float* residual, void* y,
                                          const H9Geom& g, size_t lds, unsigned grid, int bf16, bool yHalf, void* stream) {

@@ -4,7 +4,7 @@ The reference goldens pin ``Unet3D`` at dim 16 / 32 on 8^3 / 16^3 volumes, where
 16-bit conv needs >= 512 units, the pointwise GEMM >= 2048 rows, the one-kernel temporal attention C in {64, 128, 256} and 32 / 64
 frames, the flash attention its long-sequence builds).  Here the networks ``bench.py`` times run at their real sizes against
 ``oracle.iqt_oracle_b`` evaluated on the host in the same process (seconds), and a launch census (``_lib.census``) asserts that the
-kernels under test were really dispatched.  Reference: imagen_video.py:1585-1822 (Unet3D.forward), elucidated_imagen.py:329-358.
+kernels under test were really dispatched (round 4: ``conv3d_fwd_h(v9h)`` = conv_f9h_kernel carries the per-frame convs).  Reference: imagen_video.py:1585-1822 (Unet3D.forward), elucidated_imagen.py:329-358.
 
 Tolerances: fp32 as for Family A (tests/test_gpu_unet.py: max 2e-4 of max|ref|, rel-L2 <= 2e-5; gradients 1e-3 of max|ref|);
 autocast: rel-L2 to the fp32 oracle <= 1.5 x the round-off of the ORACLE ITSELF under ``torch.autocast('cpu')`` in that type -- the
@@ -51,10 +51,14 @@ def _inputs(B, F, S, seed):
 _ORACLE = {}
 
 
-def _oracle(tag, sd, cfg, x, t, lr, lt, mode):
-    """fp32 oracle output, or the oracle under CPU autocast in ``mode`` (cached per (net, mode): three parametrisations share them)."""
-    key = (tag, mode)
+def _oracle(tag, sd, cfg, x, t, lr, lt, mode, nb=None):
+    """fp32 oracle output, or the oracle under CPU autocast in ``mode`` (cached per (net, mode): three parametrisations share them).
+    ``nb``: only the first nb batch entries (torch's CPU fp16 matmuls are ~10x slower than its bf16 ones: the oracle's own fp16 round-off,
+    which only sets the tolerance, is measured on one entry)."""
+    key = (tag, mode, nb)
     if key not in _ORACLE:
+        if nb is not None:
+            x, t, lr, lt = x[:nb], t[:nb], lr[:nb], lt[:nb]
         with torch.no_grad():
             if mode == "fp32":
                 y = OB.unet3d_forward(sd, cfg, x, t, lowres_cond_img=lr, lowres_noise_times=lt)
@@ -63,6 +67,13 @@ def _oracle(tag, sd, cfg, x, t, lr, lt, mode):
                     y = OB.unet3d_forward(sd, cfg, x, t, lowres_cond_img=lr, lowres_noise_times=lt)
         _ORACLE[key] = y.float()
     return _ORACLE[key]
+
+
+def _own_roundoff(tag, sd, cfg, x, t, lr, lt, mode, y32):
+    """rel-L2 of the oracle under CPU autocast to the fp32 oracle (fp16: on the first batch entry)."""
+    nb = 1 if mode == "fp16" else None
+    ya = _oracle(tag, sd, cfg, x, t, lr, lt, mode, nb)
+    return rel(ya, y32[:ya.shape[0]])
 
 
 @pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
@@ -89,12 +100,12 @@ def test_unet3d_dim64_at_32cubed_vs_oracle(mode):
         assert r <= 2e-5, r
         assert c.count("conv3d_fwd(v9)") > 0 and c.count("mqa_attention_fwd") > 0 and c.count("conv3d_fwd(1x1x1") > 0
     else:
-        own_ref = rel(_oracle("u3", sd, cfg, x, t, lr, lt, mode), y32)            # the oracle's own round-off in this type
+        own_ref = _own_roundoff("u3", sd, cfg, x, t, lr, lt, mode, y32)           # the oracle's own round-off in this type
         got = rel(y, y32)
         assert 0 < got <= 1.5 * own_ref, (got, own_ref)
         # the production 16-bit kernels really ran: the persistent conv walk, the pointwise / temporal GEMM, the one-kernel temporal
         # attention block and the 16-bit GroupNorm-apply
-        for tag in ("conv3d_fwd_h(persistent)", "conv3d_fwd_h(gemm)", "temporal_attention_h", "gn_act_fwd_h", "mqa_attention_fwd_h"):
+        for tag in ("conv3d_fwd_h(v9h)", "conv3d_fwd_h(persistent)", "conv3d_fwd_h(gemm)", "temporal_attention_h", "gn_act_fwd_h", "mqa_attention_fwd_h"):
             assert c.count(tag) > 0, f"{tag} was not dispatched"
 
 
@@ -121,10 +132,10 @@ def test_c5_stage2_eval_at_64_frames_vs_oracle(mode):
         r = close(y, y32, 2e-4, "C5 stage 2 @ 64 x 32 x 32")
         assert r <= 2e-5, r
     else:
-        own_ref = rel(_oracle("c5s2", sd, cfg, x, t, lr, lt, mode), y32)
+        own_ref = _own_roundoff("c5s2", sd, cfg, x, t, lr, lt, mode, y32)
         got = rel(y, y32)
         assert 0 < got <= 1.5 * own_ref, (got, own_ref)
-        for tag in ("conv3d_fwd_h(persistent)", "conv3d_fwd_h(gemm)", "temporal_attention_h", "mqa_attention_fwd_h"):
+        for tag in ("conv3d_fwd_h(v9h)", "conv3d_fwd_h(persistent)", "conv3d_fwd_h(gemm)", "temporal_attention_h", "mqa_attention_fwd_h"):
             assert c.count(tag) > 0, f"{tag} was not dispatched"
 
 

@@ -1,6 +1,6 @@
 """In-kernel cycle stamps of conv_f9h_kernel on one shape (DIQT_F9H_DBG=1).   python tools/f9h_stamps.py B D H W Cin Cout kd kh kw xh yh"""
 import ctypes, os, sys
-os.environ["DIQT_F9H_DBG"] = "1"
+os.environ.setdefault("DIQT_F9H_DBG", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -27,15 +27,21 @@ fn = ctypes.CDLL(_lib.LIB_PATH).diqt_debug_f9h_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_uint]
 nw = fn(buf.ctypes.data, 1024)
 s = buf[:nw].astype(np.int64)
-t0 = s[:, 0:1]
-rel = s - t0
-valid = (s > 0)
-nst = int(valid[0].sum())
-print(f"{nw} waves, {nst} stamps per wave; median cycles since the wave's start, and the median step from the previous stamp:")
-med = np.median(rel[:, :nst], axis=0)
-step = np.median(np.diff(rel[:, :nst], axis=1), axis=0)
+start, end = s[:, 30], s[:, 31]
+body = s[:, :28]
+rt0, rt1 = s[:, 28], s[:, 29]
+nst = int((body[0] > 0).sum())
+rel = body[:, :nst] - body[:, 0:1]
+print(f"{nw} waves, {nst} stamps per wave; median cycles since the first recorded stamp, and the median step from the previous stamp:")
+med = np.median(rel, axis=0)
+step = np.median(np.diff(rel, axis=1), axis=0)
 for i in range(nst):
     print(f"  stamp {i:2d}: {med[i]:9.0f}   (+{step[i - 1] if i else 0:8.0f})")
-span = s[:, :nst].max() - s[:, 0].min()
-print(f"first start -> last end over all waves: {span} cycles; per-wave lifetime median {np.median(rel[:, nst - 1]):.0f}, max {rel[:, nst - 1].max()}")
-print("spread of wave start times: ", int(s[:, 0].max() - s[:, 0].min()))
+life = end - start
+clk = (end - start) / np.maximum(rt1 - rt0, 1) * 100.0
+print(f"in-kernel clock (cycles per 100 MHz tick): median {np.median(clk):.0f} MHz, min {clk.min():.0f}, max {clk.max():.0f}; kernel span by the real-time counter: {(rt1.max() - rt0.min()) / 100.0:.1f} us, start spread {(rt0.max() - rt0.min()) / 100.0:.1f} us, end spread {(rt1.max() - rt1.min()) / 100.0:.1f} us")
+print(f"wave lifetime: median {np.median(life):.0f}, min {life.min()}, max {life.max()} cycles")
+print(f"kernel: first start -> last end {end.max() - start.min()} cycles; start times spread {start.max() - start.min()}, end times spread {end.max() - end.min()}")
+wg = start.reshape(-1, 4)[:, 0]
+order = np.argsort(wg)
+print("workgroup start offsets (sorted, every 32nd):", (wg[order] - wg.min())[::32])

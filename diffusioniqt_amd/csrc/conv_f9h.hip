@@ -31,22 +31,21 @@ extern "C" int diqt_debug_f9h_stamps(unsigned long long* host_out, unsigned max_
 
 namespace diqt {
 
-template <class C> static bool f9h_try(H9Geom& g, size_t& lds, unsigned& grid, int mode) {
+// One candidate tiling: tile counts, grid, and an estimate of the launch's duration in (voxel x workgroup-round) units -- rounds of
+// 256 OCC workgroup slots, each round as long as a tile (two workgroups sharing a CU run at half speed each).
+template <class C> static bool f9h_try(H9Geom& g, size_t& lds, unsigned& grid, double& est) {
     g.tilesD = (g.Do + C::TD - 1) / C::TD; g.tilesH = (g.Ho + C::TH - 1) / C::TH; g.tilesW = (g.Wo + C::TW - 1) / C::TW;
     const long long mt = (long long)g.B * g.tilesD * g.tilesH * g.tilesW;
     if (mt >= (1ll << 30)) return false;
     g.MT = (int)mt;
-    const double useful = (double)g.Do * g.Ho * g.Wo / ((double)g.tilesD * g.tilesH * g.tilesW * (double)(C::TD * C::TH * C::TW));
     const long long nwg = mt * g.nNt;
-    // one workgroup per CU: whole rounds of 256 (a ragged last round idles the rest of the chip for a tile's time)
     const long long slots = 256 * C::OCC;
-    // fill: one round needs at least 200 workgroups (one per CU; the second slot of a two-workgroup build may stay empty); more rounds have to
-    // be mostly full (a ragged last round idles the chip for a tile's time)
-    if (mode != 2 && (useful < 0.85 || nwg < 200 || (nwg > slots && (double)nwg / (double)((nwg + slots - 1) / slots * slots) < 0.78))) return false;
     // persistent walk: a workgroup keeps its 64-channel block (its weight stream)
     unsigned gr = nwg > slots ? (unsigned)slots : (unsigned)nwg;
     if (nwg > slots) gr -= gr % (unsigned)g.nNt;
     if (gr == 0) return false;
+    const long long rounds = (nwg + gr - 1) / gr;
+    est = (double)rounds * (double)(C::TD * C::TH * C::TW) * (double)C::OCC * (nwg <= 256 ? 1.0 / C::OCC : 1.0);   // one workgroup per CU: full speed
     grid = gr;
     lds = C::LDS_BYTES;
     return true;
@@ -69,11 +68,14 @@ bool f9h_plan(H9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W
     const unsigned long long wb = (unsigned long long)g.nChunks * kd * kh * kw * g.CoutPad * h9::CK * 2ull;
     if (xb >= (1ull << 30) || rb >= (1ull << 31) || wb >= (1ull << 30)) return false;
     g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.rBytes = (unsigned)rb; g.wBytes = (unsigned)wb; g.stats = nullptr; g.dbg = nullptr; g.dbgSkip = 0;
+    // the candidate with the shortest estimate wins; ties go to the earlier one = the measured preference (MI355X, round 4): the 256-voxel
+    // tiles at two workgroups per CU are 0-8 % faster than the 512-voxel ones on the 3x3x3 shapes of C2 (58.7 vs 63.4 us on 64 -> 64 @
+    // 8 x 32^3 with an fp32 y) and on the 64-channel per-frame convs (208 vs 219 us @ 8 x 64^3), 4 % slower at 128 channels.  Small
+    // grids are taken too: 128 -> 128 @ 8 x 8^3 (32 workgroups) 21.7 us against 47.6 us on conv_fwd_h_kernel.
     static const int force = [] { const char* e = getenv("DIQT_F9H_VARIANT"); return e ? atoi(e) : -1; }();      // experiments: this variant only
-#define F9H_TRY(CFG, V) if ((force < 0 || force == V) && f9h_try<h9::CFG>(g, lds, grid, mode)) { g.variant = V; return true; }
-    // order = measured preference (MI355X, round 4): the 256-voxel tiles at two workgroups per CU are 0-8 % faster than the 512-voxel ones on
-    // the 3x3x3 shapes of C2 (58.7 vs 63.4 us on 64 -> 64 @ 8 x 32^3 with an fp32 y) and on the 64-channel per-frame convs (208 vs 219 us @
-    // 8 x 64^3), 4 % slower at 128 channels; a start skew between the two workgroups of a CU changed nothing
+    H9Geom best = g; size_t bl = 0; unsigned bg = 0; double be = 1e300; int bv = -1;
+#define F9H_TRY(CFG, V) if (force < 0 || force == V) { H9Geom t = g; size_t l_; unsigned g_; double e_; \
+        if (f9h_try<h9::CFG>(t, l_, g_, e_) && e_ < be) { best = t; bl = l_; bg = g_; be = e_; bv = V; } }
     if (k333) {
         F9H_TRY(H9_333_256, 1)
         F9H_TRY(H9_333_512, 0)
@@ -85,7 +87,12 @@ bool f9h_plan(H9Geom& g, size_t& lds, unsigned& grid, int B, int D, int H, int W
         F9H_TRY(H9_133_C, 4)
     }
 #undef F9H_TRY
-    return false;
+    if (bv < 0) return false;
+    // tiles that are mostly padding (a volume much smaller than any tile): leave the launch to the other kernels
+    const double usefulVox = (double)g.B * g.Do * g.Ho * g.Wo * g.nNt;
+    if (mode != 2 && be * 256.0 > 6.0 * (usefulVox < 256.0 * 256.0 ? 256.0 * 256.0 : usefulVox)) return false;
+    g = best; g.variant = bv; lds = bl; grid = bg;
+    return true;
 }
 
 int f9h_stats_blocks(const H9Geom& g) { return g.tilesD * g.tilesH * g.tilesW * 2; }

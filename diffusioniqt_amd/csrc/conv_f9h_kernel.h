@@ -22,7 +22,7 @@
 //     s_waitcnt of our own at all: the wait hipcc puts in front of the last tap's weight fragment (issued after every halo piece of the
 //     image the next chunk needs) is what guarantees that image before the barrier.
 //   * persistent tile walk with the weight stream running on (the packed [chunk][tap] order is one linear sequence, wrapped per tile).
-//   * epilogue: bias, round to the operand type (autocast semantics), optional fp32 residual, optional column sums (sum, sum of squares
+//   * epilogue: bias (fp32, behind the K sum: bit-identical to the older 16-bit kernels), round to the operand type (autocast semantics), optional fp32 residual, optional column sums (sum, sum of squares
 //     of the STORED values) per (tile, voxel half) for the consumer's GroupNorm -- per-lane partials over the wave's blocks, reduced over
 //     the 32 voxel lanes through a wave-private, bank-skewed LDS scratch in a fixed order (deterministic, no barrier).
 // Lane <-> voxel map of a block (rows j = 0..3, columns i = 0..7), t = l31 >> 2:  j = 2 t2 + parity(t),  i = 4 t1 + (l31 & 3).
@@ -207,23 +207,16 @@ __global__ __launch_bounds__(256, C::OCC) void conv_f9h_kernel(const void* __res
             xa[ky][kx] = (C::blockrow(0) + (wa ? C::blockrow(NVB) : 0) + lj * HWd + li) * ROWB + ((hf ^ gx) << 4) + (gy << 5);
         }
 
-    // output channels of this lane's accumulator rows: cb + 8 (r >> 2) + (r & 3); the accumulators START from the bias (re-loaded per
-    // tile instead of held in 16 registers: the 256-register builds need them)
+    // output channels of this lane's accumulator rows: cb + 8 (r >> 2) + (r & 3).  The bias is added in fp32 BEHIND the K sum, as in
+    // conv_fwd_h_kernel / conv_fwd_hp_kernel (same chunk -> tap -> k-half order of the sum too): the three kernels agree bit for bit.
+    // (It is re-loaded per tile instead of held in 16 registers: the 256-register builds need them.)
     const int cb = n0 + 32 * wb + 4 * hf;
     const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? g.Cout * 4 : 0, 0x00020000);
     f32x16 acc[NVB];
-    auto acc_init = [&](int vb0, int vb1) __attribute__((always_inline)) {
-        f32x4v b4[4];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-            b4[g4] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (unsigned)(cb + 8 * g4) * 4u, 0, 0));
+    for (int vb = 0; vb < NVB; ++vb)
 #pragma unroll
-        for (int vb = 0; vb < NVB; ++vb)
-            if (vb >= vb0 && vb < vb1)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[vb][i] = b4[i >> 2][i & 3];
-    };
-    acc_init(0, NVB);
+        for (int i = 0; i < 16; ++i) acc[vb][i] = 0.f;
 
     // ---- prologue: the first NIMG - 1 units' halo images, the first PD - 1 weight panels ----
     int fit = 0, fc = 0;                                   // (tile iteration, chunk) of the unit being fetched
@@ -324,6 +317,10 @@ __global__ __launch_bounds__(256, C::OCC) void conv_f9h_kernel(const void* __res
             float ssum[PW], ssq[PW];
 #pragma unroll
             for (int e = 0; e < PW; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+            f32x4v b4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                b4[g4] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (unsigned)(cb + 8 * g4) * 4u, 0, 0));
 #pragma unroll
             for (int vb = 0; vb < NVB; ++vb) {
                 const int id = wa * NVB + vb;
@@ -332,15 +329,17 @@ __global__ __launch_bounds__(256, C::OCC) void conv_f9h_kernel(const void* __res
                 for (int g4 = 0; g4 < 4; ++g4) {
                     if constexpr (YH) {
                         u32x2 p;
-                        p.x = pack2<BF>(acc[vb][4 * g4], acc[vb][4 * g4 + 1]);
-                        p.y = pack2<BF>(acc[vb][4 * g4 + 2], acc[vb][4 * g4 + 3]);
+                        p.x = pack2<BF>(acc[vb][4 * g4] + b4[g4][0], acc[vb][4 * g4 + 1] + b4[g4][1]);
+                        p.y = pack2<BF>(acc[vb][4 * g4 + 2] + b4[g4][2], acc[vb][4 * g4 + 3] + b4[g4][3]);
                         *reinterpret_cast<u32x2*>(scrb + l31 * SROW + 16 * g4 + 8 * hf) = p;
                     } else {
                         f32x4v p;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) p[e] = round_through<BF>(acc[vb][4 * g4 + e]);
+                        for (int e = 0; e < 4; ++e) p[e] = round_through<BF>(acc[vb][4 * g4 + e] + b4[g4][e]);
                         *reinterpret_cast<f32x4v*>(scrb + l31 * SROW + 32 * g4 + 16 * hf) = p;
                     }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[vb][4 * g4 + e] = 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
@@ -392,7 +391,6 @@ __global__ __launch_bounds__(256, C::OCC) void conv_f9h_kernel(const void* __res
                     __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, off, 0, 0);
                 }
             }
-            acc_init(0, NVB);
             if (wantStats) {
                 // sums over the lanes that share a piece (lane bits above log2 LPV), fixed order; the piece's first lane writes the row
                 const int tpb = g.tilesD * g.tilesH * g.tilesW, mtile = (int)(L / g.nNt);

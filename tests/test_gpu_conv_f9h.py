@@ -135,3 +135,35 @@ def test_conv_f9h_random_data_within_one_ulp_of_the_operand_type(bf16):
     ulp = 2.0 ** (-10 if not bf16 else -7)
     err = (got - ref).abs()
     assert (err <= ulp * ref.abs().clamp_min(2.0 ** -8) * 0.51 + 1e-6).all(), err.max()      # one rounding of an fp32-accumulated sum
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_conv_f9h_equals_the_persistent_16_bit_kernel_bit_for_bit_on_random_data(bf16):
+    """Same K order (chunk -> tap -> k-half), fp32 bias behind the sum, one rounding: conv_f9h_kernel and conv_fwd_hp_kernel agree in every
+    bit on random data too, so switching kernels by shape (the planner) never changes a result."""
+    from diffusioniqt_amd import _lib
+    _lib.load()
+    B, D, H, W, Cin, Cout = 2, 6, 24, 40, 96, 72
+    geo = (B, D, H, W, Cin, Cout, 1, 3, 3, 0, 1, 1, 0, 0, 0)
+    dt = LP[bf16]
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, D, H, W, Cin, generator=g).to(DEV).to(dt)
+    w = (torch.randn(Cout, Cin, 1, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    n = _lib.query("diqt_conv_packed_h_elems", Cout, Cin, 1, 3, 3)
+    packed = torch.empty(n, dtype=torch.int16, device=DEV)
+    _lib.call("diqt_conv_pack_weight_h", w, packed, Cout, Cin, 1, 3, 3, 0, bf16, st)
+    outs = []
+    for mode, tag in ((2, "conv3d_fwd_h(v9h)"), (0, "conv3d_fwd_h(persistent)")):
+        prev, prevw = _lib.query("diqt_set_conv_f9h_mode", mode), _lib.query("diqt_set_convh_workgroups", 3)
+        try:
+            y = torch.empty(B, D, H, W, Cout, dtype=dt, device=DEV)
+            with _lib.census() as c:
+                _lib.call("diqt_conv3d_fwd_h_io", x, packed, bias, None, y, *geo, bf16, 1, 1, 1, None, st)
+                torch.cuda.synchronize()
+                assert c.count(tag) == 1, tag
+            outs.append(y)
+        finally:
+            _lib.query("diqt_set_conv_f9h_mode", prev); _lib.query("diqt_set_convh_workgroups", prevw)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))

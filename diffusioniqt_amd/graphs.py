@@ -13,6 +13,7 @@ parameters' version counters, so an optimizer step or a `load_state_dict` retire
 """
 import os
 import time
+import weakref
 
 import torch
 
@@ -36,8 +37,20 @@ def _sig(v):
     raise _Uncapturable(type(v).__name__)
 
 
+_CACHES = weakref.WeakSet()
+
+
+def drop_all():
+    """A parameter update made every captured graph stale (the keys hold ``ops._WEIGHT_EPOCH``): drop them NOW, not when their module is next
+    sampled from -- while a graph lives, ops.retire() parks every packed-weight copy the training steps replace (one set per optimiser
+    step: the bf16 training micro-step of bench.py went from 17.4 to 20-21 ms behind a live sampling graph, and the pins grew without bound)."""
+    for c in list(_CACHES):
+        c.clear()
+
+
 class GraphCache:
     def __init__(self, warm=2, max_entries=4):
+        _CACHES.add(self)
         self.entries = {}
         self.warm, self.max_entries = warm, max_entries
         self.replays = 0                                 # diagnostics / tests

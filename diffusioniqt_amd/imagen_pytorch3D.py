@@ -1068,6 +1068,8 @@ class Imagen(nn.Module):
     ):
         super().__init__()
         self.configs = configs
+        from .graphs import GraphCache
+        self._graphs = GraphCache()           # hipGraph replay of launch-bound U-Net evaluations of the sampling loop (graphs.py)
         self.medlpips = medlpips
         self.boundary = boundary
         assert not lpips and not medlpips, 'perceptual losses are dead code in the reference (SURVEY.md §2 #10)'
@@ -1176,6 +1178,16 @@ class Imagen(nn.Module):
             return -1., 1., 1          # clamp_(-1, 1)            (:2023-2024)
         return float(self.min_bound), 0., 0   # clamp_(min = min_bound)  (:2025-2026)
 
+    def unet_eval(self, unet, img, cond, *, lowres_cond_img=None, cond_images=None, cond_scale=1., self_cond=None):
+        """One U-Net evaluation of the sampling loop (``unet.forward_with_cond_scale``, imagen_pytorch3D.py:2029-2031 of the reference).  When it
+        is launch-bound -- under autocast the C2 eval is ~3.2 ms of kernels behind ~3.3 ms of Python-issued launches -- the third call with the
+        same shapes / weights / precision is captured into a hipGraph and replayed from then on (bit-identical: the same launches); GPU-bound
+        evaluations (fp32) stay eager (graphs.py decides from the timed second call)."""
+        def fwd(x, c, **kw):
+            return unet.forward_with_cond_scale(x, None, c, **kw)
+        kw = dict(cond_images=cond_images, cond_scale=cond_scale, lowres_cond_img=lowres_cond_img, self_cond=self_cond)
+        return self._graphs.run(unet, fwd, (img, cond), kw)
+
     @torch.no_grad()
     def p_sample_loop(self, unet, shape, *, noise_scheduler, lowres_cond_img=None, cond_images=None, inpaint_images=None,
                       inpaint_masks=None, inpaint_resample_times=5, init_images=None, skip_steps=None, cond_scale=1,
@@ -1231,8 +1243,8 @@ class Imagen(nn.Module):
                 if has_inpainting:                                                         # (:2119-2123)
                     noised = ops.q_sample(inpaint_images, draw(), qs[i, 0], qs[i, 1])
                     img = ops.mask_blend(img, noised, mask_f)
-                pred = unet.forward_with_cond_scale(img, None, conds[i], cond_images=cond_images, cond_scale=cond_scale,
-                                                    lowres_cond_img=lowres, self_cond=x_start if unet.self_cond else None)
+                pred = self.unet_eval(unet, img, conds[i], cond_images=cond_images, cond_scale=cond_scale,
+                                      lowres_cond_img=lowres, self_cond=x_start if unet.self_cond else None)
                 pred = pred.contiguous()
                 if pred_objective != 'x_start':                                            # (:1996-2003)
                     pred = ops.axpby3(img, pred, None, x0c[i, 0], x0c[i, 1], None, 0.0, 0.0, 0)

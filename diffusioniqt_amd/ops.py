@@ -19,6 +19,9 @@ _WEIGHT_EPOCH = 0     # bumped by the fused optimiser (it writes parameters thro
 def bump_weight_epoch():
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
+    if _LIVE_GRAPHS > 0:          # every captured graph froze the old weights' packed copies: stale from here on (graphs.drop_all)
+        from . import graphs
+        graphs.drop_all()
 
 
 # A captured hipGraph (graphs.py) holds raw device addresses of everything its launches read: besides the tensors of its private pool

@@ -55,3 +55,22 @@ def test_retired_cache_tensors_are_pinned_while_a_graph_is_alive():
     cache.entries[(1, 'old')] = dict(graph=object(), failed=False, calls=9)
     cache._drop([(1, 'old')])
     assert not ops._GRAPH_PINS and ops._LIVE_GRAPHS == 0
+
+
+def test_a_weight_update_drops_every_captured_graph():
+    """The fused optimiser bumps ops._WEIGHT_EPOCH: every captured graph is stale from then on (its key holds the epoch) and is dropped at
+    once -- a live graph makes ops.retire() park every packed-weight copy training replaces, one set per optimiser step."""
+    from diffusioniqt_amd import ops
+    ops.graphs_alive(-10 ** 6)
+    c1, c2 = graphs.GraphCache(), graphs.GraphCache()
+    c1.entries[(1, 'a')] = dict(graph=object(), failed=False, calls=9)
+    c2.entries[(2, 'b')] = dict(graph=object(), failed=False, calls=9)
+    c2.entries[(3, 'c')] = dict(graph=None, failed=False, calls=1)               # still in its eager warm-up
+    ops.graphs_alive(+2)
+    ops.retire(torch.zeros(3))
+    assert len(ops._GRAPH_PINS) == 1
+    ops.bump_weight_epoch()
+    assert not c1.entries and not c2.entries and ops._LIVE_GRAPHS == 0 and not ops._GRAPH_PINS
+    e = ops._WEIGHT_EPOCH
+    ops.bump_weight_epoch()                                                      # nothing alive: just the counter
+    assert ops._WEIGHT_EPOCH == e + 1

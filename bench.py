@@ -109,6 +109,33 @@ def latest_profile(pattern_fn):
     return os.path.join(d, names[0]) if names else None
 
 
+def pmc_traffic_of(tag, kernel):
+    """HBM bytes per average launch of ``kernel`` from the committed rocprofv3 --pmc passes of the ``tag`` workload (``C4``, ``C5``,
+    ``unet3d``: profiles/rNN_pmc_hbm_traffic_<tag>.json, collected by tools/collect_profiles.sh), or None."""
+    path = latest_profile(lambda n: n.endswith(f"_pmc_hbm_traffic_{tag}.json"))
+    if path is None:
+        return None
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]
+        return next(v["hbm_bytes_per_launch"] for name, v in k.items() if kernel in name)
+    except Exception:
+        return None
+
+
+def pmc_mfma_busy(tag):
+    """Matrix-pipe busy fraction of a whole workload (``train``, ``unet3d_eval``, ``unet3d_train``, ``sample``) from the committed SQ counter
+    pass (profiles/rNN_pmc_sq_workloads.json: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES per CU ...), see its `formula`), or None."""
+    path = latest_profile(lambda n: n.endswith("_pmc_sq_workloads.json"))
+    if path is None:
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f)["workloads"][tag]["mfma_busy_frac"]
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel, batch, size):
     """HBM bytes per average launch of ``kernel`` in one C2 sampler step, from the committed rocprofv3 --pmc passes of this
     command (FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled for gfx950, MI355X_MICROARCH.md).
@@ -290,6 +317,9 @@ def bench_c4(args, torch, ops, device, world, timed, instrumented, roofline_of):
                       "global_batch": world * B, "patch": "64^3", "parallelism": f"dp{world}"},
            "whole_step_tflops": round(GFLOP_C4_EVAL * B / ms, 2), "whole_step_frac_of_f32_mfma_peak": round(GFLOP_C4_EVAL * B / ms / PEAK_F32_MFMA_TFLOPS, 4),
            "roofline": roofline_of(summ, PEAK_F32_MFMA_TFLOPS, step_ms=ms, n_steps=3), "cpu_baseline": None}
+    if res["roofline"] is not None:
+        res["roofline"]["traffic"] = pmc_traffic_of("C4", res["roofline"]["kernel"])
+        res["roofline"]["traffic_note"] = "HBM bytes per average launch from the committed rocprofv3 --pmc passes of `bench.py --config C4` (profiles/)"
 
     def step_h():
         with torch.autocast('cuda', dtype=torch.float16):
@@ -341,6 +371,10 @@ def bench_c5(args, torch, ops, device, world, timed, instrumented, roofline_of):
            "whole_step_tflops": round(tflop_per_sample * B / (ms * 1e-3), 1),
            "whole_step_frac_of_f16_mfma_peak": round(tflop_per_sample * B / (ms * 1e-3) / PEAK_F16_MFMA_TFLOPS, 4),
            "roofline": roofline_of(summ, PEAK_F16_MFMA_TFLOPS), "cpu_baseline": None}
+    if res["roofline"] is not None:
+        res["roofline"]["traffic"] = pmc_traffic_of("C5", res["roofline"]["kernel"])
+        res["roofline"]["traffic_note"] = ("HBM bytes per average launch from the committed rocprofv3 --pmc passes of one stage-2 eval "
+                                           "(tools/unet3d_bench.py 64 64 8 under autocast fp16; profiles/)")
     return res
 
 
@@ -508,6 +542,11 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
                                     patch_evals_per_s=world * B * (2 * n3 - 1) / dts, fwd_bwd_ms=1e3 * dtt, fwd_bwd_patches_per_s=world * B / dtt, fwd_bwd_bf16_ms=1e3 * dtb,
                                     fwd_bwd_frac_of_f32_mfma_peak=3 * GFLOP_U3_EVAL * B / (1e3 * dtt) / PEAK_F32_MFMA_TFLOPS)
         result["unet3d_roofline"] = roofline_of(summ3, PEAK_F32_MFMA_TFLOPS, step_ms=1e3 * dte, n_steps=2)
+        if result["unet3d_roofline"] is not None:
+            result["unet3d_roofline"]["traffic"] = pmc_traffic_of("unet3d", result["unet3d_roofline"]["kernel"])
+            result["unet3d_roofline"]["traffic_note"] = "committed rocprofv3 --pmc passes of tools/unet3d_bench.py 64 32 8 (profiles/)"
+        result["unet3d_edm"]["mfma_busy_frac_eval"] = pmc_mfma_busy("unet3d_eval")
+        result["unet3d_edm"]["mfma_busy_frac_fwd_bwd"] = pmc_mfma_busy("unet3d_train")
         del u3, elu3
 
     # ---------------- training: K micro-steps through ImagenTrainer.forward ----------------
@@ -522,7 +561,8 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
         kt = K if args.mode == "train" else max(4, K // 2)
         kt = (kt + 3) // 4 * 4                               # whole accumulation cycles: one all-reduce + Adam per 4 micro-steps
         dt = timed(train_step, max(W, 4) // 4 * 4, kt)
-        result["train"] = dict(ms_per_step=1e3 * dt / kt, steps_per_s=kt / dt, patches_per_s=world * B * kt / dt, steps=kt)
+        result["train"] = dict(ms_per_step=1e3 * dt / kt, steps_per_s=kt / dt, patches_per_s=world * B * kt / dt, steps=kt,
+                               mfma_busy_frac=pmc_mfma_busy("train"))
         summ_t = instrumented(train_step, 4)
         wg = {k: v for k, v in summ_t.items() if k.startswith("conv_bwd_weight") or k.startswith("conv_wgrad")}
         tr = roofline_of(wg, PEAK_F32_MFMA_TFLOPS, prefer="conv_wgrad3_kernel", step_ms=result["train"]["ms_per_step"], n_steps=4)
@@ -690,7 +730,15 @@ def cpu_baseline(torch, unet, S, min_bound):
             x_c = mean + (0.5 * logvar).exp() * torch.randn_like(x_c)
             n_it += 1
         dtc = time.perf_counter() - t0
-    return dict(value=round(nb * n_it / dtc, 3), unit="patches/s", cores=torch.get_num_threads(), kind="port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.lower().startswith("model name")), "unknown")
+    except OSError:
+        pass
+    # cores = the torch threads the timed loop used (the fastest of the probed counts); host_cores = what the box has
+    return dict(value=round(nb * n_it / dtc, 3), unit="patches/s", cores=torch.get_num_threads(), host_cores=ncores, cpu_model=cpu_model,
+                torch_version=str(torch.__version__), kind="port",
                 sample=f"{n_it} DDPM sampler steps (U-Net eval + posterior step) of {nb} 32^3 patches, oracle/iqt_oracle.py "
                        f"on torch-CPU fp32, anomaly detection off")
 

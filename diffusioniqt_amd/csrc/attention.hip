@@ -11,6 +11,13 @@
 //   O^T[d][query] += V^T P^T         (A = V tile from LDS, B = P^T straight from the S^T registers, no LDS round trip).
 // Key pair of MFMA step s: rows (s&3) + 8*(s>>2) + 4*half of the 32-key tile, for both operands.
 #include "common.h"
+#ifndef DIQT_DQ_OCC
+// mqa_flash_bwd_dq_kernel: workgroups per CU.  At 2 the d = 64 build is held to 256 registers per wave and spills 92 B per lane; at 1 it
+// takes 255 + 52 registers and nothing spills -- and runs SLOWER: 1139 vs 935 us per call of the joint 2048-token attention backward of
+// Unet3D dim 64 @ 32^3 (rocprofv3 kernel trace, same box, round 4): the second workgroup's latency hiding is worth more than the
+// spilled values cost (they are re-read outside the key-tile loop).  Measured, kept at 2.
+#define DIQT_DQ_OCC 2
+#endif
 
 namespace diqt {
 
@@ -610,7 +617,7 @@ extern "C" int diqt_mqa_attention_fwd_h(const float* q, const void* kv, const fl
 __device__ __forceinline__ int acc_row(int i, int hf) { return (i & 3) + 8 * (i >> 2) + 4 * hf; }
 
 template <int ND>
-__global__ __launch_bounds__(256, 2) void mqa_flash_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+__global__ __launch_bounds__(256, DIQT_DQ_OCC) void mqa_flash_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                                   const float* __restrict__ rel, const float* __restrict__ null_bias,
                                                                   const float* __restrict__ out, const float* __restrict__ dout,
                                                                   const float* __restrict__ lse, float* __restrict__ dq,

@@ -1,11 +1,15 @@
 set -o pipefail
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-run() { BENCH_PROF=1 timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $R/gpurun_out/t21_b.json 2> $R/gpurun_out/t21_b.err; grep "\[prof\]" $R/gpurun_out/t21_b.err; python - "$1" $R <<'P'
-import json,sys
-d=json.loads(open(sys.argv[2]+'/gpurun_out/t21_b.json').read().strip().splitlines()[-1])
-print(sys.argv[1], d.get('value'), {k:(v.get('ms_per_step') if isinstance(v,dict) else None) for k,v in d.items() if k in ('train','train_bf16','autocast_fp16')})
+cd /tmp && export TMPDIR=/tmp
+for v in occ1 occ2; do
+  if [ $v = occ2 ]; then export DIQT_LIB=$R/gpurun_libocc2.so; else unset DIQT_LIB; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pa_$v -o a -- python3 $R/tools/unet3d_train_bench.py 64 32 8 > $R/gpurun_out/t24_$v.log 2>&1
+  grep -i "ms" $R/gpurun_out/t24_$v.log | tail -2
+  python3 - $v <<'P'
+import csv,glob,sys
+f=sorted(glob.glob(f'/tmp/pa_{sys.argv[1]}/**/*kernel_stats.csv',recursive=True))[-1]
+for r in csv.DictReader(open(f)):
+    if 'mqa_' in r['Name']: print(sys.argv[1], f"{int(r['Calls']):5d} x {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:70]}")
 P
-}
-cd $R; BENCH_DBG=direct run "direct"
-cd $R; run "unet_eval"
+done

@@ -30,3 +30,31 @@ python3 $R/tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write $OUT/pmc_hbm_traff
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/pmc_sq -- python3 $R/tools/conv_bench.py both 10 > $OUT/pmc_sq.log 2>&1
 cp $(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1) $OUT/pmc_sq_counter_collection.csv
 echo "done sq"
+# ---- round 4 ----
+# C4 eval kernel stats; HBM traffic (two passes each) of the C4 eval, of one C5 stage-2 eval under autocast and of the Family-B eval
+stats c4_eval python3 $R/bench.py --config C4 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timer
+stats sample_autocast python3 $R/tools/autocast_bench.py
+traffic() {  # tag, command...
+  local t=$1; shift
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmcf_$t -- "$@" > $OUT/pmc_fetch_$t.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmcw_$t -- "$@" > $OUT/pmc_write_$t.log 2>&1
+  python3 $R/tools/pmc_traffic.py /tmp/pmcf_$t /tmp/pmcw_$t $OUT/pmc_hbm_traffic_$t.json "$*"
+  echo "done traffic $t"
+}
+traffic C4 python3 $R/bench.py --config C4 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer
+NO_LAYER_ATTNS=1 AUTOCAST=fp16 traffic C5 python3 $R/tools/unet3d_bench.py 64 64 8
+traffic unet3d python3 $R/tools/unet3d_bench.py 64 32 8
+# matrix-pipe busy fraction of whole workloads (SQ counters, own passes) and the conv_f9h_kernel counter set
+sq() {  # tag, command...
+  local t=$1; shift
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/sq_$t -- "$@" > $OUT/sq_$t.log 2>&1
+  cp $(find /tmp/sq_$t -name "*counter_collection.csv" | head -1) $OUT/sq_${t}_counter_collection.csv
+  echo "done sq $t"
+}
+sq sample python3 $R/bench.py --mode sample --steps 6 --warmup 2 $B
+sq train python3 $R/bench.py --mode train --steps 8 --warmup 4 $B
+sq unet3d_eval python3 $R/tools/unet3d_bench.py 64 32 8
+sq unet3d_train python3 $R/tools/unet3d_train_bench.py 64 32 8
+sq f9h_333 python3 $R/tools/convh_io_bench.py 8 32 32 32 64 64 3 3 3 1 1
+sq f9h_133 python3 $R/tools/convh_io_bench.py 8 64 64 64 64 64 1 3 3 1 1
+python3 $R/tools/pmc_sq_workloads.py $OUT $OUT/pmc_sq_workloads.json

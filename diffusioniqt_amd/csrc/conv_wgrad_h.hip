@@ -74,10 +74,14 @@ __device__ __forceinline__ u32x4w tr_frag(const unsigned char* p, int rowBytes) 
     return r;
 }
 
-template <class C, bool BF>
+// XH: x holds 16-bit values of the operand type (the GroupNorm-apply output a bf16 training step saved in that type, ops._GnActConvHFn):
+// a piece is 8 channels and goes to the LDS image as it is -- the same bits the fp32 tensor's values round to while staged.
+template <class C, bool BF, bool XH = false>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ slabs, float* __restrict__ bias_part, WHGeom g) {
-    constexpr int WT = C::T, NA = C::NA, WHH = C::HH, WHW = C::HW, WHV = C::HV, NPX = C::NPX;
+    constexpr int WT = C::T, NA = C::NA, WHH = C::HH, WHW = C::HW, WHV = C::HV, NPX = XH ? (C::HV * 4 + 255) / 256 : C::NPX;
+    constexpr int XPS = XH ? 2 : 3, XCH = XH ? 8 : 4;      // log2 pieces per 32-channel row, channels per 16-byte piece
+    constexpr unsigned XE = XH ? 2u : 4u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
     unsigned char* Xs = smw;                         // [432][64 B]   halo voxels x 32 ci
     unsigned char* Ys = smw + WHV * XROW;            // [128][192 B]  tile voxels x 64 co
@@ -100,12 +104,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
     unsigned xpc[NPX], xrel[NPX], xdst[NPX];
 #pragma unroll
     for (int u = 0; u < NPX; ++u) {
-        const int idx = u * 256 + tid, row = idx >> 3, q4 = idx & 7;
-        const bool ok = row < WHV && ci0 + q4 * 4 < g.Cin;
+        const int idx = u * 256 + tid, row = idx >> XPS, q4 = idx & ((1 << XPS) - 1);
+        const bool ok = row < WHV && ci0 + q4 * XCH < g.Cin;
         const int hx = row % WHW, hy = (row / WHW) % WHH, hz = row / (WHW * WHH);
         xpc[u] = ok ? ((unsigned)hz | ((unsigned)hy << 10) | ((unsigned)hx << 20)) : 0x3fffffffu;      // no piece: never in range
-        xrel[u] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin + ci0 + q4 * 4) * 4u;
-        xdst[u] = row < WHV ? (unsigned)(row * XROW + q4 * 8) : 0xffffffffu;
+        xrel[u] = (unsigned)(((hz * g.H + hy) * g.W + hx) * g.Cin + ci0 + q4 * XCH) * XE;
+        xdst[u] = row < WHV ? (unsigned)(row * XROW + q4 * (XH ? 16 : 8)) : 0xffffffffu;
     }
     const unsigned limits = (unsigned)(g.D + PADB - 1) | ((unsigned)(g.H + PADB - 1) << 10) | ((unsigned)(g.W + PADB - 1) << 20);
     unsigned yrel[NPY], ypc[NPY];
@@ -137,7 +141,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 px[NPX], py[NPY];
+    u32x4w px[NPX];                                   // raw pieces: 4 fp32 channels, or (XH) 8 channels of the operand type
+    float4 py[NPY];
     auto load_tile = [&](int mt) {
         int m = mt;
         const int tx = m % g.tilesW; m /= g.tilesW;
@@ -146,14 +151,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
         const int b = m / g.tilesD;
         const int d0 = tz * WTD, h0 = ty * WTH, w0 = tx * WTW;
         const unsigned xorg = (unsigned)(d0 - g.pd + (int)PADB) + ((unsigned)(h0 - g.ph + (int)PADB) << 10) + ((unsigned)(w0 - g.pw + (int)PADB) << 20);
-        const unsigned xbase = (unsigned)((((b * g.D + d0 - g.pd) * g.H + h0 - g.ph) * g.W + w0 - g.pw) * g.Cin) * 4u;
+        const unsigned xbase = (unsigned)((((b * g.D + d0 - g.pd) * g.H + h0 - g.ph) * g.W + w0 - g.pw) * g.Cin) * XE;
 #pragma unroll
         for (int u = 0; u < NPX; ++u) {
             const unsigned c = xpc[u] + xorg;                     // fields < 512: extents <= 255 (plan), PADB, a halo of 2
             const unsigned okm = ((c | GUARD) - LOW) & ((limits | GUARD) - c) & GUARD;
             const unsigned off = (okm == GUARD && xpc[u] != 0x3fffffffu) ? xbase + xrel[u] : WH_OOB;
-            const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
-            px[u] = make_float4(wasf(v.x), wasf(v.y), wasf(v.z), wasf(v.w));
+            px[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
         }
         const unsigned yorg = (unsigned)(d0 + (int)PADB) + ((unsigned)(h0 + (int)PADB) << 10) + ((unsigned)(w0 + (int)PADB) << 20);
         const unsigned ybase = (unsigned)((((b * g.Do + d0) * g.Ho + h0) * g.Wo + w0) * g.Cout) * 4u;
@@ -170,9 +174,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
 #pragma unroll
         for (int u = 0; u < NPX; ++u) {
             if (xdst[u] != 0xffffffffu) {
-                u32x2w w;
-                w.x = wpack2<BF>(px[u].x, px[u].y); w.y = wpack2<BF>(px[u].z, px[u].w);
-                *reinterpret_cast<u32x2w*>(Xs + xdst[u]) = w;
+                if constexpr (XH) {
+                    *reinterpret_cast<u32x4w*>(Xs + xdst[u]) = px[u];
+                } else {
+                    const u32x4w v = px[u];
+                    u32x2w w;
+                    w.x = wpack2<BF>(wasf(v.x), wasf(v.y)); w.y = wpack2<BF>(wasf(v.z), wasf(v.w));
+                    *reinterpret_cast<u32x2w*>(Xs + xdst[u]) = w;
+                }
             }
         }
 #pragma unroll
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
 }  // namespace
 
 bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
-                 int epd, int eph, int epw) {
+                 int epd, int eph, int epw, bool xHalf) {
     static const bool off = [] { const char* e = getenv("DIQT_NO_WGRADH"); return e && e[0] == '1'; }();
     const bool filt = (kd == 3 && kh == 3 && kw == 3) || (kd == 1 && kh == 3 && kw == 3) || (kd == 3 && kh == 1 && kw == 1);
     if (off || !filt || Cin % 32 != 0 || Cout % 4 != 0 || Cin < 32 || Cout < 32) return false;
@@ -275,9 +284,9 @@ bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, in
     if (mt >= (1ll << 30)) return false;
     g.MT = (int)mt;
     g.nCoB = (Cout + 63) / 64; g.nCiB = Cin / 32; g.CoutPad = g.nCoB * 64;
-    const unsigned long long xb = (unsigned long long)B * D * H * W * Cin * 4ull, yb = (unsigned long long)B * g.Do * g.Ho * g.Wo * Cout * 4ull;
-    if (xb >= (1ull << 30) || yb >= (1ull << 30)) return false;
-    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb;
+    const unsigned long long xb = (unsigned long long)B * D * H * W * Cin * (xHalf ? 2ull : 4ull), yb = (unsigned long long)B * g.Do * g.Ho * g.Wo * Cout * 4ull;
+    if (xb >= (1ull << 30) || yb >= (1ull << 30) || (xHalf && Cin % 8 != 0)) return false;
+    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.xHalf = xHalf ? 1 : 0;
     const int blocks = g.nCoB * g.nCiB;
     ksplit = 256 / blocks;
     if (ksplit > g.MT) ksplit = g.MT;
@@ -289,7 +298,8 @@ bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, in
 
 template <class C>
 static int wgradh_launch_t(const float* x, const float* dy, float* slabs, float* bias_part, const WHGeom& g, int ksplit, int bf16, void* stream) {
-    auto kern = bf16 ? conv_wgrad_h_kernel<C, true> : conv_wgrad_h_kernel<C, false>;
+    auto kern = g.xHalf ? (bf16 ? conv_wgrad_h_kernel<C, true, true> : conv_wgrad_h_kernel<C, false, true>)
+                        : (bf16 ? conv_wgrad_h_kernel<C, true> : conv_wgrad_h_kernel<C, false>);
     if (C::LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_bwd_weight_h: hipFuncSetAttribute: %s", hipGetErrorString(e));

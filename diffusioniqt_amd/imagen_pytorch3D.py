@@ -326,6 +326,14 @@ class Block(nn.Module):
                                         pr.padding, residual, want_stats=emit_stats, out_half=out_half)
             if y is not None:
                 return (y, x_in) if tap else y
+        if isinstance(gn, nn.GroupNorm) and not self.boundary and torch.is_grad_enabled():
+            # bf16 training: GroupNorm-apply + conv as one autograd node whose intermediate exists only in bf16 (None: not that mode / shape)
+            pr = self.project
+            if pr.groups == 1 and tuple(pr.stride) == (1, 1, 1):
+                out = ops.gn_conv3d_train_h(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps, pr.weight, pr.bias, pr.padding,
+                                            residual, want_stats=emit_stats, tap=tap)
+                if out is not None:
+                    return out
         if isinstance(gn, nn.GroupNorm):
             x = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps, tap=tap)
             if tap:

@@ -5,6 +5,7 @@ of ``csrc/``.  Activations are fp32 channels-last: ``x[B, D, H, W, C]`` (or ``[r
 There is no CPU fallback: a non-CUDA tensor raises.
 """
 import contextlib
+import os
 
 import torch
 from torch.autograd import Function
@@ -893,6 +894,123 @@ class _GnActFn(Function):
         _lib.call("diqt_gn_act_bwd_ex", x, dy, part, nblk, dtap, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
                   dscale, dshift, ws, n, B, rows, C, groups, act, _stream())
         return dx, dgamma, dbeta, dss, None, None, None, None, None, None, None
+
+
+_NO_TRAIN_FUSE = os.environ.get("DIQT_NO_TRAIN_FUSE") == "1"      # A/B switch: bf16 training Blocks as two autograd nodes
+
+
+class _GnActConvHFn(Function):
+    """Training under ``ImagenTrainer(precision='bf16')`` (trainer.py:293-311): ``conv3d(act(GN(x) * (scale + 1) + shift))`` as ONE autograd
+    node whose intermediate -- the conv's input -- exists only in bf16: the GroupNorm-apply pass writes it in that type (the bits autocast's
+    cast of the fp32 tensor produces), the forward conv reads it through ``conv_f9h_kernel`` (LDS-DMA, 16-bit x) and the weight gradient
+    reads the same tensor (``diqt_conv3d_bwd_weight_h``, bit 1).  Bit-identical to the two-node path (``_GnActFn`` + ``_Conv3dFn``), at
+    half the bytes for the saved activation and the faster forward kernel.  Backward: dX of the conv on the bf16 MFMA kernel (fp32 dY
+    rows), then the GroupNorm backward exactly as ``_GnActFn.backward``."""
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ss, groups, act, eps, pre, weight, bias, pad, residual, stats_out, tap, ss_grad):
+        _chk(x, gamma, beta, weight, bias, residual)
+        if ss is not None:
+            assert ss.is_cuda and ss.dtype == torch.float32 and ss.dim() == 2 and ss.stride(1) == 1, "scale/shift rows must be fp32 HIP tensors"
+        ctx.tap = tap
+        ctx.set_materialize_grads(False)
+        B, C = x.shape[0], x.shape[-1]
+        rows = x.numel() // (B * C)
+        mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        s = _stream()
+        if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
+            _lib.call("diqt_groupnorm_stats_from_partials", pre.partials, mean, rstd, B, pre.nblk, rows, C, groups, float(eps), s)
+        else:
+            ws, n = _reduce_ws(B, C, x.device)
+            _lib.call("diqt_groupnorm_stats", x, mean, rstd, ws, n, B, rows, C, groups, float(eps), s)
+        scale = shift = None
+        cs = 0
+        if ss is not None:
+            assert ss.shape == (B, 2 * C), f"scale/shift embedding must be [B, 2C] rows, got {tuple(ss.shape)}"
+            scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, ss.stride(0)
+        y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        _lib.call("diqt_gn_act_fwd_h", x, mean, rstd, gamma, beta, scale, shift, cs, y16, B, rows, C, groups, act, 1, 0, s)
+        y = _conv_fwd_half(y16, weight, bias, residual, pad, (0, 0, 0), 1, x_half=True, y_half=False, stats_out=stats_out)
+        ctx.ss_grad = ss_grad
+        ctx.save_for_backward(x, gamma, beta, ss, mean, rstd, y16, weight)
+        ctx.cfg = (B, rows, C, groups, act, pad, bias is not None, residual is not None)
+        return (y, x) if tap else y
+
+    @staticmethod
+    def backward(ctx, dy, dtap=None):
+        x, gamma, beta, ss, mean, rstd, y16, weight = ctx.saved_tensors
+        B, rows, C, groups, act, pad, has_bias, has_res = ctx.cfg
+        none = (None,) * 15
+        if dy is None:                      # only the alias was used downstream
+            return (dtap,) + none[1:]
+        dy = dy.contiguous()
+        Cout, Cin, kd, kh, kw = weight.shape
+        D, H, W = x.shape[1:4]
+        pd, ph, pw = pad
+        bpad = (kd - 1 - pd, kh - 1 - ph, kw - 1 - pw)
+        # ---- conv: dX on the bf16 MFMA kernel (flipped weights), dW / db with the bf16 activation as it was saved ----
+        dact = _conv_fwd_half(dy, weight, None, None, bpad, (0, 0, 0), 1, mode=1)
+        if dact is None:
+            dact = _conv_fwd_raw(dy, _packed(weight, 1), None, None, Cin, (kd, kh, kw), bpad, (0, 0, 0))
+        dw = torch.empty_like(weight)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
+        geo = (B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, 0, 0, 0)
+        nh = _lib.query("diqt_conv3d_bwd_weight_h_workspace_bytes", *geo)
+        assert nh > 0
+        if TIMER.enabled:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+        _lib.call("diqt_conv3d_bwd_weight_h", y16, dy, dw, db, _workspace(nh, x.device), nh, *geo, 3, _stream())      # 3 = bf16 | x is 16-bit
+        if TIMER.enabled:
+            t1.record()
+            Do, Ho, Wo = dy.shape[1:4]
+            TIMER.records.append((t0, t1, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_wgrad_h_kernel", geo[:9]))
+        # ---- GroupNorm + activation backward (as _GnActFn.backward) ----
+        if dtap is not None:
+            dtap = dtap.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma) if gamma is not None else None
+        dbeta = torch.empty_like(beta) if beta is not None else None
+        scale = shift = dscale = dshift = None
+        dss = None
+        cs = 0
+        if ss is not None:
+            cs = ss.stride(0)
+            dss = ctx.ss_grad if ctx.ss_grad is not None else torch.empty_strided(ss.shape, ss.stride(), dtype=ss.dtype, device=ss.device)
+            assert dss.stride() == ss.stride()
+            scale, shift = ss.data_ptr(), ss.data_ptr() + 4 * C
+            dscale, dshift = dss.data_ptr(), dss.data_ptr() + 4 * C
+        ws, n = _reduce_ws(B, C, x.device)
+        _lib.call("diqt_gn_act_bwd_ex", x, dact, None, 0, dtap, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
+                  dscale, dshift, ws, n, B, rows, C, groups, act, _stream())
+        return dx, dgamma, dbeta, dss, None, None, None, None, dw, db, None, (dy if has_res else None), None, None, None
+
+
+def gn_conv3d_train_h(x, gamma, beta, scale_shift, groups, act, eps, weight, bias, padding, residual=None, want_stats=False, tap=False):
+    """``Block.forward`` of a bf16 training step as one autograd node (``_GnActConvHFn``); ``tap`` as in ``groupnorm_act``.  None when not in a
+    bf16 training step or the shape is not taken by the 16-bit-input kernels (the caller then runs ``groupnorm_act`` + ``conv3d``)."""
+    if lp_mode() != 1 or not torch.is_grad_enabled() or x.dim() != 5 or x.dtype != torch.float32 or isinstance(scale_shift, SSView) or _NO_TRAIN_FUSE:
+        return None
+    B, D, H, W, C = x.shape
+    Cout, Cin, kd, kh, kw = weight.shape
+    padding = tuple(int(p) for p in ((padding,) * 3 if isinstance(padding, int) else padding))
+    geo = (B, D, H, W, C, Cout, kd, kh, kw, *padding, 0, 0, 0)
+    if (Cin != C or C % groups != 0 or C % 8 != 0 or not _lib.query("diqt_conv3d_fwd_h_io16_supported", *geo, 1, 0)
+            or _lib.query("diqt_conv3d_bwd_weight_h_workspace_bytes", *geo) == 0):
+        return None
+    if D + 2 * padding[0] - kd + 1 != D or H + 2 * padding[1] - kh + 1 != H or W + 2 * padding[2] - kw + 1 != W:
+        return None                                   # ('same' convs: the backward-data pads are the forward's)
+    use_tap = tap and x.requires_grad
+    ss_grad = getattr(scale_shift, "_diqt_gradview", None)
+    if scale_shift is not None and ss_grad is None and not scale_shift.is_contiguous():
+        scale_shift = scale_shift.contiguous()
+    holder = [] if want_stats else None
+    out = _GnActConvHFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None), weight, bias, padding, residual,
+                              holder, use_tap, ss_grad)
+    y, alias = out if use_tap else (out, x)
+    if holder:
+        y._diqt_stats = holder[0]
+    return (y, alias) if tap else y
 
 
 def groupnorm_act(x, gamma, beta, scale_shift=None, groups=8, act=ACT_MISH, eps=1e-5, tap=False):

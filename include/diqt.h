@@ -185,7 +185,9 @@ int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw_oidhw, flo
 
 /* The weight gradient with 16-bit MFMA operands (bf16 when `bf16`, else fp16; fp32 accumulate): x and dY are rounded to that type while
  * staged, as the reference's autocast backward does under `ImagenTrainer(precision='bf16')` (trainer.py:293-311).  dbias is summed from the
- * fp32 dY.  3x3x3, (1,3,3), (3,1,1) filters, Cin % 32 == 0; ..._workspace_bytes == 0: shape not taken -- use diqt_conv3d_bwd_weight.  Deterministic.   */
+ * fp32 dY.  3x3x3, (1,3,3), (3,1,1) filters, Cin % 32 == 0; ..._workspace_bytes == 0: shape not taken -- use diqt_conv3d_bwd_weight.  Deterministic.
+ * Bit 1 of `bf16` (value 2): x already HOLDS 16-bit values of the operand type (the GroupNorm-apply output a bf16 training step kept in
+ * that type for the conv's forward and for this pass: half the bytes, the same bits the fp32 values round to).                          */
 size_t diqt_conv3d_bwd_weight_h_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
                                                 int pw, int epd, int eph, int epw);
 int diqt_conv3d_bwd_weight_h(const float* x, const float* dy, float* dw_oidhw, float* dbias, void* workspace, size_t workspace_bytes,

@@ -559,3 +559,53 @@ def test_temporal_conv_as_a_gemm_over_shifted_rows(B, D, H, W, Cin, Cout, pd, ep
     if res:
         want = want + r
     assert torch.equal(y.cpu(), want), (y.cpu() - want).abs().max()
+
+
+@pytest.mark.parametrize("with_ss,res,tap", [(True, False, True), (False, True, False)])
+def test_bf16_training_block_as_one_node_with_a_bf16_activation_is_bit_identical(with_ss, res, tap):
+    """ImagenTrainer(precision='bf16'): GroupNorm-apply + conv as ONE autograd node (ops._GnActConvHFn) whose intermediate exists only in
+    bf16 -- written so by the GroupNorm-apply pass, read by conv_f9h_kernel in the forward and by the bf16 weight-gradient kernel in the
+    backward -- against the two-node path (fp32 activation, rounded to bf16 while each conv kernel stages it): the same bits everywhere
+    (output, dx, dW, db, GroupNorm parameter gradients, scale/shift gradient, the residual's gradient)."""
+    from diffusioniqt_amd import ops, _lib
+    B, S, C, Co, G = 2, 16, 64, 64, 8
+    g = torch.Generator().manual_seed(17)
+    x0 = torch.randn(B, S, S, S, C, generator=g)
+    gamma0, beta0 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    w0 = torch.randn(Co, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5
+    b0 = torch.randn(Co, generator=g)
+    ss0 = torch.randn(B, 2 * C, generator=g) * 0.3 if with_ss else None
+    r0 = torch.randn(B, S, S, S, Co, generator=g) if res else None
+    dy = torch.randn(B, S, S, S, Co, generator=g).to(DEV)
+
+    def run(fused):
+        leaves = [t.clone().to(DEV).requires_grad_(True) if t is not None else None for t in (x0, gamma0, beta0, w0, b0, ss0, r0)]
+        x, gamma, beta, w, b, ss, r = leaves
+        xin = x * 1.0                                        # a non-leaf input, as inside the U-Net (the tap routes its second consumer)
+        with ops.low_precision('bf16'), _lib.census() as c:
+            if fused:
+                out = ops.gn_conv3d_train_h(xin, gamma, beta, ss, G, ops.ACT_MISH, 1e-5, w, b, (1, 1, 1), r, want_stats=True, tap=tap)
+                assert out is not None
+            else:
+                h = ops.groupnorm_act(xin, gamma, beta, ss, G, ops.ACT_MISH, 1e-5, tap=tap)
+                h, alias = h if tap else (h, None)
+                y = ops.conv3d(h, w, b, (1, 1, 1), r, want_stats=True)
+                out = (y, alias) if tap else y
+            y, alias = out if tap else (out, None)
+            loss = (y * dy).sum() + ((alias * 0.5).sum() if tap else 0.0)
+            loss.backward()
+            torch.cuda.synchronize()
+            nf9 = c.count("conv3d_fwd_h(v9h)")
+        return y.detach(), [t.grad for t in leaves if t is not None], nf9, getattr(y, "_diqt_stats", None)
+
+    ya, ga, na, sa = run(True)
+    yb, gb, nb, sb = run(False)
+    assert na == 1 and nb == 0                               # the fused node's forward ran on the LDS-DMA kernel
+    assert torch.equal(ya, yb)
+    for a, b_ in zip(ga, gb):
+        assert a is not None and b_ is not None and torch.equal(a, b_), (a - b_).abs().max()
+    # the fused node's conv also hands the next GroupNorm its column sums (the two-node path has none under autocast): against y itself
+    assert sa is not None
+    flat = ya.double().reshape(B, -1, Co)
+    got = sa.partials.double().sum(1)
+    assert torch.allclose(got[:, 0], flat.sum(1), rtol=1e-6, atol=1e-2) and torch.allclose(got[:, 1], (flat * flat).sum(1), rtol=1e-6, atol=1e-2)

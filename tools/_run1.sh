@@ -1,8 +1,6 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_lowprec.py -x -q -k "bf16_training_block" > gpurun_out/t26_tests.log 2>&1; echo "rc=$?" >> gpurun_out/t26_tests.log
-tail -3 gpurun_out/t26_tests.log
-for i in 1 2; do
-DIQT_NO_TRAIN_FUSE=1 timeout -k 10 300 python tools/train_bf16_only.py 24 2>&1 | grep micro-step | sed 's/^/two nodes: /'
-timeout -k 10 300 python tools/train_bf16_only.py 24 2>&1 | grep micro-step | sed 's/^/one node:  /'
-done
+timeout -k 10 600 python bench.py > gpurun_out/r04_bench_C2.json 2> gpurun_out/r04_bench_C2.err; tail -c 300 gpurun_out/r04_bench_C2.json; echo
+timeout -k 10 600 python bench.py --config C4 > gpurun_out/r04_bench_C4.json 2> gpurun_out/r04_bench_C4.err; tail -c 200 gpurun_out/r04_bench_C4.json; echo
+timeout -k 10 900 python bench.py --config C5 > gpurun_out/r04_bench_C5.json 2> gpurun_out/r04_bench_C5.err; tail -c 200 gpurun_out/r04_bench_C5.json; echo
+timeout -k 10 900 python tools/volume_bench.py > gpurun_out/r04_volume.log 2>&1; grep -v "Warn\|amdgpu\|base dim" gpurun_out/r04_volume.log | tail -4

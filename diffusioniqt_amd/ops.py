@@ -517,7 +517,8 @@ class _Conv3dFn(Function):
             bpad, bepad = (kd - 1 - pd, kh - 1 - ph, kw - 1 - pw), (-epd, -eph, -epw)
             # bf16 training: backward-data on the bf16 MFMA kernel too (the reference's autocast backward runs in the forward's
             # type).  fp16 gradients would need the GradScaler the reference pairs with fp16; they stay on the fp32 kernel.
-            dx = _conv_fwd_half(dy, weight, None, None, bpad, bepad, 1, mode=1) if ctx.lp == 1 else None
+            lpb = _lp_backward(ctx.lp)
+            dx = _conv_fwd_half(dy, weight, None, None, bpad, bepad, lpb, mode=1) if lpb is not None else None
             gn = ctx.gnctx
             if dx is None and gn is not None:
                 dx = _conv_bwd_data_gn(dy, _packed(weight, 1), Cin, (kd, kh, kw), bpad, bepad, gn)
@@ -526,8 +527,9 @@ class _Conv3dFn(Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            lpb = _lp_backward(ctx.lp)
             nh = _lib.query("diqt_conv3d_bwd_weight_h_workspace_bytes", B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw) \
-                if ctx.lp == 1 else 0
+                if lpb is not None else 0
             if nh:
                 # bf16 training: the weight gradient on the bf16 MFMA too (x and dY rounded to bf16 while staged, fp32 accumulation; the
                 # reference's autocast backward runs in the forward's type); other shapes stay on the fp32 kernel
@@ -535,7 +537,7 @@ class _Conv3dFn(Function):
                 if TIMER.enabled:
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
-                _lib.call("diqt_conv3d_bwd_weight_h", x, dy, dw, db, ws, nh, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, 1,
+                _lib.call("diqt_conv3d_bwd_weight_h", x, dy, dw, db, ws, nh, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, lpb,
                           _stream())
                 if TIMER.enabled:
                     e.record()
@@ -896,11 +898,22 @@ class _GnActFn(Function):
         return dx, dgamma, dbeta, dss, None, None, None, None, None, None, None
 
 
+# fp16 training with a loss scaler (ImagenTrainer(fp16=True): the reference pairs fp16 autocast with torch's GradScaler, trainer.py:293-311,
+# 364): the trainer sets this while its scaler is active, and the backward kernels of fp16-forward convs then run on the fp16 MFMA too
+# (dY carries the loss scale, which is what keeps fp16 gradients out of the denormals).  Without a scaler fp16 backward stays in fp32.
+FP16_BACKWARD = False
+
+
+def _lp_backward(lp):
+    """The 16-bit type of a conv's backward kernels: bf16 always follows the forward; fp16 only under a loss scaler; else None (fp32)."""
+    return lp if lp == 1 or (lp == 0 and FP16_BACKWARD) else None
+
+
 _NO_TRAIN_FUSE = os.environ.get("DIQT_NO_TRAIN_FUSE") == "1"      # A/B switch: bf16 training Blocks as two autograd nodes
 
 
 class _GnActConvHFn(Function):
-    """Training under ``ImagenTrainer(precision='bf16')`` (trainer.py:293-311): ``conv3d(act(GN(x) * (scale + 1) + shift))`` as ONE autograd
+    """Training under ``ImagenTrainer(precision='bf16')`` -- or ``fp16=True`` with its loss scaler -- (trainer.py:293-311): ``conv3d(act(GN(x) * (scale + 1) + shift))`` as ONE autograd
     node whose intermediate -- the conv's input -- exists only in bf16: the GroupNorm-apply pass writes it in that type (the bits autocast's
     cast of the fp32 tensor produces), the forward conv reads it through ``conv_f9h_kernel`` (LDS-DMA, 16-bit x) and the weight gradient
     reads the same tensor (``diqt_conv3d_bwd_weight_h``, bit 1).  Bit-identical to the two-node path (``_GnActFn`` + ``_Conv3dFn``), at
@@ -928,9 +941,11 @@ class _GnActConvHFn(Function):
         if ss is not None:
             assert ss.shape == (B, 2 * C), f"scale/shift embedding must be [B, 2C] rows, got {tuple(ss.shape)}"
             scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, ss.stride(0)
-        y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-        _lib.call("diqt_gn_act_fwd_h", x, mean, rstd, gamma, beta, scale, shift, cs, y16, B, rows, C, groups, act, 1, 0, s)
-        y = _conv_fwd_half(y16, weight, bias, residual, pad, (0, 0, 0), 1, x_half=True, y_half=False, stats_out=stats_out)
+        lp = lp_mode()                                       # 1: bf16, 0: fp16 (under a loss scaler)
+        y16 = torch.empty(x.shape, dtype=torch.bfloat16 if lp == 1 else torch.float16, device=x.device)
+        _lib.call("diqt_gn_act_fwd_h", x, mean, rstd, gamma, beta, scale, shift, cs, y16, B, rows, C, groups, act, lp, 0, s)
+        y = _conv_fwd_half(y16, weight, bias, residual, pad, (0, 0, 0), lp, x_half=True, y_half=False, stats_out=stats_out)
+        ctx.lp = lp
         ctx.ss_grad = ss_grad
         ctx.save_for_backward(x, gamma, beta, ss, mean, rstd, y16, weight)
         ctx.cfg = (B, rows, C, groups, act, pad, bias is not None, residual is not None)
@@ -949,7 +964,7 @@ class _GnActConvHFn(Function):
         pd, ph, pw = pad
         bpad = (kd - 1 - pd, kh - 1 - ph, kw - 1 - pw)
         # ---- conv: dX on the bf16 MFMA kernel (flipped weights), dW / db with the bf16 activation as it was saved ----
-        dact = _conv_fwd_half(dy, weight, None, None, bpad, (0, 0, 0), 1, mode=1)
+        dact = _conv_fwd_half(dy, weight, None, None, bpad, (0, 0, 0), ctx.lp, mode=1)
         if dact is None:
             dact = _conv_fwd_raw(dy, _packed(weight, 1), None, None, Cin, (kd, kh, kw), bpad, (0, 0, 0))
         dw = torch.empty_like(weight)
@@ -960,7 +975,7 @@ class _GnActConvHFn(Function):
         if TIMER.enabled:
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record()
-        _lib.call("diqt_conv3d_bwd_weight_h", y16, dy, dw, db, _workspace(nh, x.device), nh, *geo, 3, _stream())      # 3 = bf16 | x is 16-bit
+        _lib.call("diqt_conv3d_bwd_weight_h", y16, dy, dw, db, _workspace(nh, x.device), nh, *geo, ctx.lp | 2, _stream())      # bit 1: x is 16-bit
         if TIMER.enabled:
             t1.record()
             Do, Ho, Wo = dy.shape[1:4]
@@ -989,7 +1004,7 @@ class _GnActConvHFn(Function):
 def gn_conv3d_train_h(x, gamma, beta, scale_shift, groups, act, eps, weight, bias, padding, residual=None, want_stats=False, tap=False):
     """``Block.forward`` of a bf16 training step as one autograd node (``_GnActConvHFn``); ``tap`` as in ``groupnorm_act``.  None when not in a
     bf16 training step or the shape is not taken by the 16-bit-input kernels (the caller then runs ``groupnorm_act`` + ``conv3d``)."""
-    if lp_mode() != 1 or not torch.is_grad_enabled() or x.dim() != 5 or x.dtype != torch.float32 or isinstance(scale_shift, SSView) or _NO_TRAIN_FUSE:
+    if _lp_backward(lp_mode()) is None or not torch.is_grad_enabled() or x.dim() != 5 or x.dtype != torch.float32 or isinstance(scale_shift, SSView) or _NO_TRAIN_FUSE:
         return None
     B, D, H, W, C = x.shape
     Cout, Cin, kd, kh, kw = weight.shape

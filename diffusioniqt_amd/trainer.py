@@ -182,12 +182,36 @@ class FusedAdam:
             self._load_into_arena(self._pending_state)
             self._pending_state = None
 
-    def step(self, max_grad_norm=None):
+    step_was_skipped = False
+
+    def step(self, max_grad_norm=None, scaler=None):
         """One Adam step over the arena, fused with zero_grad.  ``max_grad_norm``: the reference's clip in front of the step
         (trainer.py:1054, torch's clip_grad_norm_): one norm reduction over the flat gradients, the coefficient is applied inside the
         Adam pass (the gradients are consumed and zeroed there, so scaling them in place would be a wasted pass)."""
         assert self.arena is not None, 'optimizer used before the trainer prepared the unet'
         g = self.param_groups[0]
+        self.step_was_skipped = False
+        if scaler is not None and scaler.enabled:
+            # GradScaler.step: the gradients carry the loss scale.  One norm reduction over the arena serves the finite check (read back:
+            # the one host sync of an fp16 optimiser step), the un-scaling and the clip -- all applied as ONE coefficient inside the Adam pass
+            import math
+            out = ops.grad_norm_clip(self.arena.grad, 1e30)
+            norm = float(out[0].item())
+            if not math.isfinite(norm):
+                self.arena.grad.zero_()                    # optimizer.zero_grad() still runs (trainer.py:1057)
+                scaler.update(True)
+                self.step_was_skipped = True
+                return
+            inv = 1.0 / scaler.get_scale()
+            c = inv if max_grad_norm is None else inv * min(1.0, max_grad_norm / (norm * inv + 1e-6))
+            self.last_grad_norm = out
+            self.step_count += 1
+            self.stateful |= self.arena.touched
+            ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                          g['weight_decay'], self.step_count, zero_grad=True,
+                          grad_scale=torch.tensor([c], dtype=torch.float32, device=self.arena.grad.device))
+            scaler.update(False)
+            return
         self.step_count += 1
         self.stateful |= self.arena.touched
         coef = None
@@ -290,8 +314,51 @@ class _LinearWarmup:
         self.__dict__.update(sd)
 
 
+class _GradScaler:
+    """``torch.cuda.amp.GradScaler`` for the flat-arena optimiser -- what the reference pairs with ``fp16=True`` (trainer.py:309-311, 364:
+    ``GradScaler(enabled=fp16)``, set on the accelerator per U-Net): the loss is multiplied by ``scale`` before ``backward``, the optimiser
+    step un-scales inside the fused Adam pass (one coefficient, together with the clip), a non-finite gradient norm skips the step and
+    halves the scale, ``growth_interval`` good steps in a row double it.  Same state keys and update rule as torch's (pinned against
+    ``torch.amp.GradScaler`` on the host, tests/test_host_trainer.py); the finite check is the arena's norm reduction, read back once per
+    optimiser step."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self._scale, self.growth_factor, self.backoff_factor, self.growth_interval = float(init_scale), growth_factor, backoff_factor, growth_interval
+        self._growth_tracker = 0
+
+    enabled = True
+
+    def get_scale(self):
+        return self._scale
+
+    def update(self, found_inf):
+        if found_inf:
+            self._scale *= self.backoff_factor
+            self._growth_tracker = 0
+        else:
+            self._growth_tracker += 1
+            if self._growth_tracker == self.growth_interval:
+                self._scale *= self.growth_factor
+                self._growth_tracker = 0
+
+    def state_dict(self):
+        return {"scale": self._scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self._growth_tracker}
+
+    def load_state_dict(self, sd):
+        if not sd:
+            return
+        self._scale, self.growth_factor, self.backoff_factor = float(sd["scale"]), sd["growth_factor"], sd["backoff_factor"]
+        self.growth_interval, self._growth_tracker = sd["growth_interval"], int(sd["_growth_tracker"])
+
+
 class _NullScaler:
     """fp32 path: the reference's GradScaler(enabled=False) (trainer.py:364) — empty state."""
+
+    enabled = False
+
+    def get_scale(self):
+        return 1.0
 
     def state_dict(self):
         return {}
@@ -387,9 +454,10 @@ class ImagenTrainer(nn.Module):
         assert exists(imagen) ^ exists(imagen_checkpoint_path), 'either imagen instance is passed into the trainer, or a checkpoint path that contains the imagen config'
         assert exists(imagen), 'imagen_checkpoint_path (CLI configs) is dead code in the reference and not built'
         # mixed precision (trainer.py:293-311: Accelerator(mixed_precision=...)): the model forward runs under torch.autocast, where
-        # conv3d / linear forwards take the fp16 / bf16 MFMA kernel (ops.lp_mode); master weights, gradients, loss and the
-        # optimiser stay fp32 and every backward kernel is fp32, so no loss scaling is needed (the scaler slot keeps its
-        # checkpoint key with an empty state)
+        # conv3d / linear forwards take the fp16 / bf16 MFMA kernel (ops.lp_mode); master weights, accumulated gradients, loss and the
+        # optimiser stay fp32.  bf16: the conv backward kernels run in bf16 too.  `fp16=True`: the reference's GradScaler(enabled=fp16)
+        # (trainer.py:311, 364) is real here as well (_GradScaler: scaled loss, fp16 backward kernels, un-scale + finite check + skip inside
+        # the optimiser step); precision='fp16' WITHOUT the fp16 switch has no scaler in the reference either: its backward stays fp32 here
         assert not (fp16 and exists(precision)), 'either set fp16 = True or forward the precision ("fp16", "bf16") to Accelerator'
         self.mixed_precision = default(precision, 'fp16' if fp16 else 'no')
         assert self.mixed_precision in ('no', 'fp16', 'bf16'), self.mixed_precision
@@ -437,7 +505,8 @@ class ImagenTrainer(nn.Module):
                 if not exists(scheduler):
                     scheduler = LambdaLR(optimizer.lr_carrier, lr_lambda=lambda step: 1.0)
                 optimizer.param_groups[0]['lr'] = optimizer.lr_carrier.param_groups[0]['lr']     # damped from the first step on
-            setattr(self, f'scaler{ind}', _NullScaler())
+            # trainer.py:311, 364: GradScaler(enabled = fp16) -- only the `fp16=True` switch turns it on (precision='fp16' alone does not)
+            setattr(self, f'scaler{ind}', _GradScaler() if fp16 else _NullScaler())
             setattr(self, f'scheduler{ind}', scheduler)
             setattr(self, f'warmup{ind}', warmup_scheduler)
         self.max_grad_norm = max_grad_norm
@@ -819,10 +888,13 @@ class ImagenTrainer(nn.Module):
         optimizer = getattr(self, f'optim{index}')
         scheduler, warmup_scheduler = getattr(self, f'scheduler{index}'), getattr(self, f'warmup{index}')
         stepped = getattr(self, '_sync_now', False)
+        scaler = getattr(self, f'scaler{index}')
         if stepped:
-            optimizer.step(max_grad_norm=self.max_grad_norm)      # (clip ->) fused Adam + zero_grad (trainer.py:1054-1057)
+            optimizer.step(max_grad_norm=self.max_grad_norm, scaler=scaler)      # (unscale, clip ->) fused Adam + zero_grad (trainer.py:1054-1057)
             self._sync_now = False
-        elif exists(self.max_grad_norm) and self.training:
+            stepped = not optimizer.step_was_skipped        # a skipped step (non-finite fp16 gradients) does not move the LR schedule either
+        elif exists(self.max_grad_norm) and self.training and not scaler.enabled:
+            # (with a loss scaler the reference's clip on accumulation micro-steps would un-scale twice -- torch raises; clipped at the step only)
             optimizer.clip_accumulated(self.max_grad_norm)
         if self.use_ema:
             self.ema_unets[index].update()
@@ -881,7 +953,15 @@ class ImagenTrainer(nn.Module):
                 arena = getattr(self, '_arena', None)
                 if arena is not None:
                     arena.begin_backward()
-                (loss / self.gradient_accumulation_steps).backward()
+                scaler = getattr(self, f'scaler{unet_number - 1}')
+                if scaler.enabled:                      # accelerator.backward: scaler.scale(loss).backward(), fp16 kernels in the backward too
+                    ops.FP16_BACKWARD = True
+                    try:
+                        (loss / self.gradient_accumulation_steps * scaler.get_scale()).backward()
+                    finally:
+                        ops.FP16_BACKWARD = False
+                else:
+                    (loss / self.gradient_accumulation_steps).backward()
                 if exists(reducer):
                     reducer.finalize_backward()
                 if arena is not None:

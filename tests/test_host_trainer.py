@@ -284,3 +284,29 @@ def test_linear_warmup_restatement_and_checkpoint_keys(tmp_path):
         trainer.warmup1.last_step, trainer.optim1.param_groups[0]['lr'] = 0, 1.0
         trainer.load(path)
         assert trainer.warmup1.last_step == 6 and trainer.scheduler1.last_epoch == 3 and trainer.get_lr(2) == lr_now
+
+
+def test_grad_scaler_follows_torch_gradscaler_update_rule_and_state_keys():
+    """ImagenTrainer(fp16=True) pairs autocast with a loss scaler (reference trainer.py:311, 364: torch's GradScaler).  The product's scaler
+    for the flat-arena optimiser restates its update rule: same scale / growth tracker after the same sequence of finite / non-finite steps,
+    same ``state_dict`` keys (checkpoint interop: the reference saves ``scaler{i}.state_dict()``, trainer.py:857)."""
+    import torch
+    from diffusioniqt_amd.trainer import _GradScaler, _NullScaler
+    ref = torch.amp.GradScaler('cpu', init_scale=2.0 ** 16, growth_interval=3)
+    mine = _GradScaler(init_scale=2.0 ** 16, growth_interval=3)
+    p = torch.nn.Parameter(torch.ones(2))
+    opt = torch.optim.SGD([p], lr=0.0)
+    for found_inf in (False, False, True, False, False, False, False, True, True, False, False, False):
+        p.grad = torch.full((2,), float('inf') if found_inf else 1.0)
+        ref.scale(torch.zeros(()))                         # (lazy init of the reference's scale tensor)
+        ref.step(opt)
+        ref.update()
+        mine.update(found_inf)
+        want = ref.state_dict()
+        got = mine.state_dict()
+        assert list(got) == list(want)
+        assert got["scale"] == want["scale"] and got["_growth_tracker"] == want["_growth_tracker"], (got, want)
+    other = _GradScaler()
+    other.load_state_dict(mine.state_dict())
+    assert other.state_dict() == mine.state_dict()
+    assert _NullScaler().state_dict() == {} and _NullScaler().get_scale() == 1.0

@@ -81,6 +81,8 @@ PROTOTYPES = {
     "diqt_concat_channels": (I, [P, I, P, I, P, Z, P]),
     "diqt_split_channels": (I, [P, P, I, P, I, Z, P]),
     "diqt_concat_channels_scaled": (I, [P, I, P, I, F, F, P, Z, P]),
+    "diqt_concat_channels_stats_blocks": (I, [I, I, I]),
+    "diqt_concat_channels_stats": (I, [P, I, P, I, F, F, P, I, I, P, P]),
     "diqt_split_channels_scaled": (I, [P, P, I, P, I, F, F, Z, P]),
     "diqt_subvolume_gather": (I, [P, P, I, I, I, I, P]),
     "diqt_subvolume_scatter": (I, [P, P, I, I, I, I, I, P]),

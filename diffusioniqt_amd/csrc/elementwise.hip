@@ -933,6 +933,41 @@ __global__ __launch_bounds__(256) void concat4_kernel(const float4* __restrict__
         y[i] = v;
     }
 }
+// The same pass with the column sums (sum, sum of squares) of the rows it writes, per workgroup: [B][nblk][2][C] -- the concatenated
+// tensor's consumer is a GroupNorm (the ResnetBlocks of the up path), whose statistics pass over the tensor disappears (15 launches of
+// colreduce_kernel<MomentsF> per C5 stage-2 eval: 1.15 ms).  Workgroup (blockIdx.x, b) owns rows [blk * rpb, (blk + 1) * rpb) of batch
+// entry b; thread t < RL * C4: channel quad t % C4, row lane t / C4; fixed-order combine of the row lanes through LDS: deterministic.
+__global__ __launch_bounds__(256) void concat4_stats_kernel(const float4* __restrict__ a, int Ca4, const float4* __restrict__ b, int Cb4,
+                                                            float sa, float sb, float4* __restrict__ y, int rowsPerBatch, int rpb,
+                                                            float* __restrict__ stats, int nblk) {
+    extern __shared__ float4 cs_sm[];          // [RL][C4] sums | [RL][C4] sums of squares
+    const int C4 = Ca4 + Cb4, RL = 256 / C4;
+    const int t = threadIdx.x, c = t % C4, rl = t / C4;
+    const int bb = blockIdx.y, blk = blockIdx.x;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < RL) {
+        const bool first = c < Ca4;
+        const float f = first ? sa : sb;
+        const int r1 = min(rowsPerBatch, (blk + 1) * rpb);
+        for (int r = blk * rpb + rl; r < r1; r += RL) {
+            const size_t row = (size_t)bb * rowsPerBatch + r;
+            float4 v = first ? a[row * Ca4 + c] : b[row * Cb4 + (c - Ca4)];
+            v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+            y[row * C4 + c] = v;
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+        }
+        cs_sm[rl * C4 + c] = s;
+        cs_sm[(RL + rl) * C4 + c] = q;
+    }
+    __syncthreads();
+    if (t < 2 * C4) {
+        const int which = t / C4, cc = t % C4;
+        float4 acc = cs_sm[(which * RL) * C4 + cc];
+        for (int k = 1; k < RL; ++k) { const float4 v = cs_sm[(which * RL + k) * C4 + cc]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        reinterpret_cast<float4*>(stats + (((size_t)bb * nblk + blk) * 2 + which) * (size_t)(4 * C4))[cc] = acc;
+    }
+}
 __global__ __launch_bounds__(256) void split4_kernel(const float4* __restrict__ y, float4* __restrict__ a, int Ca4, float4* __restrict__ b,
                                                      int Cb4, float sa, float sb, size_t rows) {
     const int C4 = Ca4 + Cb4;
@@ -2425,6 +2460,24 @@ extern "C" int diqt_concat_channels_scaled(const float* a, int Ca, const float* 
         hipLaunchKernelGGL(concat_scaled_kernel, dim3(grid_for(rows * (Ca + Cb), 256)), dim3(256), 0, STREAM, a, Ca, b, Cb, sa, sb, y, rows);
     }
     return check_launch("concat_channels_scaled");
+}
+// rows of column sums per batch entry diqt_concat_channels_stats writes (0: shape not taken -- channel counts that are not multiples of 4
+// or more than 1024 channels)
+extern "C" int diqt_concat_channels_stats_blocks(int Ca, int Cb, int rows_per_batch) {
+    if (Ca <= 0 || Cb <= 0 || rows_per_batch <= 0 || Ca % 4 || Cb % 4 || (Ca + Cb) / 4 > 256) return 0;
+    return (rows_per_batch + 255) / 256;
+}
+extern "C" int diqt_concat_channels_stats(const float* a, int Ca, const float* b, int Cb, float sa, float sb, float* y, int B,
+                                          int rows_per_batch, float* stats, void* stream) {
+    DIQT_REQUIRE(a && b && y && stats, DIQT_E_ALIGN, "concat_channels_stats: null pointer");
+    const int nblk = diqt_concat_channels_stats_blocks(Ca, Cb, rows_per_batch);
+    DIQT_REQUIRE(nblk > 0 && B > 0, DIQT_E_UNSUPPORTED, "concat_channels_stats: shape not taken (diqt_concat_channels_stats_blocks == 0)");
+    DIQT_REQUIRE(aligned16(a) && aligned16(b) && aligned16(y) && aligned16(stats), DIQT_E_ALIGN, "concat_channels_stats: pointers must be 16-byte aligned");
+    const int C4 = (Ca + Cb) / 4, RL = 256 / C4;
+    hipLaunchKernelGGL(concat4_stats_kernel, dim3(nblk, B), dim3(256), (size_t)2 * RL * C4 * sizeof(float4), STREAM,
+                       reinterpret_cast<const float4*>(a), Ca / 4, reinterpret_cast<const float4*>(b), Cb / 4, sa, sb,
+                       reinterpret_cast<float4*>(y), rows_per_batch, 256, stats, nblk);
+    return check_launch("concat_channels_stats");
 }
 extern "C" int diqt_split_channels_scaled(const float* y, float* a, int Ca, float* b, int Cb, float sa, float sb, size_t rows,
                                           void* stream) {

@@ -886,7 +886,7 @@ class Unet3D(nn.Module):
         x = self.mid_block2(x, t, c, ignore_time=ignore_time)
 
         def add_skip_connection(x):
-            return ops.concat_channels(x, hiddens.pop(), 1.0, self.skip_connect_scale)           # cat(x, skip * scale) in one pass
+            return ops.concat_channels(x, hiddens.pop(), 1.0, self.skip_connect_scale, want_stats=True)   # cat(x, skip * scale) in one pass (+ the next GroupNorm's column sums)
 
         up_hiddens = []
         for init_block, resnet_blocks, attn_block, temporal_peg, temporal_attn, temporal_upsample, upsample in self.ups:

@@ -1378,8 +1378,21 @@ class _ConcatFn(Function):
         return da, db, None, None
 
 
-def concat_channels(a, b, scale_a=1.0, scale_b=1.0):
-    """cat(scale_a * a, scale_b * b) over the last axis in one pass (the scaled skip connections)."""
+def concat_channels(a, b, scale_a=1.0, scale_b=1.0, want_stats=False):
+    """cat(scale_a * a, scale_b * b) over the last axis in one pass (the scaled skip connections).  ``want_stats`` (sampling path): the
+    pass also writes the column sums of its output for the GroupNorm that consumes it (``_diqt_stats``), when the shape is taken."""
+    if want_stats and not torch.is_grad_enabled() and a.dim() >= 3 and a.dtype == torch.float32 and b.dtype == torch.float32:
+        a, b = a.contiguous(), b.contiguous()
+        Ca, Cb, B = a.shape[-1], b.shape[-1], a.shape[0]
+        rows = a.numel() // (B * Ca)
+        nblk = _lib.query("diqt_concat_channels_stats_blocks", Ca, Cb, rows)
+        if nblk > 0 and b.shape[:-1] == a.shape[:-1]:
+            _chk(a, b)
+            y = torch.empty((*a.shape[:-1], Ca + Cb), dtype=torch.float32, device=a.device)
+            stats = torch.empty((B, nblk, 2, Ca + Cb), dtype=torch.float32, device=a.device)
+            _lib.call("diqt_concat_channels_stats", a, Ca, b, Cb, float(scale_a), float(scale_b), y, B, rows, stats, _stream())
+            y._diqt_stats = ColStats(stats, nblk, rows)
+            return y
     return _ConcatFn.apply(a.contiguous(), b.contiguous(), float(scale_a), float(scale_b))
 
 

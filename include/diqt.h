@@ -435,6 +435,12 @@ int diqt_split_channels(const float* y, float* a, int Ca, float* b, int Cb, size
  * the scaled skip connections cat(x, skip * 2^-0.5) of the U-Nets (imagen_video.py:1743, imagen_pytorch3D.py:1631) in one pass.
  * float4 lanes when both channel counts are multiples of 4.                                                                  */
 int diqt_concat_channels_scaled(const float* a, int Ca, const float* b, int Cb, float sa, float sb, float* y, size_t rows, void* stream);
+/* The same pass ALSO writing the column sums (sum, sum of squares) of y per 256-row block, stats[B][nblk][2][Ca + Cb] with nblk =
+ * diqt_concat_channels_stats_blocks (0: shape not taken): the concatenated skip connection feeds a ResnetBlock's GroupNorm
+ * (imagen_video.py:1743-1747, imagen_pytorch3D.py:1631-1633), whose statistics then come from diqt_groupnorm_stats_from_partials. */
+int diqt_concat_channels_stats_blocks(int Ca, int Cb, int rows_per_batch);
+int diqt_concat_channels_stats(const float* a, int Ca, const float* b, int Cb, float sa, float sb, float* y, int B, int rows_per_batch,
+                               float* stats, void* stream);
 int diqt_split_channels_scaled(const float* y, float* a, int Ca, float* b, int Cb, float sa, float sb, size_t rows, void* stream);
 /* trilinear x`scale` up-sampling with align_corners=True (nn.Upsample imagen_pytorch3D.py:954) and its
  * adjoint (dx must be zeroed by the caller; accumulated with float atomics)                          */

@@ -977,3 +977,34 @@ def test_scaled_concat_and_its_adjoint_bit_exact(ops, shape, Ca, Cb, fa, fb):
     assert torch.equal(y.cpu(), torch.cat((a * fa, b * fb), -1))
     y.backward(dy.to(DEV))
     assert torch.equal(ad.grad.cpu(), dy[..., :Ca] * fa) and torch.equal(bd.grad.cpu(), dy[..., Ca:] * fb)
+
+
+@pytest.mark.parametrize("B,rows,Ca,Cb", [(2, 1000, 64, 64), (1, 777, 128, 256), (3, 256, 4, 8), (2, 4096, 256, 128)])
+def test_concat_with_column_sums_for_the_next_groupnorm(B, rows, Ca, Cb):
+    """cat(x, skip * 2^-0.5) of the up path (imagen_video.py:1743, imagen_pytorch3D.py:1631) in one pass that also writes the column sums
+    of its output: y bit-identical to the plain concat, the sums equal to a float64 reduction of y, and the GroupNorm that follows takes
+    them (``_diqt_stats``) instead of a statistics pass."""
+    from diffusioniqt_amd import ops, _lib
+    g = torch.Generator().manual_seed(B * 7 + Ca)
+    a = torch.randn(B, rows, 1, 1, Ca, generator=g).to(DEV)
+    b = torch.randn(B, rows, 1, 1, Cb, generator=g).to(DEV)
+    sb = 2 ** -0.5
+    with torch.no_grad():
+        y0 = ops.concat_channels(a, b, 1.0, sb)
+        with _lib.census() as c:
+            y = ops.concat_channels(a, b, 1.0, sb, want_stats=True)
+            assert c.count("concat_channels_stats") == 1
+    assert torch.equal(y, y0)
+    st = y._diqt_stats
+    assert st.rows == rows and st.partials.shape == (B, st.nblk, 2, Ca + Cb)
+    got = st.partials.double().sum(1)
+    flat = y.double().reshape(B, rows, Ca + Cb)
+    assert torch.allclose(got[:, 0], flat.sum(1), rtol=1e-6, atol=1e-3) and torch.allclose(got[:, 1], (flat * flat).sum(1), rtol=1e-6, atol=1e-3)
+    # the consumer: GroupNorm statistics from the partials == from a pass over the tensor
+    gamma, beta = torch.ones(Ca + Cb, device=DEV), torch.zeros(Ca + Cb, device=DEV)
+    with torch.no_grad(), _lib.census() as c:
+        z1 = ops.groupnorm_act(y, gamma, beta, None, 4, ops.ACT_SILU, 1e-5)
+        assert c.count("groupnorm_stats_from_partials") == 1 and c.count("groupnorm_stats/reduce") == 0
+    with torch.no_grad():
+        z0 = ops.groupnorm_act(y0, gamma, beta, None, 4, ops.ACT_SILU, 1e-5)
+    assert (z1 - z0).abs().max().item() <= 2e-5 * z0.abs().max().item()

@@ -2297,9 +2297,9 @@ extern "C" int diqt_conv3d_bwd_weight_h(const float* x, const float* dy, float* 
     DIQT_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace), DIQT_E_ALIGN, "conv3d_bwd_weight_h: pointers must be 16-byte aligned");
     WHGeom g;
     int ks = 0;
-    const bool xHalf = (bf16 & 2) != 0;          // bit 1 of `bf16`: x holds 16-bit values of the operand type
+    const bool xHalf = (bf16 & 2) != 0, dyHalf = (bf16 & 4) != 0;      // bits 1, 2 of `bf16`: x / dY hold 16-bit values of the operand type
     bf16 &= 1;
-    DIQT_REQUIRE(wgradh_plan(g, ks, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, xHalf), DIQT_E_UNSUPPORTED,
+    DIQT_REQUIRE(wgradh_plan(g, ks, B, D, H, W, Cin, Cout, kd, kh, kw, pd, ph, pw, epd, eph, epw, xHalf, dyHalf), DIQT_E_UNSUPPORTED,
                  "conv3d_bwd_weight_h: shape not taken (diqt_conv3d_bwd_weight_h_workspace_bytes == 0)");
     const int T = kd * kh * kw;
     const size_t need = ((size_t)ks * Cout * Cin * T + (size_t)ks * g.CoutPad) * sizeof(float);

@@ -76,12 +76,16 @@ __device__ __forceinline__ u32x4w tr_frag(const unsigned char* p, int rowBytes) 
 
 // XH: x holds 16-bit values of the operand type (the GroupNorm-apply output a bf16 training step saved in that type, ops._GnActConvHFn):
 // a piece is 8 channels and goes to the LDS image as it is -- the same bits the fp32 tensor's values round to while staged.
-template <class C, bool BF, bool XH = false>
+// DYH: dY holds 16-bit values as well (the gradient a low-precision training step keeps in the operand type between a GroupNorm backward
+// and the conv backward that consumes it): 8 channels per piece, copied verbatim; the bias gradient sums exactly those values.
+template <class C, bool BF, bool XH = false, bool DYH = false>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ slabs, float* __restrict__ bias_part, WHGeom g) {
     constexpr int WT = C::T, NA = C::NA, WHH = C::HH, WHW = C::HW, WHV = C::HV, NPX = XH ? (C::HV * 4 + 255) / 256 : C::NPX;
     constexpr int XPS = XH ? 2 : 3, XCH = XH ? 8 : 4;      // log2 pieces per 32-channel row, channels per 16-byte piece
     constexpr unsigned XE = XH ? 2u : 4u;
+    constexpr int NPYK = DYH ? WMV * 8 / 256 : NPY, YPS = DYH ? 3 : 4, YCH = DYH ? 8 : 4;      // dY pieces per thread, log2 pieces per 64-channel row, channels per piece
+    constexpr unsigned YE = DYH ? 2u : 4u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
     unsigned char* Xs = smw;                         // [432][64 B]   halo voxels x 32 ci
     unsigned char* Ys = smw + WHV * XROW;            // [128][192 B]  tile voxels x 64 co
@@ -112,17 +116,17 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
         xdst[u] = row < WHV ? (unsigned)(row * XROW + q4 * (XH ? 16 : 8)) : 0xffffffffu;
     }
     const unsigned limits = (unsigned)(g.D + PADB - 1) | ((unsigned)(g.H + PADB - 1) << 10) | ((unsigned)(g.W + PADB - 1) << 20);
-    unsigned yrel[NPY], ypc[NPY];
+    unsigned yrel[NPYK], ypc[NPYK];
+    const int yq = tid & ((1 << YPS) - 1);            // this thread's co quad (octet) of a dY row (the same for all its pieces)
 #pragma unroll
-    for (int u = 0; u < NPY; ++u) {
-        const int row = (u * 256 + tid) >> 4;
+    for (int u = 0; u < NPYK; ++u) {
+        const int row = (u * 256 + tid) >> YPS;
         const int tw = row % WTW, th = (row / WTW) % WTH, td = row / (WTW * WTH);
         ypc[u] = (unsigned)td | ((unsigned)th << 10) | ((unsigned)tw << 20);
-        yrel[u] = (unsigned)(((td * g.Ho + th) * g.Wo + tw) * g.Cout + co0 + (tid & 15) * 4) * 4u;
+        yrel[u] = (unsigned)(((td * g.Ho + th) * g.Wo + tw) * g.Cout + co0 + yq * YCH) * YE;
     }
     const unsigned ylimits = (unsigned)(g.Do + PADB - 1) | ((unsigned)(g.Ho + PADB - 1) << 10) | ((unsigned)(g.Wo + PADB - 1) << 20);
-    const int yq = tid & 15;                          // this thread's co quad of a dY row (the same for all its pieces)
-    const bool yok = co0 + yq * 4 < g.Cout;
+    const bool yok = co0 + yq * YCH < g.Cout;
     // ---- fragment addresses ----
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
     const unsigned char* aBase = Ys + (8 * hf + trq) * YROW + (32 * ct + 16 * trc + 4 * trp) * 2;
@@ -139,10 +143,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
     for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f), bsum2 = make_float4(0.f, 0.f, 0.f, 0.f);      // (bsum2: channels 4..7 of a 16-bit octet)
 
     u32x4w px[NPX];                                   // raw pieces: 4 fp32 channels, or (XH) 8 channels of the operand type
-    float4 py[NPY];
+    u32x4w py[NPYK];
     auto load_tile = [&](int mt) {
         int m = mt;
         const int tx = m % g.tilesW; m /= g.tilesW;
@@ -160,14 +164,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
             px[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
         }
         const unsigned yorg = (unsigned)(d0 + (int)PADB) + ((unsigned)(h0 + (int)PADB) << 10) + ((unsigned)(w0 + (int)PADB) << 20);
-        const unsigned ybase = (unsigned)((((b * g.Do + d0) * g.Ho + h0) * g.Wo + w0) * g.Cout) * 4u;
+        const unsigned ybase = (unsigned)((((b * g.Do + d0) * g.Ho + h0) * g.Wo + w0) * g.Cout) * YE;
 #pragma unroll
-        for (int u = 0; u < NPY; ++u) {
+        for (int u = 0; u < NPYK; ++u) {
             const unsigned c = ypc[u] + yorg;
             const unsigned okm = ((c | GUARD) - LOW) & ((ylimits | GUARD) - c) & GUARD;
             const unsigned off = (yok && okm == GUARD) ? ybase + yrel[u] : WH_OOB;
-            const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
-            py[u] = make_float4(wasf(v.x), wasf(v.y), wasf(v.z), wasf(v.w));
+            py[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
         }
     };
     auto store_tile = [&]() {
@@ -185,12 +188,31 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
             }
         }
 #pragma unroll
-        for (int u = 0; u < NPY; ++u) {
-            const int row = (u * 256 + tid) >> 4;
-            u32x2w w;
-            w.x = wpack2<BF>(py[u].x, py[u].y); w.y = wpack2<BF>(py[u].z, py[u].w);
-            *reinterpret_cast<u32x2w*>(Ys + row * YROW + yq * 8) = w;
-            bsum.x += py[u].x; bsum.y += py[u].y; bsum.z += py[u].z; bsum.w += py[u].w;      // exact fp32 dY: the bias gradient
+        for (int u = 0; u < NPYK; ++u) {
+            const int row = (u * 256 + tid) >> YPS;
+            const u32x4w v = py[u];
+            if constexpr (DYH) {
+                *reinterpret_cast<u32x4w*>(Ys + row * YROW + yq * 16) = v;
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned wd = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+                    if (BF) { f[2 * e] = wasf(wd << 16); f[2 * e + 1] = wasf(wd & 0xffff0000u); }
+                    else {
+                        typedef _Float16 h2w __attribute__((ext_vector_type(2)));
+                        const h2w hv = __builtin_bit_cast(h2w, wd);
+                        f[2 * e] = (float)hv[0]; f[2 * e + 1] = (float)hv[1];
+                    }
+                }
+                bsum.x += f[0]; bsum.y += f[1]; bsum.z += f[2]; bsum.w += f[3];
+                bsum2.x += f[4]; bsum2.y += f[5]; bsum2.z += f[6]; bsum2.w += f[7];
+            } else {
+                const float4 pf = make_float4(wasf(v.x), wasf(v.y), wasf(v.z), wasf(v.w));
+                u32x2w w;
+                w.x = wpack2<BF>(pf.x, pf.y); w.y = wpack2<BF>(pf.z, pf.w);
+                *reinterpret_cast<u32x2w*>(Ys + row * YROW + yq * 8) = w;
+                bsum.x += pf.x; bsum.y += pf.y; bsum.z += pf.z; bsum.w += pf.w;      // exact fp32 dY: the bias gradient
+            }
         }
     };
 
@@ -255,13 +277,24 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
     // ---- bias partial of this slice (workgroups of the first ci block): 16 threads share a co quad ----
     if (bias_part && cib == 0) {
         float4* red = reinterpret_cast<float4*>(smw);
-        red[tid] = bsum;
-        __syncthreads();
-        if (tid < 16) {
-            float4 s = red[tid];
-            for (int k = 1; k < 16; ++k) { const float4 t = red[tid + 16 * k]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
-            float* bp = bias_part + (size_t)blockIdx.y * g.CoutPad + co0 + tid * 4;
-            if (co0 + tid * 4 < g.Cout) { bp[0] = s.x; bp[1] = s.y; bp[2] = s.z; bp[3] = s.w; }
+        if constexpr (DYH) {            // 32 threads share a channel octet: [256][2] quads
+            red[2 * tid] = bsum; red[2 * tid + 1] = bsum2;
+            __syncthreads();
+            if (tid < 16) {             // quad tid of the 64 channels: octet tid / 2, half tid % 2
+                float4 s = red[2 * (tid >> 1) + (tid & 1)];
+                for (int k = 1; k < 32; ++k) { const float4 t = red[2 * ((tid >> 1) + 8 * k) + (tid & 1)]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+                float* bp = bias_part + (size_t)blockIdx.y * g.CoutPad + co0 + tid * 4;
+                if (co0 + tid * 4 < g.Cout) { bp[0] = s.x; bp[1] = s.y; bp[2] = s.z; bp[3] = s.w; }
+            }
+        } else {
+            red[tid] = bsum;
+            __syncthreads();
+            if (tid < 16) {
+                float4 s = red[tid];
+                for (int k = 1; k < 16; ++k) { const float4 t = red[tid + 16 * k]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+                float* bp = bias_part + (size_t)blockIdx.y * g.CoutPad + co0 + tid * 4;
+                if (co0 + tid * 4 < g.Cout) { bp[0] = s.x; bp[1] = s.y; bp[2] = s.z; bp[3] = s.w; }
+            }
         }
     }
 }
@@ -269,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h_kernel(const float* __res
 }  // namespace
 
 bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
-                 int epd, int eph, int epw, bool xHalf) {
+                 int epd, int eph, int epw, bool xHalf, bool dyHalf) {
     static const bool off = [] { const char* e = getenv("DIQT_NO_WGRADH"); return e && e[0] == '1'; }();
     const bool filt = (kd == 3 && kh == 3 && kw == 3) || (kd == 1 && kh == 3 && kw == 3) || (kd == 3 && kh == 1 && kw == 1);
     if (off || !filt || Cin % 32 != 0 || Cout % 4 != 0 || Cin < 32 || Cout < 32) return false;
@@ -284,9 +317,9 @@ bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, in
     if (mt >= (1ll << 30)) return false;
     g.MT = (int)mt;
     g.nCoB = (Cout + 63) / 64; g.nCiB = Cin / 32; g.CoutPad = g.nCoB * 64;
-    const unsigned long long xb = (unsigned long long)B * D * H * W * Cin * (xHalf ? 2ull : 4ull), yb = (unsigned long long)B * g.Do * g.Ho * g.Wo * Cout * 4ull;
-    if (xb >= (1ull << 30) || yb >= (1ull << 30) || (xHalf && Cin % 8 != 0)) return false;
-    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.xHalf = xHalf ? 1 : 0;
+    const unsigned long long xb = (unsigned long long)B * D * H * W * Cin * (xHalf ? 2ull : 4ull), yb = (unsigned long long)B * g.Do * g.Ho * g.Wo * Cout * (dyHalf ? 2ull : 4ull);
+    if (xb >= (1ull << 30) || yb >= (1ull << 30) || (xHalf && Cin % 8 != 0) || (dyHalf && Cout % 8 != 0)) return false;
+    g.xBytes = (unsigned)xb; g.yBytes = (unsigned)yb; g.xHalf = xHalf ? 1 : 0; g.dyHalf = dyHalf ? 1 : 0;
     const int blocks = g.nCoB * g.nCiB;
     ksplit = 256 / blocks;
     if (ksplit > g.MT) ksplit = g.MT;
@@ -298,8 +331,10 @@ bool wgradh_plan(WHGeom& g, int& ksplit, int B, int D, int H, int W, int Cin, in
 
 template <class C>
 static int wgradh_launch_t(const float* x, const float* dy, float* slabs, float* bias_part, const WHGeom& g, int ksplit, int bf16, void* stream) {
-    auto kern = g.xHalf ? (bf16 ? conv_wgrad_h_kernel<C, true, true> : conv_wgrad_h_kernel<C, false, true>)
+    auto kern = g.xHalf && g.dyHalf ? (bf16 ? conv_wgrad_h_kernel<C, true, true, true> : conv_wgrad_h_kernel<C, false, true, true>)
+              : g.xHalf ? (bf16 ? conv_wgrad_h_kernel<C, true, true> : conv_wgrad_h_kernel<C, false, true>)
                         : (bf16 ? conv_wgrad_h_kernel<C, true> : conv_wgrad_h_kernel<C, false>);
+    DIQT_REQUIRE(!g.dyHalf || g.xHalf, DIQT_E_UNSUPPORTED, "conv3d_bwd_weight_h: a 16-bit dY is built together with a 16-bit x");
     if (C::LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         DIQT_REQUIRE(e == hipSuccess, DIQT_E_LAUNCH, "conv3d_bwd_weight_h: hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -368,11 +368,37 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
     }
 }
 
+// four consecutive channels of a tensor that holds fp32 (ty 0), fp16 (1) or bf16 (2) values; `i` = element index (a multiple of 4)
+__device__ __forceinline__ float4 ld4_any(const void* p, size_t i, int ty) {
+    if (ty == 0) return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + i);
+    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p) + i);
+    if (ty == 2) return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const unsigned ux = u.x, uy = u.y;       // (by value: __builtin_bit_cast on a vector component reads element 0 on this hipcc, see conv_half.hip)
+    const h2v a = __builtin_bit_cast(h2v, ux), b = __builtin_bit_cast(h2v, uy);
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+__device__ __forceinline__ void st4_any(void* p, size_t i, float4 v, int ty) {
+    if (ty == 0) { *reinterpret_cast<float4*>(static_cast<float*>(p) + i) = v; return; }
+    uint2 u;
+    if (ty == 2) {
+        typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+        const b2v a = {(__bf16)v.x, (__bf16)v.y}, b = {(__bf16)v.z, (__bf16)v.w};
+        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
+    } else {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const h2v a = {(_Float16)v.x, (_Float16)v.y}, b = {(_Float16)v.z, (_Float16)v.w};
+        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
+    }
+    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p) + i) = u;
+}
+
 // pass 1 of the backward: S1[b][c] = sum dz, S2[b][c] = sum dz*xhat, dz = dy*act'(z)
 struct GnBwdF {
     const float *x, *dy;
     GnCoef k;
     int act;
+    int xty = 0;                           // x holds fp32 (0), fp16 (1) or bf16 (2) values (the 16-bit block output of a low-precision training step)
     __device__ __forceinline__ void one(float xv, float dyv, int b, int c, float& s1, float& s2) const {
         float A, Bc;
         k.get(b, c, A, Bc);
@@ -396,7 +422,7 @@ struct GnBwdF {
         s1 = dz; s2 = dz * xhat;
     }
     __device__ void vec4(size_t i, int, int, float (&o)[2][4]) const {
-        const float4 xv = *reinterpret_cast<const float4*>(x + i);
+        const float4 xv = ld4_any(x, i, xty);
         const float4 dv = *reinterpret_cast<const float4*>(dy + i);
         onej(xv.x, dv.x, 0, o[0][0], o[1][0]);
         onej(xv.y, dv.y, 1, o[0][1], o[1][1]);
@@ -450,15 +476,16 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ dx, GnCoef k,
                                                             const float* __restrict__ m12, int rows, int act,
-                                                            const float* __restrict__ add) {
+                                                            const float* __restrict__ add, int xty = 0, int dxty = 0) {
+    // xty / dxty (VEC only): x read / dx written as fp32 (0), fp16 (1) or bf16 (2) values
     // add (optional, kernel-uniform): the gradient that reaches x through its OTHER consumer (the residual branch of a ResnetBlock),
     // summed here instead of in a separate pass over three tensors
     const int b = blockIdx.y, C = k.C, G = k.G, Cg = C / G;
     const size_t per = (size_t)rows * C;
-    const float* xb = x + (size_t)b * per;
+    const float* xb = xty ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * per) : x + (size_t)b * per;
     const float* dyb = dy + (size_t)b * per;
     const float* adb = add ? add + (size_t)b * per : nullptr;
-    float* dxb = dx + (size_t)b * per;
+    float* dxb = dxty ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(dx) + (size_t)b * per) : dx + (size_t)b * per;
     auto one = [&](float xv, float dyv, int c) -> float {
         float A, Bc;
         k.get(b, c, A, Bc);
@@ -492,7 +519,7 @@ __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restr
             float4 xv[2], dv[2], av[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                xv[u] = *reinterpret_cast<const float4*>(xb + (i + u * st) * 4);
+                xv[u] = ld4_any(xb, (i + u * st) * 4, xty);
                 dv[u] = *reinterpret_cast<const float4*>(dyb + (i + u * st) * 4);
                 av[u] = adb ? *reinterpret_cast<const float4*>(adb + (i + u * st) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -501,17 +528,17 @@ __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restr
                 float4 o;
                 o.x = onej(xv[u].x, dv[u].x, 0) + av[u].x; o.y = onej(xv[u].y, dv[u].y, 1) + av[u].y;
                 o.z = onej(xv[u].z, dv[u].z, 2) + av[u].z; o.w = onej(xv[u].w, dv[u].w, 3) + av[u].w;
-                *reinterpret_cast<float4*>(dxb + (i + u * st) * 4) = o;
+                st4_any(dxb, (i + u * st) * 4, o, dxty);
             }
         }
         for (; i < n4; i += st) {
-            const float4 xv = *reinterpret_cast<const float4*>(xb + i * 4);
+            const float4 xv = ld4_any(xb, i * 4, xty);
             const float4 dv = *reinterpret_cast<const float4*>(dyb + i * 4);
             const float4 av = adb ? *reinterpret_cast<const float4*>(adb + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 o;
             o.x = onej(xv.x, dv.x, 0) + av.x; o.y = onej(xv.y, dv.y, 1) + av.y;
             o.z = onej(xv.z, dv.z, 2) + av.z; o.w = onej(xv.w, dv.w, 3) + av.w;
-            *reinterpret_cast<float4*>(dxb + i * 4) = o;
+            st4_any(dxb, i * 4, o, dxty);
         }
     } else {
         for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256)
@@ -2023,8 +2050,9 @@ static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
                            const float* gamma, const float* beta, const float* scale, const float* shift,
                            int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
                            size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream, const float* ext_partials,
-                           int ext_nblk, const float* dx_add = nullptr) {
+                           int ext_nblk, const float* dx_add = nullptr, int xty = 0, int dxty = 0) {
     DIQT_REQUIRE(x && dy && mean && rstd && dx && workspace, DIQT_E_ALIGN, "gn_act_bwd: null pointer");
+    DIQT_REQUIRE(xty >= 0 && xty <= 2 && dxty >= 0 && dxty <= 2, DIQT_E_SHAPE, "gn_act_bwd: x / dx type is 0 (fp32), 1 (fp16) or 2 (bf16)");
     DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_act_bwd: bad shape");
     DIQT_REQUIRE(workspace_bytes >= diqt_reduce_workspace_bytes(B, C), DIQT_E_WORKSPACE, "gn_act_bwd: workspace too small");
     DIQT_REQUIRE(aligned16(workspace), DIQT_E_ALIGN, "gn_act_bwd: misaligned workspace");
@@ -2036,7 +2064,9 @@ static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
     float* m12 = S + (size_t)2 * B * C;
     const size_t per = (size_t)rows * C;
     const bool vec = vec_ok(x, dy, dx, per, C) && (!dx_add || aligned16(dx_add));
+    DIQT_REQUIRE(vec || (xty == 0 && dxty == 0), DIQT_E_UNSUPPORTED, "gn_act_bwd: 16-bit x / dx need C %% 4 == 0 and 16-byte aligned tensors");
     GnBwdF f{x, dy, k, act};
+    f.xty = xty;
     int rc = DIQT_OK;
     if (ext_partials) {
         DIQT_REQUIRE(ext_nblk > 0, DIQT_E_SHAPE, "gn_act_bwd_from_partials: nblk");
@@ -2057,7 +2087,7 @@ static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
     rc = check_launch("gn_act_bwd/final");
     if (rc) return rc;
     const dim3 grid(gn_grid(per, C, B), B);
-    if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act, dx_add);
+    if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act, dx_add, xty, dxty);
     else hipLaunchKernelGGL(gn_act_bwd_dx_kernel<false>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act, dx_add);
     return check_launch("gn_act_bwd/dx");
 }
@@ -2088,6 +2118,17 @@ extern "C" int diqt_gn_act_bwd_ex(const float* x, const float* dy, const float* 
                                   size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream) {
     return gn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, scale, shift, cond_stride, dx, dgamma, dbeta, dscale, dshift, workspace,
                            workspace_bytes, B, rows, C, G, act, stream, partials, nblk, dx_add);
+}
+
+// The same with x read and / or dx written in a 16-bit type (x_type, dx_type: 0 fp32, 1 fp16, 2 bf16): a low-precision training step
+// keeps a ResnetBlock's block1 output -- a conv result, rounded to the operand type by autocast anyway -- in that type, and the gradient
+// that flows back into it is only ever read by 16-bit-operand conv kernels (backward-data, weight gradient), which would round it too.
+extern "C" int diqt_gn_act_bwd_h(const void* x, const float* dy, const float* partials, int nblk, const float* dx_add, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
+                                 int cond_stride, void* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
+                                 size_t workspace_bytes, int B, int rows, int C, int G, int act, int x_type, int dx_type, void* stream) {
+    return gn_act_bwd_impl(static_cast<const float*>(x), dy, mean, rstd, gamma, beta, scale, shift, cond_stride, static_cast<float*>(dx), dgamma,
+                           dbeta, dscale, dshift, workspace, workspace_bytes, B, rows, C, G, act, stream, partials, nblk, dx_add, x_type, dx_type);
 }
 
 extern "C" int diqt_chan_layernorm_fwd_res(const float* x, const float* g, const float* b, const float* residual, float* y,

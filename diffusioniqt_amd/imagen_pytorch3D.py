@@ -331,7 +331,7 @@ class Block(nn.Module):
             pr = self.project
             if pr.groups == 1 and tuple(pr.stride) == (1, 1, 1):
                 out = ops.gn_conv3d_train_h(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_MISH, gn.eps, pr.weight, pr.bias, pr.padding,
-                                            residual, want_stats=emit_stats, tap=tap)
+                                            residual, want_stats=emit_stats, tap=tap, out_half=out_half)
                 if out is not None:
                     return out
         if isinstance(gn, nn.GroupNorm):
@@ -448,7 +448,9 @@ class ResnetBlock(nn.Module):
         # (sampling under autocast: h only feeds block2's GroupNorm -- 16-bit when block2's conv takes a 16-bit input)
         b2 = self.block2.project
         oh = (not self.block2.boundary and isinstance(self.block2.groupnorm, nn.GroupNorm) and b2.groups == 1 and tuple(b2.stride) == (1, 1, 1)
-              and x.dim() == 5 and ops.conv_half_out_ok((*x.shape[:4], b2.weight.shape[1]), b2.weight, b2.padding))
+              and x.dim() == 5
+              and (ops.conv_half_out_ok((*x.shape[:4], b2.weight.shape[1]), b2.weight, b2.padding)
+                   or ops.train_half_out_ok((*x.shape[:4], b2.weight.shape[1]), b2.weight, b2.padding, self.block2.groupnorm.num_groups)))
         h, x = self.block1(x, emit_stats=True, tap=True, out_half=oh)
         res = self.res_conv(x)
         if isinstance(self.se, SE3D):

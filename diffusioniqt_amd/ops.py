@@ -910,20 +910,25 @@ def _lp_backward(lp):
 
 
 _NO_TRAIN_FUSE = os.environ.get("DIQT_NO_TRAIN_FUSE") == "1"      # A/B switch: bf16 training Blocks as two autograd nodes
+_NO_TRAIN_HALF = os.environ.get("DIQT_NO_TRAIN_HALF") == "1"      # A/B switch: fp32 tensor (and gradient) between block1 and block2
 
 
 class _GnActConvHFn(Function):
-    """Training under ``ImagenTrainer(precision='bf16')`` -- or ``fp16=True`` with its loss scaler -- (trainer.py:293-311): ``conv3d(act(GN(x) * (scale + 1) + shift))`` as ONE autograd
-    node whose intermediate -- the conv's input -- exists only in bf16: the GroupNorm-apply pass writes it in that type (the bits autocast's
-    cast of the fp32 tensor produces), the forward conv reads it through ``conv_f9h_kernel`` (LDS-DMA, 16-bit x) and the weight gradient
-    reads the same tensor (``diqt_conv3d_bwd_weight_h``, bit 1).  Bit-identical to the two-node path (``_GnActFn`` + ``_Conv3dFn``), at
-    half the bytes for the saved activation and the faster forward kernel.  Backward: dX of the conv on the bf16 MFMA kernel (fp32 dY
-    rows), then the GroupNorm backward exactly as ``_GnActFn.backward``."""
+    """Training under ``ImagenTrainer(precision='bf16')`` -- or ``fp16=True`` with its loss scaler -- (trainer.py:293-311):
+    ``conv3d(act(GN(x) * (scale + 1) + shift))`` as ONE autograd node whose intermediate -- the conv's input -- exists only in the 16-bit
+    operand type: the GroupNorm-apply pass writes it so (the bits autocast's cast of the fp32 tensor produces), the forward conv reads it
+    through ``conv_f9h_kernel`` (LDS-DMA, 16-bit x) and the weight gradient reads the same tensor (``diqt_conv3d_bwd_weight_h``, bit 1).
+    ``out_half``: the conv's OUTPUT is an autograd tensor of that type too (a ResnetBlock's block1 -> block2: a conv result autocast rounds
+    anyway); the node that consumes it (x of a 16-bit type, statistics from the column sums) hands back a 16-bit gradient
+    (``diqt_gn_act_bwd_h``), which this node's backward-data runs through ``conv_f9h_kernel`` and its weight gradient reads as it is (bit 2)
+    -- the same bits the fp32 tensors round to inside those kernels.  Bit-identical to the two-node path (``_GnActFn`` + ``_Conv3dFn``)."""
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, groups, act, eps, pre, weight, bias, pad, residual, stats_out, tap, ss_grad):
-        _chk(x, gamma, beta, weight, bias, residual)
+    def forward(ctx, x, gamma, beta, ss, groups, act, eps, pre, weight, bias, pad, residual, stats_out, tap, ss_grad, out_half):
+        x_half = x.dtype != torch.float32
+        _chk(None if x_half else x, gamma, beta, weight, bias, residual)
         if ss is not None:
             assert ss.is_cuda and ss.dtype == torch.float32 and ss.dim() == 2 and ss.stride(1) == 1, "scale/shift rows must be fp32 HIP tensors"
+        assert not (x_half and tap), "the alias output routes an fp32 input's second consumer"
         ctx.tap = tap
         ctx.set_materialize_grads(False)
         B, C = x.shape[0], x.shape[-1]
@@ -934,6 +939,7 @@ class _GnActConvHFn(Function):
         if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
             _lib.call("diqt_groupnorm_stats_from_partials", pre.partials, mean, rstd, B, pre.nblk, rows, C, groups, float(eps), s)
         else:
+            assert not x_half, "a 16-bit block output must carry the GroupNorm statistics of the conv that wrote it"
             ws, n = _reduce_ws(B, C, x.device)
             _lib.call("diqt_groupnorm_stats", x, mean, rstd, ws, n, B, rows, C, groups, float(eps), s)
         scale = shift = None
@@ -942,30 +948,34 @@ class _GnActConvHFn(Function):
             assert ss.shape == (B, 2 * C), f"scale/shift embedding must be [B, 2C] rows, got {tuple(ss.shape)}"
             scale, shift, cs = ss.data_ptr(), ss.data_ptr() + 4 * C, ss.stride(0)
         lp = lp_mode()                                       # 1: bf16, 0: fp16 (under a loss scaler)
-        y16 = torch.empty(x.shape, dtype=torch.bfloat16 if lp == 1 else torch.float16, device=x.device)
-        _lib.call("diqt_gn_act_fwd_h", x, mean, rstd, gamma, beta, scale, shift, cs, y16, B, rows, C, groups, act, lp, 0, s)
-        y = _conv_fwd_half(y16, weight, bias, residual, pad, (0, 0, 0), lp, x_half=True, y_half=False, stats_out=stats_out)
+        hdt = torch.bfloat16 if lp == 1 else torch.float16
+        assert not x_half or x.dtype == hdt
+        y16 = torch.empty(x.shape, dtype=hdt, device=x.device)
+        _lib.call("diqt_gn_act_fwd_h", x, mean, rstd, gamma, beta, scale, shift, cs, y16, B, rows, C, groups, act, lp, int(x_half), s)
+        y = _conv_fwd_half(y16, weight, bias, residual, pad, (0, 0, 0), lp, x_half=True, y_half=bool(out_half), stats_out=stats_out)
         ctx.lp = lp
         ctx.ss_grad = ss_grad
         ctx.save_for_backward(x, gamma, beta, ss, mean, rstd, y16, weight)
-        ctx.cfg = (B, rows, C, groups, act, pad, bias is not None, residual is not None)
+        ctx.cfg = (B, rows, C, groups, act, pad, bias is not None, residual is not None, x_half, bool(out_half))
         return (y, x) if tap else y
 
     @staticmethod
     def backward(ctx, dy, dtap=None):
         x, gamma, beta, ss, mean, rstd, y16, weight = ctx.saved_tensors
-        B, rows, C, groups, act, pad, has_bias, has_res = ctx.cfg
-        none = (None,) * 15
+        B, rows, C, groups, act, pad, has_bias, has_res, x_half, y_half = ctx.cfg
+        none = (None,) * 16
         if dy is None:                      # only the alias was used downstream
             return (dtap,) + none[1:]
         dy = dy.contiguous()
+        assert (dy.dtype != torch.float32) == y_half
         Cout, Cin, kd, kh, kw = weight.shape
         D, H, W = x.shape[1:4]
         pd, ph, pw = pad
         bpad = (kd - 1 - pd, kh - 1 - ph, kw - 1 - pw)
-        # ---- conv: dX on the bf16 MFMA kernel (flipped weights), dW / db with the bf16 activation as it was saved ----
-        dact = _conv_fwd_half(dy, weight, None, None, bpad, (0, 0, 0), ctx.lp, mode=1)
+        # ---- conv: dX on the 16-bit MFMA kernel (flipped weights; conv_f9h_kernel when dY is 16-bit), dW / db with the 16-bit activation ----
+        dact = _conv_fwd_half(dy, weight, None, None, bpad, (0, 0, 0), ctx.lp, mode=1, x_half=y_half)
         if dact is None:
+            assert not y_half
             dact = _conv_fwd_raw(dy, _packed(weight, 1), None, None, Cin, (kd, kh, kw), bpad, (0, 0, 0))
         dw = torch.empty_like(weight)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
@@ -975,12 +985,13 @@ class _GnActConvHFn(Function):
         if TIMER.enabled:
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record()
-        _lib.call("diqt_conv3d_bwd_weight_h", y16, dy, dw, db, _workspace(nh, x.device), nh, *geo, ctx.lp | 2, _stream())      # bit 1: x is 16-bit
+        _lib.call("diqt_conv3d_bwd_weight_h", y16, dy, dw, db, _workspace(nh, x.device), nh, *geo, ctx.lp | 2 | (4 if y_half else 0),
+                  _stream())                                # bit 1: x is 16-bit, bit 2: dY is 16-bit
         if TIMER.enabled:
             t1.record()
             Do, Ho, Wo = dy.shape[1:4]
             TIMER.records.append((t0, t1, 2.0 * B * Do * Ho * Wo * Cout * Cin * kd * kh * kw, "conv_wgrad_h_kernel", geo[:9]))
-        # ---- GroupNorm + activation backward (as _GnActFn.backward) ----
+        # ---- GroupNorm + activation backward (as _GnActFn.backward; a 16-bit x gets a 16-bit gradient) ----
         if dtap is not None:
             dtap = dtap.contiguous()
         dx = torch.empty_like(x)
@@ -996,35 +1007,73 @@ class _GnActConvHFn(Function):
             scale, shift = ss.data_ptr(), ss.data_ptr() + 4 * C
             dscale, dshift = dss.data_ptr(), dss.data_ptr() + 4 * C
         ws, n = _reduce_ws(B, C, x.device)
-        _lib.call("diqt_gn_act_bwd_ex", x, dact, None, 0, dtap, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
-                  dscale, dshift, ws, n, B, rows, C, groups, act, _stream())
-        return dx, dgamma, dbeta, dss, None, None, None, None, dw, db, None, (dy if has_res else None), None, None, None
+        if x_half:
+            ty = 2 if ctx.lp == 1 else 1
+            _lib.call("diqt_gn_act_bwd_h", x, dact, None, 0, dtap, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
+                      dscale, dshift, ws, n, B, rows, C, groups, act, ty, ty, _stream())
+        else:
+            _lib.call("diqt_gn_act_bwd_ex", x, dact, None, 0, dtap, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
+                      dscale, dshift, ws, n, B, rows, C, groups, act, _stream())
+        return dx, dgamma, dbeta, dss, None, None, None, None, dw, db, None, (dy if has_res else None), None, None, None, None
 
 
-def gn_conv3d_train_h(x, gamma, beta, scale_shift, groups, act, eps, weight, bias, padding, residual=None, want_stats=False, tap=False):
-    """``Block.forward`` of a bf16 training step as one autograd node (``_GnActConvHFn``); ``tap`` as in ``groupnorm_act``.  None when not in a
-    bf16 training step or the shape is not taken by the 16-bit-input kernels (the caller then runs ``groupnorm_act`` + ``conv3d``)."""
-    if _lp_backward(lp_mode()) is None or not torch.is_grad_enabled() or x.dim() != 5 or x.dtype != torch.float32 or isinstance(scale_shift, SSView) or _NO_TRAIN_FUSE:
+def _train_h_geo_ok(B, D, H, W, Cin, Cout, k, padding, groups):
+    """Is a 'same' conv of this shape taken by the one-node low-precision training Block (16-bit-x forward kernel + 16-bit weight gradient)?"""
+    kd, kh, kw = k
+    geo = (B, D, H, W, Cin, Cout, kd, kh, kw, *padding, 0, 0, 0)
+    if Cin % groups != 0 or Cin % 8 != 0 or not _lib.query("diqt_conv3d_fwd_h_io16_supported", *geo, 1, 0):
+        return False
+    if _lib.query("diqt_conv3d_bwd_weight_h_workspace_bytes", *geo) == 0:
+        return False
+    return D + 2 * padding[0] - kd + 1 == D and H + 2 * padding[1] - kh + 1 == H and W + 2 * padding[2] - kw + 1 == W
+
+
+def train_half_out_ok(shape5, w_next, padding_next, groups_next):
+    """May a Block of a low-precision TRAINING step hand its conv output on in the operand type?  (the next Block has to take it: see
+    ``gn_conv3d_train_h``)"""
+    if _lp_backward(lp_mode()) is None or not torch.is_grad_enabled() or _NO_TRAIN_FUSE or _NO_TRAIN_HALF:
+        return False
+    B, D, H, W, C = shape5
+    Cout, Cin, kd, kh, kw = w_next.shape
+    padding_next = tuple(int(p) for p in ((padding_next,) * 3 if isinstance(padding_next, int) else padding_next))
+    return Cin == C and _train_h_geo_ok(B, D, H, W, C, Cout, (kd, kh, kw), padding_next, groups_next)
+
+
+def gn_conv3d_train_h(x, gamma, beta, scale_shift, groups, act, eps, weight, bias, padding, residual=None, want_stats=False, tap=False,
+                      out_half=False):
+    """``Block.forward`` of a low-precision training step as one autograd node (``_GnActConvHFn``); ``tap`` as in ``groupnorm_act``;
+    ``out_half``: the output may leave in the operand type (it only feeds the next Block's GroupNorm).  None when not in such a step or
+    the shape is not taken by the 16-bit-input kernels (the caller then runs ``groupnorm_act`` + ``conv3d``)."""
+    x_half = x.dtype != torch.float32
+    if _lp_backward(lp_mode()) is None or not torch.is_grad_enabled() or x.dim() != 5 or isinstance(scale_shift, SSView) or _NO_TRAIN_FUSE:
+        assert not x_half
         return None
     B, D, H, W, C = x.shape
     Cout, Cin, kd, kh, kw = weight.shape
     padding = tuple(int(p) for p in ((padding,) * 3 if isinstance(padding, int) else padding))
-    geo = (B, D, H, W, C, Cout, kd, kh, kw, *padding, 0, 0, 0)
-    if (Cin != C or C % groups != 0 or C % 8 != 0 or not _lib.query("diqt_conv3d_fwd_h_io16_supported", *geo, 1, 0)
-            or _lib.query("diqt_conv3d_bwd_weight_h_workspace_bytes", *geo) == 0):
+    if Cin != C or not _train_h_geo_ok(B, D, H, W, C, Cout, (kd, kh, kw), padding, groups):
+        if x_half:
+            raise RuntimeError("gn_conv3d_train_h: a 16-bit block output reached a conv that does not take 16-bit input")
         return None
-    if D + 2 * padding[0] - kd + 1 != D or H + 2 * padding[1] - kh + 1 != H or W + 2 * padding[2] - kw + 1 != W:
-        return None                                   # ('same' convs: the backward-data pads are the forward's)
+    geo = (B, D, H, W, C, Cout, kd, kh, kw, *padding, 0, 0, 0)
+    bpad = (kd - 1 - padding[0], kh - 1 - padding[1], kw - 1 - padding[2])
+    # a 16-bit output: statistics rows for its consumer, and this node's backward-data (a conv Cout -> Cin over the 16-bit gradient)
+    yh = bool(out_half and want_stats and residual is None
+              and _lib.query("diqt_conv3d_fwd_h_io16_supported", *geo, 1, 1)
+              and _lib.query("diqt_conv3d_fwd_h_stats_blocks", *geo, 1, 1) > 0
+              and _lib.query("diqt_conv3d_fwd_h_io16_supported", B, D, H, W, Cout, C, kd, kh, kw, *bpad, 0, 0, 0, 1, 0)
+              and Cout % 8 == 0)
     use_tap = tap and x.requires_grad
     ss_grad = getattr(scale_shift, "_diqt_gradview", None)
     if scale_shift is not None and ss_grad is None and not scale_shift.is_contiguous():
         scale_shift = scale_shift.contiguous()
     holder = [] if want_stats else None
     out = _GnActConvHFn.apply(x, gamma, beta, scale_shift, groups, act, eps, getattr(x, "_diqt_stats", None), weight, bias, padding, residual,
-                              holder, use_tap, ss_grad)
+                              holder, use_tap, ss_grad, yh)
     y, alias = out if use_tap else (out, x)
     if holder:
         y._diqt_stats = holder[0]
+    assert not yh or holder
     return (y, alias) if tap else y
 
 

@@ -186,6 +186,7 @@ int diqt_conv3d_bwd_weight(const float* x, const float* dy, float* dw_oidhw, flo
 /* The weight gradient with 16-bit MFMA operands (bf16 when `bf16`, else fp16; fp32 accumulate): x and dY are rounded to that type while
  * staged, as the reference's autocast backward does under `ImagenTrainer(precision='bf16')` (trainer.py:293-311).  dbias is summed from the
  * fp32 dY.  3x3x3, (1,3,3), (3,1,1) filters, Cin % 32 == 0; ..._workspace_bytes == 0: shape not taken -- use diqt_conv3d_bwd_weight.  Deterministic.
+ * Bit 2 of `bf16` (value 4): dY holds 16-bit values of the operand type too (the gradient a low-precision training step keeps in that type).
  * Bit 1 of `bf16` (value 2): x already HOLDS 16-bit values of the operand type (the GroupNorm-apply output a bf16 training step kept in
  * that type for the conv's forward and for this pass: half the bytes, the same bits the fp32 values round to).                          */
 size_t diqt_conv3d_bwd_weight_h_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph,
@@ -301,6 +302,12 @@ int diqt_gn_act_bwd_ex(const float* x, const float* dy, const float* partials, i
                        const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
                        int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
                        size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream);
+/* diqt_gn_act_bwd_ex with x read and / or dx written in a 16-bit type (x_type, dx_type: 0 fp32, 1 fp16, 2 bf16): the block1 output of a
+ * ResnetBlock and the gradient flowing back into it during a low-precision training step (both only meet 16-bit-operand kernels). */
+int diqt_gn_act_bwd_h(const void* x, const float* dy, const float* partials, int nblk, const float* dx_add, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift, int cond_stride,
+                      void* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace, size_t workspace_bytes, int B,
+                      int rows, int C, int G, int act, int x_type, int dx_type, void* stream);
 int diqt_gn_act_bwd_from_partials(const float* x, const float* dy, const float* partials, int nblk, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, const float* scale, const float* shift, int cond_stride,
                                   float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,

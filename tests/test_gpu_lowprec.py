@@ -684,3 +684,58 @@ def test_fp16_training_with_the_loss_scaler():
         tr2 = make(fp16=True)
         tr2.load(path)
         assert tr2.scaler1.state_dict() == tr.scaler1.state_dict()
+
+
+@pytest.mark.parametrize("mode,use_se", [("bf16", True), ("bf16", False), ("fp16", True)])
+def test_low_precision_training_resnet_block_with_16_bit_tensor_and_gradient_between_its_blocks(mode, use_se):
+    """A ResnetBlock of a low-precision training step (imagen_pytorch3D.py:568-614 under trainer.py:293-311): block1's output -- a conv
+    result autocast rounds anyway -- and the gradient flowing back into it live in the operand type only (written by conv_f9h_kernel /
+    the GroupNorm backward, read by the GroupNorm-apply pass, conv_f9h_kernel's backward-data and the weight gradient).
+    The 16-bit tensors hold exactly what the conv kernels round the fp32 ones to, so against the same one-node Blocks with fp32 tensors
+    between them (DIQT_NO_TRAIN_HALF) and against the two-node path everything agrees to the round-off of the GroupNorm statistics (the
+    conv epilogue sums its columns in another order) -- except block1's conv bias gradient, which is now summed from the 16-bit gradient
+    (what the reference's autocast backward sums, too) instead of from its fp32 precursor."""
+    from diffusioniqt_amd import ops, _lib
+    from diffusioniqt_amd.imagen_pytorch3D import ResnetBlock
+    B, S, C = 2, 16, 64
+    g = torch.Generator().manual_seed(23)
+    x0 = torch.randn(B, S, S, S, C, generator=g)
+    t0 = torch.randn(B, 32, generator=g)
+    dy = torch.randn(B, S, S, S, C, generator=g).to(DEV)
+    torch.manual_seed(5)
+    blk = ResnetBlock(C, C, time_cond_dim=32, groups=8, use_se=use_se).to(DEV).train()
+    for p_ in blk.parameters():
+        torch.nn.init.normal_(p_, std=0.2 if p_.dim() == 1 else 0.05)
+
+    def run(fused, half):
+        blk.zero_grad(set_to_none=True)
+        x = x0.clone().to(DEV).requires_grad_(True)
+        t = t0.clone().to(DEV).requires_grad_(True)
+        was = ops._NO_TRAIN_FUSE, ops._NO_TRAIN_HALF
+        ops._NO_TRAIN_FUSE, ops._NO_TRAIN_HALF = not fused, not half
+        ops.FP16_BACKWARD = mode == "fp16"                   # (what the trainer's loss scaler switches on)
+        try:
+            with ops.low_precision(mode), _lib.census() as c:
+                y = blk(x * 1.0, t)
+                (y * dy).sum().backward()
+                torch.cuda.synchronize()
+                n9 = c.count("conv3d_fwd_h(v9h)")
+        finally:
+            ops._NO_TRAIN_FUSE, ops._NO_TRAIN_HALF = was
+            ops.FP16_BACKWARD = False
+        out = {k: p_.grad.clone() for k, p_ in blk.named_parameters() if p_.grad is not None}
+        out.update(y=y.detach(), gx=x.grad, gt=t.grad)
+        return out, n9
+
+    a, na = run(True, True)
+    b, nb = run(True, False)
+    c2, nc = run(False, False)
+    assert (na, nb, nc) == (3, 2, 0)                         # both forwards (+ block1's backward-data over the 16-bit gradient)
+    assert a.keys() == b.keys() == c2.keys() and len(a) >= 11
+    # one rounding of a value to the operand type can flip when the GroupNorm statistics move in their last fp32 bits (another order of
+    # the same column sums): a few 16-bit ulps of the tensor's scale; on this seed the bf16 runs agree bit for bit except that bias
+    ulp = 2.0 ** -8 if mode == "bf16" else 2.0 ** -11
+    for k in a:
+        tol = 3e-2 if k == "block1.project.bias" else 2 * ulp
+        assert (a[k] - b[k]).abs().max().item() <= tol * b[k].abs().max().item() + 1e-6, (k, (a[k] - b[k]).abs().max())
+        assert (a[k] - c2[k]).abs().max().item() <= tol * c2[k].abs().max().item() + 1e-6, (k, (a[k] - c2[k]).abs().max())

@@ -10,6 +10,32 @@ namespace diqt {
 
 constexpr int RED_NBLK = 256;  // row slices per batch element in the column reductions (8 x 256 workgroups: 64 slices left the loads of a 32^3 x 64 pass at 4 TB/s)
 
+// four consecutive channels of a tensor that holds fp32 (ty 0), fp16 (1) or bf16 (2) values; `i` = element index (a multiple of 4)
+__device__ __forceinline__ float4 ld4_any(const void* p, size_t i, int ty) {
+    if (ty == 0) return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + i);
+    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p) + i);
+    if (ty == 2) return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const unsigned ux = u.x, uy = u.y;       // (by value: __builtin_bit_cast on a vector component reads element 0 on this hipcc, see conv_half.hip)
+    const h2v a = __builtin_bit_cast(h2v, ux), b = __builtin_bit_cast(h2v, uy);
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+__device__ __forceinline__ void st4_any(void* p, size_t i, float4 v, int ty) {
+    if (ty == 0) { *reinterpret_cast<float4*>(static_cast<float*>(p) + i) = v; return; }
+    uint2 u;
+    if (ty == 2) {
+        typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+        const b2v a = {(__bf16)v.x, (__bf16)v.y}, b = {(__bf16)v.z, (__bf16)v.w};
+        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
+    } else {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const h2v a = {(_Float16)v.x, (_Float16)v.y}, b = {(_Float16)v.z, (_Float16)v.w};
+        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
+    }
+    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p) + i) = u;
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // generic per-(b,c) column reduction: partial[b][blk][NV][C] = sum over the block's rows of f(...)
 // ---------------------------------------------------------------------------------------------
@@ -368,31 +394,6 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
     }
 }
 
-// four consecutive channels of a tensor that holds fp32 (ty 0), fp16 (1) or bf16 (2) values; `i` = element index (a multiple of 4)
-__device__ __forceinline__ float4 ld4_any(const void* p, size_t i, int ty) {
-    if (ty == 0) return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + i);
-    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p) + i);
-    if (ty == 2) return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    const unsigned ux = u.x, uy = u.y;       // (by value: __builtin_bit_cast on a vector component reads element 0 on this hipcc, see conv_half.hip)
-    const h2v a = __builtin_bit_cast(h2v, ux), b = __builtin_bit_cast(h2v, uy);
-    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
-}
-__device__ __forceinline__ void st4_any(void* p, size_t i, float4 v, int ty) {
-    if (ty == 0) { *reinterpret_cast<float4*>(static_cast<float*>(p) + i) = v; return; }
-    uint2 u;
-    if (ty == 2) {
-        typedef __bf16 b2v __attribute__((ext_vector_type(2)));
-        const b2v a = {(__bf16)v.x, (__bf16)v.y}, b = {(__bf16)v.z, (__bf16)v.w};
-        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
-    } else {
-        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-        const h2v a = {(_Float16)v.x, (_Float16)v.y}, b = {(_Float16)v.z, (_Float16)v.w};
-        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
-    }
-    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p) + i) = u;
-}
-
 // pass 1 of the backward: S1[b][c] = sum dz, S2[b][c] = sum dz*xhat, dz = dy*act'(z)
 struct GnBwdF {
     const float *x, *dy;
@@ -686,10 +687,11 @@ struct WeightedF {      // x[b][row][c] * w[b][row]  (GlobalContext pooling, ima
 };
 struct ProdF {
     const float *a, *b;
+    int bty = 0;                           // b holds fp32 (0), fp16 (1) or bf16 (2) values
     __device__ void prep(int, int) {}
     __device__ void vec4(size_t i, int, int, float (&o)[1][4]) const {
         const float4 u = *reinterpret_cast<const float4*>(a + i);
-        const float4 v = *reinterpret_cast<const float4*>(b + i);
+        const float4 v = ld4_any(b, i, bty);
         o[0][0] = u.x * v.x; o[0][1] = u.y * v.y; o[0][2] = u.z * v.z; o[0][3] = u.w * v.w;
     }
     __device__ void scalar(size_t i, int, int, float (&o)[1]) const { o[0] = a[i] * b[i]; }
@@ -699,19 +701,20 @@ struct ProdF {
 template <bool VEC>
 __global__ __launch_bounds__(256) void gate_residual_kernel(const float* __restrict__ h, const float* __restrict__ gate,
                                                             const float* __restrict__ res, const float* __restrict__ addc,
-                                                            float alpha, float* __restrict__ y, int rows, int C) {
+                                                            float alpha, float* __restrict__ y, int rows, int C, int hty = 0, int yty = 0) {
+    // hty / yty (VEC only): h read / y written as fp32 (0), fp16 (1) or bf16 (2) values
     const int b = blockIdx.y;
     const size_t per = (size_t)rows * C;
-    const float* hb = h + (size_t)b * per;
+    const float* hb = hty ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(h) + (size_t)b * per) : h + (size_t)b * per;
     const float* rb = res ? res + (size_t)b * per : nullptr;
     const float* gb = gate + (size_t)b * C;
     const float* ab = addc ? addc + (size_t)b * C : nullptr;
-    float* yb = y + (size_t)b * per;
+    float* yb = yty ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(y) + (size_t)b * per) : y + (size_t)b * per;
     if (VEC) {
         const size_t n4 = per >> 2;
         for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
             const int c = (int)((i * 4) % C);
-            float4 v = *reinterpret_cast<const float4*>(hb + i * 4);
+            float4 v = ld4_any(hb, i * 4, hty);
             const float4 gq = *reinterpret_cast<const float4*>(gb + c);
             v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
             if (ab) {
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const float* __restr
                 const float4 r = *reinterpret_cast<const float4*>(rb + i * 4);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
-            *reinterpret_cast<float4*>(yb + i * 4) = v;
+            st4_any(yb, i * 4, v, yty);
         }
     } else {
         for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
@@ -740,18 +743,18 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const float* __restr
 // the threads t, t + C/4, ... of a workgroup share it: fixed-order combine through LDS, one partial row per workgroup.
 __global__ __launch_bounds__(256) void gate_residual_stats_kernel(const float* __restrict__ h, const float* __restrict__ gate,
                                                                   const float* __restrict__ res, float* __restrict__ y,
-                                                                  float* __restrict__ stats, int rows, int C) {
+                                                                  float* __restrict__ stats, int rows, int C, int hty = 0) {
     __shared__ float red[256 * 8];
     const int b = blockIdx.y, t = threadIdx.x;
     const size_t per = (size_t)rows * C, n4 = per >> 2;
-    const float* hb = h + (size_t)b * per;
+    const float* hb = hty ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(h) + (size_t)b * per) : h + (size_t)b * per;
     const float* rb = res ? res + (size_t)b * per : nullptr;
     float* yb = y + (size_t)b * per;
     const int c = (t * 4) % C;
     const float4 gq = *reinterpret_cast<const float4*>(gate + (size_t)b * C + c);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
     for (size_t i = blockIdx.x * (size_t)256 + t; i < n4; i += (size_t)gridDim.x * 256) {
-        float4 v = *reinterpret_cast<const float4*>(hb + i * 4);
+        float4 v = ld4_any(hb, i * 4, hty);
         v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
         if (rb) {
             const float4 r = *reinterpret_cast<const float4*>(rb + i * 4);
@@ -2382,6 +2385,44 @@ extern "C" int diqt_gate_residual_fwd(const float* h, const float* gate, const f
     else
         hipLaunchKernelGGL(gate_residual_kernel<false>, grid, dim3(256), 0, STREAM, h, gate, res, addc, alpha, y, rows, C);
     return check_launch("gate_residual_fwd");
+}
+
+// The SE gate / its gradient with the conv output h -- a value autocast rounds to the operand type anyway -- and the gradient written back
+// into it held in a 16-bit type (h_type / y_type: 0 fp32, 1 fp16, 2 bf16): block2's output of a ResnetBlock under autocast sampling or
+// low-precision training lives in that type only (imagen_pytorch3D.py:601-632).  C % 4 == 0, 16-byte aligned tensors.
+extern "C" int diqt_gate_residual_fwd_h(const void* h, const float* gate, const float* res, const float* addc, float alpha, void* y, int B,
+                                        int rows, int C, int h_type, int y_type, void* stream) {
+    DIQT_REQUIRE(h && gate && y, DIQT_E_ALIGN, "gate_residual_fwd_h: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && C % 4 == 0 && h_type >= 0 && h_type <= 2 && y_type >= 0 && y_type <= 2, DIQT_E_SHAPE,
+                 "gate_residual_fwd_h: bad shape / type");
+    DIQT_REQUIRE(aligned16(h) && aligned16(y) && aligned16(gate) && (!res || aligned16(res)) && (!addc || aligned16(addc)), DIQT_E_ALIGN,
+                 "gate_residual_fwd_h: pointers must be 16-byte aligned");
+    const size_t per = (size_t)rows * C;
+    const dim3 grid(grid_for(per / 4 + 1, 256, 1024), B);
+    hipLaunchKernelGGL(gate_residual_kernel<true>, grid, dim3(256), 0, STREAM, static_cast<const float*>(h), gate, res, addc, alpha,
+                       static_cast<float*>(y), rows, C, h_type, y_type);
+    return check_launch("gate_residual_fwd_h");
+}
+extern "C" int diqt_gate_residual_fwd_stats_h(const void* h, const float* gate, const float* res, float* y, float* stats, int B, int rows,
+                                              int C, int h_type, void* stream) {
+    DIQT_REQUIRE(h && gate && y && stats, DIQT_E_ALIGN, "gate_residual_fwd_stats_h: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && h_type >= 0 && h_type <= 2, DIQT_E_SHAPE, "gate_residual_fwd_stats_h: bad shape / type");
+    const int nblk = diqt_gate_residual_stats_blocks(rows, C);
+    DIQT_REQUIRE(nblk > 0, DIQT_E_UNSUPPORTED, "gate_residual_fwd_stats_h: C = %d must be a multiple of 4 dividing 1024", C);
+    DIQT_REQUIRE(aligned16(h) && aligned16(gate) && aligned16(y) && aligned16(stats) && (!res || aligned16(res)), DIQT_E_ALIGN,
+                 "gate_residual_fwd_stats_h: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(gate_residual_stats_kernel, dim3(nblk, B), dim3(256), 0, STREAM, static_cast<const float*>(h), gate, res, y, stats, rows,
+                       C, h_type);
+    return check_launch("gate_residual_fwd_stats_h");
+}
+extern "C" int diqt_gate_residual_bwd_h(const void* h, const float* dy, float* dgate, void* workspace, size_t workspace_bytes, int B, int rows,
+                                        int C, int h_type, void* stream) {
+    DIQT_REQUIRE(h && dy && dgate, DIQT_E_ALIGN, "gate_residual_bwd_h: null pointer");
+    DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && C % 4 == 0 && C <= 1024 && h_type >= 0 && h_type <= 2, DIQT_E_SHAPE, "gate_residual_bwd_h: bad shape / type");
+    DIQT_REQUIRE(aligned16(h) && aligned16(dy), DIQT_E_ALIGN, "gate_residual_bwd_h: misaligned pointer");
+    ProdF f{dy, static_cast<const float*>(h)};
+    f.bty = h_type;
+    return colreduce1(f, dgate, 1.f, workspace, workspace_bytes, B, rows, C, stream, "gate_residual_bwd_h");
 }
 
 // number of per-workgroup partial rows diqt_gate_residual_fwd_stats writes per batch entry (0: shape not supported -- C must divide

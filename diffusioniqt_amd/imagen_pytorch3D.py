@@ -454,7 +454,10 @@ class ResnetBlock(nn.Module):
         h, x = self.block1(x, emit_stats=True, tap=True, out_half=oh)
         res = self.res_conv(x)
         if isinstance(self.se, SE3D):
-            h = self.block2(h, scale_shift=scale_shift, emit_stats=True)     # ... and the SE pooling from this one's
+            # ... and the SE pooling from this one's.  Under autocast sampling / low-precision training block2's output only meets the SE
+            # gate (statistics from the column sums, one elementwise pass): it may leave in the operand type (gn_conv3d_h / gn_conv3d_train_h
+            # decide whether the shape allows it)
+            h = self.block2(h, scale_shift=scale_shift, emit_stats=True, out_half=ops.lp_mode() is not None and not ops._NO_TRAIN_HALF)
             return self.se(h, residual=res)
         return self.block2(h, scale_shift=scale_shift, residual=res)   # residual add fused in the conv epilogue
 

@@ -1259,7 +1259,9 @@ def learned_sinusoidal(t, w):
 class _SEResidualFn(Function):
     @staticmethod
     def forward(ctx, h, w1, w2, res, pre=None, stats_out=None):
-        _chk(h, w1, w2, res)
+        h_half = h.dtype != torch.float32      # block2's conv output in the operand type (autocast sampling / low-precision training)
+        hty = 0 if not h_half else (2 if h.dtype == torch.bfloat16 else 1)
+        _chk(None if h_half else h, w1, w2, res)
         B, C = h.shape[0], h.shape[-1]
         rows = h.numel() // (B * C)
         Cr = w1.shape[0]
@@ -1276,20 +1278,27 @@ class _SEResidualFn(Function):
             if pre is not None and pre.rows == rows and pre.partials.shape == (B, pre.nblk, 2, C):
                 _lib.call("diqt_channel_mean_from_partials", pre.partials, pooled, B, pre.nblk, rows, C, s)
             else:
+                assert not h_half, "a 16-bit conv output must carry its column sums (the SE squeeze reads them)"
                 ws, n = _reduce_ws(B, C, dev)
                 _lib.call("diqt_channel_mean", h, pooled, ws, n, B, rows, C, s)
             _lib.call("diqt_se_pool_mlp_fwd", None, 0, 0, pooled, w1, w2, hidden, gate, B, C, Cr, s)
-        y = torch.empty_like(h)
+        y = torch.empty(h.shape, dtype=torch.float32, device=dev)
         nblk = _lib.query("diqt_gate_residual_stats_blocks", rows, C) if stats_out is not None else 0
         if nblk > 0:
             # the block's output feeds the next block's first GroupNorm: its per-workgroup column sums ride along (no statistics pass)
             stats = torch.empty((B, nblk, 2, C), dtype=torch.float32, device=dev)
-            _lib.call("diqt_gate_residual_fwd_stats", h, gate, res, y, stats, B, rows, C, s)
+            if h_half:
+                _lib.call("diqt_gate_residual_fwd_stats_h", h, gate, res, y, stats, B, rows, C, hty, s)
+            else:
+                _lib.call("diqt_gate_residual_fwd_stats", h, gate, res, y, stats, B, rows, C, s)
             stats_out.append(ColStats(stats, nblk, rows))
+        elif h_half:
+            _lib.call("diqt_gate_residual_fwd_h", h, gate, res, None, 0.0, y, B, rows, C, hty, 0, s)
         else:
             _lib.call("diqt_gate_residual_fwd", h, gate, res, None, 0.0, y, B, rows, C, s)
         ctx.save_for_backward(h, w1, w2, pooled, hidden, gate)
         ctx.has_res = res is not None
+        ctx.hty = hty
         return y
 
     @staticmethod
@@ -1303,13 +1312,19 @@ class _SEResidualFn(Function):
         s = _stream()
         dgate = torch.empty_like(gate)
         ws, n = _reduce_ws(B, C, dev)
-        _lib.call("diqt_gate_residual_bwd", h, dy, dgate, ws, n, B, rows, C, s)
+        if ctx.hty:
+            _lib.call("diqt_gate_residual_bwd_h", h, dy, dgate, ws, n, B, rows, C, ctx.hty, s)
+        else:
+            _lib.call("diqt_gate_residual_bwd", h, dy, dgate, ws, n, B, rows, C, s)
         dpooled = torch.empty_like(pooled)
         dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
         scratch = torch.empty(B * (C + Cr), dtype=torch.float32, device=dev)
         _lib.call("diqt_se_mlp_bwd", pooled, w1, w2, hidden, gate, dgate, dpooled, dw1, dw2, scratch, B, C, Cr, s)
-        dh = torch.empty_like(h)
-        _lib.call("diqt_gate_residual_fwd", dy, gate, None, dpooled, 1.0 / rows, dh, B, rows, C, s)
+        dh = torch.empty_like(h)                       # (a 16-bit h gets a 16-bit gradient: only 16-bit-operand conv kernels read it)
+        if ctx.hty:
+            _lib.call("diqt_gate_residual_fwd_h", dy, gate, None, dpooled, 1.0 / rows, dh, B, rows, C, 0, ctx.hty, s)
+        else:
+            _lib.call("diqt_gate_residual_fwd", dy, gate, None, dpooled, 1.0 / rows, dh, B, rows, C, s)
         return dh, dw1, dw2, (dy if ctx.has_res else None), None, None
 
 

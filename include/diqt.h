@@ -394,6 +394,16 @@ int diqt_gate_residual_fwd_stats(const float* h, const float* gate, const float*
 /* dgate[b][c] = sum_rows dy*h */
 int diqt_gate_residual_bwd(const float* h, const float* dy, float* dgate, void* workspace, size_t workspace_bytes,
                            int B, int rows_per_batch, int C, void* stream);
+/* The SE gate with the conv output h and the gradient flowing back into it in a 16-bit type (h_type / y_type: 0 fp32, 1 fp16, 2 bf16): a
+ * ResnetBlock's block2 output under autocast sampling / low-precision training exists in the operand type only -- autocast rounds a conv
+ * result to it anyway (imagen_pytorch3D.py:601-632).  _fwd_h: y = h gate (+ res) (+ alpha addc[b][c]); with res = NULL and addc it is also
+ * the backward dh = dy gate + dpooled / rows, written in y_type.                                                                       */
+int diqt_gate_residual_fwd_h(const void* h, const float* gate, const float* res, const float* addc, float alpha, void* y, int B, int rows,
+                             int C, int h_type, int y_type, void* stream);
+int diqt_gate_residual_fwd_stats_h(const void* h, const float* gate, const float* res, float* y, float* stats, int B, int rows, int C,
+                                   int h_type, void* stream);
+int diqt_gate_residual_bwd_h(const void* h, const float* dy, float* dgate, void* workspace, size_t workspace_bytes, int B, int rows, int C,
+                             int h_type, void* stream);
 /* SE3D.fc (imagen_pytorch3D.py:621-626,631): hidden = relu(pooled w1^T), gate = sigmoid(hidden w2^T);
  * w1[Cr][C], w2[C][Cr], no biases.  bwd: dpooled, dw1, dw2 from dgate; scratch >= B*(C+Cr) floats.     */
 int diqt_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* hidden, float* gate,

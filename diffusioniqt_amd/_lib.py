@@ -118,6 +118,7 @@ PROTOTYPES = {
     "diqt_bgemm_workspace_bytes": (Z, [I, I, I, I]),
     "diqt_bgemm_ws": (I, [P, P, P, P, Z, I, I, I, I, I, I, L, L, L, I, I, I, F, F, P]),
     "diqt_multi_accumulate": (I, [P, P, I, I, P]),
+    "diqt_multi_accumulate_host": (I, [P, P, I, I, P]),
     "diqt_conv3d_fwd_stats_blocks": (I, [I] * 15),
     "diqt_conv3d_fwd_kernel_id": (I, [I] * 15),
     "diqt_conv3d_bwd_weight_kernel_id": (I, [I] * 15),

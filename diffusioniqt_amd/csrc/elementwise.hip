@@ -1267,6 +1267,28 @@ __global__ __launch_bounds__(256) void multi_accumulate_kernel(float* __restrict
         for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] += src[i];
     }
 }
+// the same with the table passed BY VALUE in the kernel arguments (no table upload: the launch is self-contained, so a captured hipGraph
+// of a training micro-step replays it as it stands -- the gradient tensors of a capture live at fixed addresses of the graph's pool)
+constexpr int MA_ROWS = 120;
+struct MaTable { const float* src[MA_ROWS]; long long off[MA_ROWS]; long long n[MA_ROWS]; };
+static_assert(sizeof(MaTable) + 16 <= 4096, "kernel arguments are limited to 4 KiB");
+__global__ __launch_bounds__(256) void multi_accumulate_args_kernel(float* __restrict__ dst, const MaTable t) {
+    const float* __restrict__ src = t.src[blockIdx.y];
+    float* __restrict__ d = dst + t.off[blockIdx.y];
+    const size_t n = (size_t)t.n[blockIdx.y];
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
+        const size_t n4 = n >> 2;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            float4 a = reinterpret_cast<float4*>(d)[i];
+            const float4 b = reinterpret_cast<const float4*>(src)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            reinterpret_cast<float4*>(d)[i] = a;
+        }
+        for (size_t i = (n4 << 2) + blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] += src[i];
+    } else {
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] += src[i];
+    }
+}
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, size_t n, float w) {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         e[i] += (p[i] - e[i]) * w;
@@ -2689,6 +2711,25 @@ extern "C" int diqt_multi_accumulate(float* dst, const long long* table, int cou
     DIQT_REQUIRE(count <= 65535 && blocks_per_tensor > 0, DIQT_E_SHAPE, "multi_accumulate: count %d out of range", count);
     hipLaunchKernelGGL(multi_accumulate_kernel, dim3(blocks_per_tensor, count), dim3(256), 0, STREAM, dst, table);
     return check_launch("multi_accumulate");
+}
+extern "C" int diqt_multi_accumulate_host(float* dst, const long long* host_table, int count, int blocks_per_tensor, void* stream) {
+    DIQT_REQUIRE(dst && host_table, DIQT_E_ALIGN, "multi_accumulate_host: null pointer");
+    DIQT_REQUIRE(count >= 0 && blocks_per_tensor > 0, DIQT_E_SHAPE, "multi_accumulate_host: count %d out of range", count);
+    for (int lo = 0; lo < count; lo += MA_ROWS) {
+        const int m = count - lo < MA_ROWS ? count - lo : MA_ROWS;
+        MaTable t;
+        for (int i = 0; i < MA_ROWS; ++i) {
+            const long long* e = host_table + 3 * (size_t)(lo + (i < m ? i : 0));
+            t.src[i] = reinterpret_cast<const float*>(e[0]);
+            t.off[i] = e[1];
+            t.n[i] = e[2];
+            DIQT_REQUIRE(t.src[i] && t.off[i] >= 0 && t.n[i] >= 0, DIQT_E_SHAPE, "multi_accumulate_host: bad row %d", lo + i);
+        }
+        hipLaunchKernelGGL(multi_accumulate_args_kernel, dim3(blocks_per_tensor, m), dim3(256), 0, STREAM, dst, t);
+        const int rc = check_launch("multi_accumulate");
+        if (rc != DIQT_OK) return rc;
+    }
+    return DIQT_OK;
 }
 extern "C" int diqt_ema_lerp(float* ema, const float* param, size_t n, float one_minus_decay, void* stream) {
     DIQT_REQUIRE(ema && param, DIQT_E_ALIGN, "ema_lerp: null pointer");

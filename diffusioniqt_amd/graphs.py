@@ -141,6 +141,7 @@ class GraphCache:
                 fn(*s_args, **s_kwargs)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
+            ops.capture_begins()
             with torch.cuda.graph(g):
                 out = fn(*s_args, **s_kwargs)
             ent.update(graph=g, args=s_args, kwargs=s_kwargs, out=out)
@@ -151,3 +152,103 @@ class GraphCache:
             ent["error"] = repr(e)
             if FORCE:                                    # strict mode for tests
                 raise
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# training micro-steps
+# ------------------------------------------------------------------------------------------------------------------------------
+TRAIN_ENABLED = os.environ.get("DIQT_TRAIN_GRAPH", "1") != "0"
+TRAIN_FORCE = os.environ.get("DIQT_TRAIN_GRAPH") == "2"
+
+
+class TrainStepGraphs:
+    """hipGraph capture + replay of ONE training micro-step: forward, loss, backward and the hand-over of the parameter gradients to
+    the flat arena (trainer.ImagenTrainer.forward; trainer.py:1099-1128 of the reference is the loop it sits in).
+
+    The bf16 micro-step of the C2 U-Net is ~675 launches and 12.6 ms of kernel time, but 14.8 ms of wall time when Python (the forward)
+    and the autograd engine (the backward) issue them one by one.  The step is the same launch sequence every time -- same shapes, same
+    kernels, activations and gradients at the same addresses of the graph's private pool, parameters and the gradient arena at fixed
+    addresses -- so after ``warm`` eager micro-steps of a key it is captured once and replayed: the per-step inputs (images, noise,
+    noise-schedule coefficients) are copied into the captured buffers; loss / prediction are read from them.  Same kernels, same
+    arguments: bit-identical to the eager step.
+
+    What a replay must not depend on is anything the host cached from the WEIGHTS (16-bit packed copies, merged projections): those are
+    re-derived inside the graph -- the capture runs with ``ops._WEIGHT_EPOCH`` bumped, so every such cache misses and its pack launch is
+    part of the graph -- and a replay after an optimiser step therefore reads the new weights.  Only launch-bound steps are captured
+    (host time of the last eager step > 0.7 x its GPU span): the fp32 step (40 ms of kernels behind ~14 ms of issuing) stays eager.
+    ``DIQT_TRAIN_GRAPH=0`` switches this off, ``=2`` captures regardless of the timing (tests)."""
+
+    def __init__(self, warm=3, max_entries=2):
+        self.entries = {}
+        self.warm, self.max_entries = warm, max_entries
+        self.replays = 0
+
+    def clear(self):
+        n = sum(1 for e in self.entries.values() if e["graph"] is not None)
+        self.entries = {}
+        if n:
+            ops.graphs_alive(-n)
+
+    def __del__(self):
+        try:
+            self.clear()
+        except Exception:                                # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def run(self, key, fn, tensors, recover):
+        """``fn(*tensors)`` (tensors: device tensors or None) -> tuple of tensors / None.  ``recover()`` restores the host-side state a
+        failed capture left half-changed (nothing has run on the GPU then)."""
+        if not TRAIN_ENABLED or ops.TIMER.enabled:
+            return fn(*tensors)
+        key = key + (_sig(tensors), ops.lp_mode(), _lib.SWITCH_EPOCH)
+        ent = self.entries.get(key)
+        if ent is None:
+            if len(self.entries) >= self.max_entries:
+                self.clear()
+            ent = self.entries[key] = dict(calls=0, graph=None, failed=False)
+        if ent["failed"]:
+            return fn(*tensors)
+        if ent["graph"] is None:
+            ent["calls"] += 1
+            if ent["calls"] < self.warm:
+                return fn(*tensors)
+            if ent["calls"] == self.warm:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                t0 = time.perf_counter()
+                out = fn(*tensors)
+                ent["host_ms"] = (time.perf_counter() - t0) * 1e3
+                e1.record()
+                ent["events"] = (e0, e1)
+                return out
+            e0, e1 = ent.pop("events")
+            e1.synchronize()
+            ent["gpu_ms"] = e0.elapsed_time(e1)
+            if not (TRAIN_FORCE or ent["host_ms"] > 0.7 * ent["gpu_ms"]):
+                ent["failed"] = True                     # GPU-bound: the host already runs ahead of the kernels
+                return fn(*tensors)
+            static = [t.clone() if torch.is_tensor(t) else t for t in tensors]
+            try:
+                torch.cuda.synchronize()
+                ops.bump_weight_epoch()                  # every weight-derived host cache misses: its launch becomes part of the graph
+                g = torch.cuda.CUDAGraph()
+                ops.capture_begins()
+                with torch.cuda.graph(g):
+                    out = fn(*static)
+                ent.update(graph=g, static=static, out=out)
+                ops.graphs_alive(+1)
+            except Exception as e:                       # noqa: BLE001 -- capture refused: this key stays eager
+                torch.cuda.synchronize()
+                ent["failed"] = True
+                ent["error"] = repr(e)
+                recover()
+                if TRAIN_FORCE:
+                    raise
+                return fn(*tensors)
+        else:
+            for dst, src in zip(ent["static"], tensors):
+                if torch.is_tensor(dst):
+                    dst.copy_(src)
+        ent["graph"].replay()
+        self.replays += 1
+        return tuple(o.clone() if torch.is_tensor(o) else o for o in ent["out"])

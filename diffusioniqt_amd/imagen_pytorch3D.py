@@ -402,9 +402,9 @@ class BatchedTimeMLPs:
         if key != self.key:
             ops.retire(self.w, self.b)
             with torch.no_grad():
-                self.w = torch.cat([l.weight for l in self.linears], dim=0).contiguous()
-                self.b = torch.cat([l.bias if l.bias is not None else torch.zeros(l.weight.shape[0], device=l.weight.device)
-                                    for l in self.linears]).contiguous()
+                self.w = ops.born(torch.cat([l.weight for l in self.linears], dim=0).contiguous())
+                self.b = ops.born(torch.cat([l.bias if l.bias is not None else torch.zeros(l.weight.shape[0], device=l.weight.device)
+                                             for l in self.linears]).contiguous())
             self.offs, off = {}, 0
             for l in self.linears:
                 self.offs[id(l)] = (off, l.weight.shape[0])
@@ -1327,8 +1327,13 @@ class Imagen(nn.Module):
 
     # ---- training ---------------------------------------------------------------------------------
     def p_losses(self, unet, x_start, times, *, noise_scheduler, lowres_cond_img=None, cond_images=None, noise=None,
-                 pred_objective='noise', p2_loss_weight_gamma=0., **kwargs):
-        """imagen_pytorch3D.py:2277-2387 -> (loss, pred, x_noisy, lowres)."""
+                 pred_objective='noise', p2_loss_weight_gamma=0., deferred=False, **kwargs):
+        """imagen_pytorch3D.py:2277-2387 -> (loss, pred, x_noisy, lowres).
+
+        ``deferred=True`` returns ``(core, tensors)`` instead: everything that touches the host (the noise schedule is evaluated on the
+        host like in the reference's trace, its values uploaded) has happened, ``core(*tensors)`` is device work only -- q_sample, the
+        U-Net, the loss -- with every device tensor it reads passed in, so the trainer can capture it (and the backward behind it) into a
+        hipGraph and replay it on other tensors of the same shapes (trainer._TrainGraphs)."""
         if pred_objective not in ('noise', 'x_start', 'v'):
             raise ValueError(f'unknown objective {pred_objective}')
         device = x_start.device
@@ -1338,25 +1343,30 @@ class Imagen(nn.Module):
         times_cpu = times.detach().cpu().float()
         log_snr = noise_scheduler.log_snr(times_cpu)
         alpha, sigma = log_snr_to_alpha_sigma(log_snr)
-        x_noisy = ops.q_sample(x_start, noise, alpha.to(device), sigma.to(device))          # (:311-322)
-        noise_cond = log_snr.to(device)
         inner = unet.module if hasattr(unet, 'module') else unet
         assert not inner.self_cond, 'self-conditioning is not used by the IQT path'
-        pred = unet.forward(x_noisy, times, noise_cond, lowres_cond_img=lowres_cond_img, cond_images=cond_images,
-                            cond_drop_prob=self.cond_drop_prob)
         weight = None
         if p2_loss_weight_gamma > 0:                                                       # (:2368-2370)
             weight = ((self.p2_loss_weight_k + log_snr.exp()) ** -p2_loss_weight_gamma).to(device)
-        if pred_objective == 'x_start':
-            # in-place clamp_(min_bound) + MSE mean in one kernel; returns the clamped pred like the reference (:2361-2364)
-            loss, pred = ops.mse_clamp(pred, x_start, lo=float(self.min_bound), do_clamp=True, weight=weight, kind=self.loss_type)
-        else:
-            if pred_objective == 'noise':                                                  # (:2344-2345)
-                target = noise
-            else:                                                                          # v = alpha*eps - sigma*x0 (:2348-2352)
-                target = ops.axpby3(noise, x_start, None, alpha.to(device), (-sigma).to(device), None, 0.0, 0.0, 0)
-            loss, pred = ops.mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=weight, kind=self.loss_type)
-        return loss, pred, x_noisy, lowres_cond_img
+        min_bound, loss_type, drop = float(self.min_bound), self.loss_type, self.cond_drop_prob
+
+        def core(x_start, noise, alpha, sigma, neg_sigma, noise_cond, lowres_cond_img, cond_images, weight):
+            x_noisy = ops.q_sample(x_start, noise, alpha, sigma)                           # (:311-322)
+            pred = unet.forward(x_noisy, times, noise_cond, lowres_cond_img=lowres_cond_img, cond_images=cond_images, cond_drop_prob=drop)
+            if pred_objective == 'x_start':
+                # in-place clamp_(min_bound) + MSE mean in one kernel; returns the clamped pred like the reference (:2361-2364)
+                loss, pred = ops.mse_clamp(pred, x_start, lo=min_bound, do_clamp=True, weight=weight, kind=loss_type)
+            else:
+                if pred_objective == 'noise':                                              # (:2344-2345)
+                    target = noise
+                else:                                                                      # v = alpha*eps - sigma*x0 (:2348-2352)
+                    target = ops.axpby3(noise, x_start, None, alpha, neg_sigma, None, 0.0, 0.0, 0)
+                loss, pred = ops.mse_clamp(pred, target, lo=0.0, do_clamp=False, weight=weight, kind=loss_type)
+            return loss, pred, x_noisy, lowres_cond_img
+
+        tensors = (x_start, noise, alpha.to(device), sigma.to(device), (-sigma).to(device) if pred_objective == 'v' else None,
+                   log_snr.to(device), lowres_cond_img, cond_images, weight)
+        return (core, tensors) if deferred else core(*tensors)
 
     def forward(self, images, lowres_img=None, unet=None, text_embeds=None, text_masks=None, unet_number=None,
                 cond_images=None, **kwargs):

@@ -181,6 +181,24 @@ class Conv3d(nn.Module):
                           want_stats=want_stats)
 
 
+    def train_h(self, x, norm, ss, ignore_time=False, residual=None, want_stats=False, tap=False):
+        """Training step under autocast: ``norm`` + SiLU + the per-frame conv as one autograd node whose activation between the two is
+        kept in the operand type (ops.gn_conv3d_train_h), then the temporal conv.  None: shape not taken."""
+        sc = self.spatial_conv
+        k = self.kernel_size
+        last = ignore_time or not exists(self.temporal_conv)
+        out = ops.gn_conv3d_train_h(x, norm.weight, norm.bias, ss, norm.num_groups, ACT_SILU, norm.eps, sc.weight.unsqueeze(2), sc.bias,
+                                    (0, k // 2, k // 2), residual if last else None, want_stats=want_stats and last, tap=tap)
+        if out is None or last:
+            return out
+        y, alias = out if tap else (out, None)
+        tc = self.temporal_conv
+        kt = tc.weight.shape[-1]
+        y = ops.conv3d(y, tc.weight.unsqueeze(-1).unsqueeze(-1), tc.bias, (kt - 1, 0, 0), residual=residual, extra_pad=(-(kt - 1), 0, 0),
+                       want_stats=want_stats)
+        return (y, alias) if tap else y
+
+
 class DynamicPositionBias(nn.Module):
     """imagen_video.py:1119-1160 — returns the table [2n-1, heads]; the (i - j) gather is fused into the soft-max kernel."""
 
@@ -398,6 +416,11 @@ class Block(nn.Module):
                 return (y, x) if tap else y
             if x.dtype != torch.float32:                 # a 16-bit block output whose consumer does not take the 16-bit path after all
                 x = x.float()
+        elif ops.lp_mode() is not None:
+            # low-precision training step: GroupNorm-apply -> operand type -> per-frame conv as one autograd node (ops._GnActConvHFn)
+            out = self.project.train_h(x, gn, scale_shift, ignore_time=ignore_time, residual=residual, want_stats=emit_stats, tap=tap)
+            if out is not None:
+                return out
         if tap:
             x, alias = ops.groupnorm_act(x, gn.weight, gn.bias, scale_shift, gn.num_groups, ACT_SILU, gn.eps, tap=True)
             return self.project(x, ignore_time=ignore_time, residual=residual, want_stats=emit_stats), alias

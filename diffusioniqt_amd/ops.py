@@ -32,10 +32,29 @@ _GRAPH_PINS = []
 _LIVE_GRAPHS = 0
 
 
+_CAPTURE_CLOCK = 0      # number of graph captures begun so far
+
+
+def capture_begins():
+    """graphs.py, right before a capture: tensors the host caches created up to here may be addressed by the new graph."""
+    global _CAPTURE_CLOCK
+    _CAPTURE_CLOCK += 1
+
+
+def born(t):
+    """Stamps a tensor a host-side cache is about to keep with the capture clock (see ``retire``)."""
+    if t is not None:
+        t._diqt_born = _CAPTURE_CLOCK
+    return t
+
+
 def retire(*tensors):
-    """A host-side cache is dropping these device tensors: keep them alive while any captured graph may still address them."""
+    """A host-side cache is dropping these device tensors: keep them alive while any captured graph may still address them.  A tensor
+    created after the newest capture began (``born``) is addressed by no graph -- or lives in that graph's own pool -- and is not pinned:
+    with a captured TRAINING step alive for the whole run, every validation / sampling pass in between re-packs the weights, and those
+    copies must not pile up."""
     if _LIVE_GRAPHS > 0:
-        _GRAPH_PINS.extend(t for t in tensors if t is not None)
+        _GRAPH_PINS.extend(t for t in tensors if t is not None and getattr(t, "_diqt_born", -1) < _CAPTURE_CLOCK)
 
 
 def graphs_alive(delta):
@@ -191,7 +210,7 @@ def _packed(weight5, mode):
     _lib.call("diqt_conv_pack_weight", weight5.detach(), packed, Cout, Cin, kd, kh, kw, mode, _stream())
     if hit is not None:
         retire(hit[1])
-    cache[mode] = (key, packed)
+    cache[mode] = (key, born(packed))
     return packed
 
 
@@ -217,7 +236,7 @@ def _packed_h(weight5, bf16, mode=0):
     _lib.call("diqt_conv_pack_weight_h", weight5.detach(), packed, Cout, Cin, kd, kh, kw, mode, bf16, _stream())
     if hit is not None:
         retire(hit[1])
-    cache[slot] = (key, packed)
+    cache[slot] = (key, born(packed))
     return packed
 
 
@@ -2186,8 +2205,9 @@ def multi_accumulate(dst_flat, srcs, offsets):
     for t, off in zip(srcs, offsets):
         assert t.is_contiguous() and t.dtype == torch.float32
         rows.append((t.data_ptr(), int(off), t.numel()))
-    table = torch.tensor(rows, dtype=torch.int64).to(dst_flat.device, non_blocking=True)
-    _lib.call("diqt_multi_accumulate", dst_flat, table, len(rows), 16, _stream())   # same stream as the producers/allocator
+    # the table stays on the host and travels in the kernel arguments: no upload, and a captured micro-step replays the launch as it is
+    table = torch.tensor(rows, dtype=torch.int64)
+    _lib.call("diqt_multi_accumulate_host", dst_flat, table, len(rows), 16, _stream())   # same stream as the producers/allocator
 
 
 def ema_lerp(ema, param, one_minus_decay):

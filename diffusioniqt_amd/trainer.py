@@ -23,7 +23,7 @@ from torch import nn
 from torch.optim.lr_scheduler import CosineAnnealingLR, LambdaLR
 from torch.utils.data import DataLoader, random_split
 
-from . import ops
+from . import ops, graphs
 from . import distributed as D
 from .imagen_pytorch3D import Imagen, NullUnet
 from .utils_mine import convertVolume2subVolume, merge_sub_volumes
@@ -474,6 +474,7 @@ class ImagenTrainer(nn.Module):
         self.split_batches = split_batches
         self.gradient_accumulation_steps = gradient_accumulation_steps
         self._micro_step = 0
+        self._train_graphs = graphs.TrainStepGraphs()          # captured micro-steps (launch-bound ones only)
         ImagenTrainer.locked = self.is_distributed
 
         self.imagen = imagen
@@ -937,34 +938,57 @@ class ImagenTrainer(nn.Module):
             f'you can only train unet #{self.only_train_unet_number}'
         total_loss = 0.
         reducer = self.unet_being_trained.reducer
+        arena = getattr(self, '_arena', None)
+        scaler = getattr(self, f'scaler{unet_number - 1}')
         for chunk_size_frac, (chunked_args, chunked_kwargs) in split_args_and_kwargs(*args, split_size=max_batch_size, **kwargs):
             self._micro_step += 1
             sync = self._is_sync_step()
-            with self._autocast():
-                out = self.imagen(*chunked_args, unet=self.unet_being_trained, unet_number=unet_number, **chunked_kwargs)
-            # Imagen.forward returns (loss, pred, x_noisy, lowres); ElucidatedImagen.forward a scalar loss (the reference
-            # trainer crashes on the latter, trainer.py:1119 — driving EDM is a superset feature here)
-            loss, pred, x_noisy, lowres_cond_img_noisy = out if isinstance(out, tuple) else (out, None, None, None)
-            loss = loss * chunk_size_frac
-            if self.training:
-                # like accelerate.accumulate: the loss is divided by the accumulation steps, DDP syncs on the boundary
-                if exists(reducer):
-                    reducer.prepare_backward(sync=sync)
-                arena = getattr(self, '_arena', None)
-                if arena is not None:
-                    arena.begin_backward()
-                scaler = getattr(self, f'scaler{unet_number - 1}')
-                if scaler.enabled:                      # accelerator.backward: scaler.scale(loss).backward(), fp16 kernels in the backward too
-                    ops.FP16_BACKWARD = True
+            # the loss scale of this micro-step (accelerator.backward: scaler.scale(loss).backward(); accumulate: / accumulation steps)
+            back_scale = (scaler.get_scale() if scaler.enabled else 1.0) / self.gradient_accumulation_steps
+
+            def device_work(core, tensors):
+                """Forward, loss, backward, gradients handed to the arena: device launches only (captured as one hipGraph when the step
+                is launch-bound, graphs.TrainStepGraphs)."""
+                with self._autocast():
+                    out = core(*tensors)
+                # Imagen.forward returns (loss, pred, x_noisy, lowres); ElucidatedImagen.forward a scalar loss (the reference
+                # trainer crashes on the latter, trainer.py:1119 — driving EDM is a superset feature here)
+                loss, pred, x_noisy, lowres = out if isinstance(out, tuple) else (out, None, None, None)
+                loss = loss * chunk_size_frac
+                if self.training:
+                    if arena is not None:
+                        arena.begin_backward()
+                    if scaler.enabled:                  # fp16 kernels in the backward too
+                        ops.FP16_BACKWARD = True
                     try:
-                        (loss / self.gradient_accumulation_steps * scaler.get_scale()).backward()
+                        (loss * back_scale).backward()
                     finally:
                         ops.FP16_BACKWARD = False
-                else:
-                    (loss / self.gradient_accumulation_steps).backward()
+                return loss, pred, x_noisy, lowres
+
+            if exists(reducer) and self.training:
+                reducer.prepare_backward(sync=sync)     # like accelerate.accumulate: DDP syncs on the boundary
+            # a captured micro-step holds no collective: with a live reducer only the accumulation steps in between go through the graph
+            graphable = (self.training and arena is not None and not self.is_elucidated and self.device.type == 'cuda'
+                         and not (exists(reducer) and reducer.active and sync))
+            if graphable:
+                core, tensors = self.imagen(*chunked_args, unet=self.unet_being_trained, unet_number=unet_number, deferred=True,
+                                            **chunked_kwargs)
+
+                def step(*ts):
+                    out = device_work(core, ts)
+                    arena.collect()
+                    return out
+                key = (unet_number, chunk_size_frac, back_scale, arena.grad.data_ptr(), arena.flat.data_ptr(),
+                       sum(1 for p in arena.params if p.requires_grad))
+                loss, pred, x_noisy, lowres_cond_img_noisy = self._train_graphs.run(key, step, tensors, arena.reinstall_grads)
+            else:
+                loss, pred, x_noisy, lowres_cond_img_noisy = device_work(
+                    lambda: self.imagen(*chunked_args, unet=self.unet_being_trained, unet_number=unet_number, **chunked_kwargs), ())
+            if self.training:
                 if exists(reducer):
                     reducer.finalize_backward()
-                if arena is not None:
+                if arena is not None and not graphable:
                     arena.collect()             # whatever no bucket launch has collected yet (all of it on non-sync steps)
                 self._sync_now = sync
                 self.update(unet_number=unet_number)

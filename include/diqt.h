@@ -570,6 +570,9 @@ int diqt_ssim3d(const float* pred, const float* target, int N, int D, int H, int
  * micro-step are added into the flat gradient arena in ONE launch.  table[t] = {src device pointer, dst element offset,
  * element count} (3 x int64, device memory); every tensor gets `blocks_per_tensor` workgroups.                    */
 int diqt_multi_accumulate(float* dst, const long long* table, int count, int blocks_per_tensor, void* stream);
+/* The same with the table in HOST memory: it travels in the kernel arguments (120 rows per launch), so there is no table upload and the
+ * launches can be captured into a hipGraph as they stand (the trainer's captured micro-step).                                   */
+int diqt_multi_accumulate_host(float* dst, const long long* host_table, int count, int blocks_per_tensor, void* stream);
 int diqt_ema_lerp(float* ema, const float* param, size_t n, float one_minus_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

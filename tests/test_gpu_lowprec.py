@@ -740,3 +740,46 @@ def test_low_precision_training_resnet_block_with_16_bit_tensor_and_gradient_bet
         tol = 3e-2 if k in ("block1.project.bias", "block2.project.bias") else 2 * ulp
         assert (a[k] - b[k]).abs().max().item() <= tol * b[k].abs().max().item() + 1e-6, (k, (a[k] - b[k]).abs().max())
         assert (a[k] - c2[k]).abs().max().item() <= tol * c2[k].abs().max().item() + 1e-6, (k, (a[k] - c2[k]).abs().max())
+
+
+@pytest.mark.parametrize("ignore_time", [False, True])
+def test_family_b_block_of_a_bf16_training_step_as_one_node_is_bit_identical(ignore_time):
+    """imagen_video.Block (GroupNorm -> SiLU -> per-frame conv -> temporal conv, imagen_video.py:671-697) in a bf16 training step: the
+    GroupNorm-apply + per-frame conv pair runs as one autograd node with a bf16 activation between the two (Conv3d.train_h), against
+    the two-node path (``ops._NO_TRAIN_FUSE``): same output, same gradients, bit for bit."""
+    from diffusioniqt_amd import ops, _lib
+    from diffusioniqt_amd.imagen_video import Block
+    torch.manual_seed(5)
+    B, Fr, S, C = 2, 8, 64, 64
+    blk = Block(C, C).to(DEV)
+    with torch.no_grad():
+        blk.project.temporal_conv.weight.add_(torch.randn_like(blk.project.temporal_conv.weight) * 0.05)   # not the identity it starts as
+    x0 = torch.randn(B, Fr, S, S, C, device=DEV)
+    ss0 = torch.randn(B, 2 * C, device=DEV) * 0.3
+    r0 = torch.randn(B, Fr, S, S, C, device=DEV)
+    dy = torch.randn(B, Fr, S, S, C, device=DEV)
+
+    def run(fused):
+        blk.zero_grad(set_to_none=True)
+        x, ss, r = (t.clone().requires_grad_(True) for t in (x0, ss0, r0))
+        old = ops._NO_TRAIN_FUSE
+        ops._NO_TRAIN_FUSE = not fused
+        try:
+            with ops.low_precision('bf16'), _lib.census() as c:
+                y, alias = blk(x * 1.0, scale_shift=ss, ignore_time=ignore_time, residual=r, emit_stats=True, tap=True)
+                ((y * dy).sum() + (alias * 0.5).sum()).backward()
+                torch.cuda.synchronize()
+                n9 = c.count("conv3d_fwd_h(v9h)")
+        finally:
+            ops._NO_TRAIN_FUSE = old
+        grads = [x.grad, ss.grad, r.grad] + [p.grad for p in blk.parameters()]
+        return y.detach(), grads, n9
+
+    ya, ga, na = run(True)
+    yb, gb, nb = run(False)
+    assert na >= 1 and nb == 0
+    assert torch.equal(ya, yb)
+    for a, b_ in zip(ga, gb):
+        if ignore_time and a is None and b_ is None:         # the temporal conv takes no part
+            continue
+        assert a is not None and b_ is not None and torch.equal(a, b_), (a - b_).abs().max()

@@ -1,0 +1,77 @@
+"""The captured training micro-step (graphs.TrainStepGraphs; the loop of /root/reference/trainer.py:1099-1128): forward + loss + backward +
+gradient hand-over replayed as one hipGraph must be the eager micro-step bit for bit -- same losses, same weights after every Adam step --
+including across optimiser steps (the packed 16-bit weight copies are re-derived inside the graph) and with an eager evaluation in between."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import iqt_oracle as O
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def run_trainer(graph_mode, precision, n_steps, max_grad_norm=None, sample_between=False):
+    from diffusioniqt_amd import graphs
+    from diffusioniqt_amd.imagen_pytorch3D import Imagen, NullUnet, SRUnet256
+    from diffusioniqt_amd.trainer import ImagenTrainer
+    gu = load_golden('unetA_tiny')
+    unet = SRUnet256(**json.loads(str(gu['kwargs'])))
+    unet.load_state_dict(O.hash_fill_state_dict(unet.state_dict(), 0))
+    configs = {'Data': {'norm': 'z-score'}, 'Train': {'batch_sample': False, 'patch_size_sub': 8, 'pred_obj': 'x_start'},
+               'Eval': {'repeat': 1}}
+    imagen = Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=float(gu['min_bound']), image_sizes=(8, 8), channels=1,
+                    pred_objectives='x_start', timesteps=4, dynamic_thresholding=False, p2_loss_weight_gamma=0.0, cond_drop_prob=0.0).to(DEV)
+    ImagenTrainer.locked = False
+    kw = {'fp16': True} if precision == 'fp16' else {'precision': precision} if precision else {}
+    trainer = ImagenTrainer(configs=configs, imagen=imagen, verbose=False, gradient_accumulation_steps=2, max_grad_norm=max_grad_norm, **kw)
+    old = graphs.TRAIN_ENABLED, graphs.TRAIN_FORCE
+    graphs.TRAIN_ENABLED, graphs.TRAIN_FORCE = graph_mode != 0, graph_mode == 2
+    try:
+        torch.manual_seed(11)
+        g = torch.Generator().manual_seed(3)
+        losses, preds = [], []
+        for i in range(n_steps):
+            hr, lr = torch.randn(2, 1, 8, 8, 8, generator=g), torch.randn(2, 1, 8, 8, 8, generator=g)
+            loss, pred, x_noisy, _ = trainer.forward(hr, lowres_img=lr, unet_number=2, max_batch_size=2)
+            losses.append(loss)
+            preds.append(pred.detach().clone())
+            if sample_between and i == n_steps // 2:
+                with torch.no_grad():                    # an eager evaluation between two replays: re-packs the weights on its own
+                    imagen.unets[1].eval()
+                    imagen.unets[1](hr.to(DEV), torch.zeros(2, device=DEV), lowres_cond_img=lr.to(DEV))
+                    imagen.unets[1].train()
+        replays = trainer._train_graphs.replays
+        errors = [e.get("error") for e in trainer._train_graphs.entries.values() if e.get("error")]
+        trainer._train_graphs.clear()
+    finally:
+        graphs.TRAIN_ENABLED, graphs.TRAIN_FORCE = old
+    return losses, preds, [p.detach().clone() for p in imagen.unets[1].parameters()], replays, errors
+
+
+@pytest.mark.parametrize("precision,mgn,between", [('bf16', None, False), (None, None, True), ('bf16', 0.5, True), ('fp16', None, False)])
+def test_captured_micro_step_is_the_eager_micro_step_bit_for_bit(precision, mgn, between):
+    n = 10
+    la, pa, wa, ra, ea = run_trainer(2, precision, n, mgn, between)
+    lb, pb, wb, rb, eb = run_trainer(0, precision, n, mgn, between)
+    assert not ea, ea
+    assert ra == n - 3 and rb == 0                       # three eager warm-up micro-steps, then the capture and replays
+    assert la == lb, (la, lb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    moved = 0
+    for a, b in zip(wa, wb):
+        assert torch.equal(a, b), (a - b).abs().max()
+        moved += 1
+    assert moved > 10 and all(np.isfinite(la))
+
+
+def test_gpu_bound_steps_stay_eager_and_the_switch_turns_capture_off():
+    from diffusioniqt_amd import graphs
+    assert graphs.TRAIN_ENABLED                          # the default
+    _, _, _, r0, _ = run_trainer(0, 'bf16', 6)
+    assert r0 == 0

@@ -580,6 +580,8 @@ def bench_c2(args, torch, dist, D, ops, device, world, rank, timed, instrumented
             dtb = timed(train_step, 4, kt)
             trainer.mixed_precision = 'no'
             result["train_bf16"] = dict(ms_per_step=1e3 * dtb / kt, patches_per_s=world * B * kt / dtb, steps=kt)
+        # which micro-steps ran as a captured hipGraph (graphs.TrainStepGraphs: only launch-bound ones are captured)
+        result["train"]["step_graphs"] = dict(replays=trainer._train_graphs.replays, keys=trainer._train_graphs.summary())
 
     # ---------------- BASELINE configs[3] and configs[4] beside the headline (single GPU): C4 evals and a SHORT C5 cascade ----------------
     if args.mode == "both" and extras and S == 32:

@@ -195,6 +195,11 @@ class TrainStepGraphs:
         except Exception:                                # noqa: BLE001 -- interpreter shutdown
             pass
 
+    def summary(self):
+        """[{captured, host_ms, gpu_ms, error}] per key seen (diagnostics: bench.py prints it beside the training lines)."""
+        return [dict(captured=e["graph"] is not None, calls=e["calls"], host_ms=round(e.get("host_ms", 0.0), 3), gpu_ms=round(e.get("gpu_ms", 0.0), 3),
+                     **({"error": e["error"]} if e.get("error") else {})) for e in self.entries.values()]
+
     def run(self, key, fn, tensors, recover):
         """``fn(*tensors)`` (tensors: device tensors or None) -> tuple of tensors / None.  ``recover()`` restores the host-side state a
         failed capture left half-changed (nothing has run on the GPU then)."""

@@ -979,7 +979,7 @@ class ImagenTrainer(nn.Module):
                     out = device_work(core, ts)
                     arena.collect()
                     return out
-                key = (unet_number, chunk_size_frac, back_scale, arena.grad.data_ptr(), arena.flat.data_ptr(),
+                key = (unet_number, self.mixed_precision, chunk_size_frac, back_scale, arena.grad.data_ptr(), arena.flat.data_ptr(),
                        sum(1 for p in arena.params if p.requires_grad))
                 loss, pred, x_noisy, lowres_cond_img_noisy = self._train_graphs.run(key, step, tensors, arena.reinstall_grads)
             else:

@@ -200,9 +200,10 @@ class TrainStepGraphs:
         return [dict(captured=e["graph"] is not None, calls=e["calls"], host_ms=round(e.get("host_ms", 0.0), 3), gpu_ms=round(e.get("gpu_ms", 0.0), 3),
                      **({"error": e["error"]} if e.get("error") else {})) for e in self.entries.values()]
 
-    def run(self, key, fn, tensors, recover):
+    def run(self, key, fn, tensors, recover, stream=None):
         """``fn(*tensors)`` (tensors: device tensors or None) -> tuple of tensors / None.  ``recover()`` restores the host-side state a
-        failed capture left half-changed (nothing has run on the GPU then)."""
+        failed capture left half-changed (nothing has run on the GPU then).  ``stream``: the (non-default) stream the steps run on -- the
+        capture happens on it as well, so autograd nodes bound to it stay inside the capture."""
         if not TRAIN_ENABLED or ops.TIMER.enabled:
             return fn(*tensors)
         key = key + (_sig(tensors), ops.lp_mode(), _lib.SWITCH_EPOCH)
@@ -238,7 +239,7 @@ class TrainStepGraphs:
                 ops.bump_weight_epoch()                  # every weight-derived host cache misses: its launch becomes part of the graph
                 g = torch.cuda.CUDAGraph()
                 ops.capture_begins()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, stream=stream):
                     out = fn(*static)
                 ent.update(graph=g, static=static, out=out)
                 ops.graphs_alive(+1)

@@ -936,6 +936,31 @@ class ImagenTrainer(nn.Module):
         self.max_batch_size = max_batch_size
         assert not exists(self.only_train_unet_number) or self.only_train_unet_number == unet_number, \
             f'you can only train unet #{self.only_train_unet_number}'
+        if not (self.training and self.device.type == 'cuda' and getattr(self, '_arena', None) is not None):
+            return self._forward_chunks(args, kwargs, unet_number, max_batch_size, None)
+        # Training steps run on the trainer's own stream, fenced against the caller's on both sides.  autograd's AccumulateGrad nodes
+        # remember the stream they were created on and run THERE; a node that outlives its iteration (anything holding a tensor of an
+        # old graph does that) would pull the null stream into the capture of a micro-step (graphs.TrainStepGraphs captures on this very
+        # stream) -- an un-joined fork that ends the capture in the runtime, not in an exception.  So the nodes are created once, on this
+        # stream, and kept (as DDP keeps them).
+        ts = self._train_stream = getattr(self, '_train_stream', None) or torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        ts.wait_stream(cur)
+        try:
+            with torch.cuda.stream(ts):
+                if getattr(self, '_acc_nodes_of', None) is not self._arena:
+                    with torch.enable_grad():
+                        self._acc_nodes = [p.view_as(p).grad_fn.next_functions[0][0] for p in self._arena.params if p.requires_grad]
+                    self._acc_nodes_of = self._arena
+                out = self._forward_chunks(args, kwargs, unet_number, max_batch_size, ts)
+        finally:
+            cur.wait_stream(ts)
+        for t in out[1:]:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(cur)                    # allocated on the training stream, read by the caller on its own
+        return out
+
+    def _forward_chunks(self, args, kwargs, unet_number, max_batch_size, stream):
         total_loss = 0.
         reducer = self.unet_being_trained.reducer
         arena = getattr(self, '_arena', None)
@@ -964,7 +989,10 @@ class ImagenTrainer(nn.Module):
                         (loss * back_scale).backward()
                     finally:
                         ops.FP16_BACKWARD = False
-                return loss, pred, x_noisy, lowres
+                # handed back without their graph (the reference's are attached to a graph backward() has already freed): a caller
+                # keeping `pred` would otherwise keep every node of this micro-step -- and its AccumulateGrad nodes -- alive
+                det = lambda t: t.detach() if torch.is_tensor(t) else t
+                return loss.detach(), det(pred), det(x_noisy), det(lowres)
 
             if exists(reducer) and self.training:
                 reducer.prepare_backward(sync=sync)     # like accelerate.accumulate: DDP syncs on the boundary
@@ -981,7 +1009,7 @@ class ImagenTrainer(nn.Module):
                     return out
                 key = (unet_number, self.mixed_precision, chunk_size_frac, back_scale, arena.grad.data_ptr(), arena.flat.data_ptr(),
                        sum(1 for p in arena.params if p.requires_grad))
-                loss, pred, x_noisy, lowres_cond_img_noisy = self._train_graphs.run(key, step, tensors, arena.reinstall_grads)
+                loss, pred, x_noisy, lowres_cond_img_noisy = self._train_graphs.run(key, step, tensors, arena.reinstall_grads, stream)
             else:
                 loss, pred, x_noisy, lowres_cond_img_noisy = device_work(
                     lambda: self.imagen(*chunked_args, unet=self.unet_being_trained, unet_number=unet_number, **chunked_kwargs), ())

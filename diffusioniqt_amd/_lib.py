@@ -51,7 +51,7 @@ PROTOTYPES = {
     "diqt_conv3d_fwd_gn_supported": (I, [I] * 16),
     "diqt_conv3d_fwd_gn": (I, [P, P, P, P, P, P, P, Z, P, I] + [I] * 15 + [P]),
     "diqt_gn_act_bwd_ex": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
-    "diqt_gn_act_bwd_h": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P]),
+    "diqt_gn_act_bwd_h": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, I, P]),
     "diqt_chan_layernorm_bwd_ex": (I, [P, P, P, P, P, P, P, P, P, P, Z, I, I, P]),
     "diqt_gn_act_bwd_from_partials": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "diqt_conv3d_fwd_gnbwd_blocks": (I, [I] * 15),

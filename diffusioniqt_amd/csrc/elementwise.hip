@@ -400,6 +400,7 @@ struct GnBwdF {
     GnCoef k;
     int act;
     int xty = 0;                           // x holds fp32 (0), fp16 (1) or bf16 (2) values (the 16-bit block output of a low-precision training step)
+    int dyty = 0;                          // ... and so does dy (the 16-bit output of the backward-data conv in front of this pass)
     __device__ __forceinline__ void one(float xv, float dyv, int b, int c, float& s1, float& s2) const {
         float A, Bc;
         k.get(b, c, A, Bc);
@@ -424,7 +425,7 @@ struct GnBwdF {
     }
     __device__ void vec4(size_t i, int, int, float (&o)[2][4]) const {
         const float4 xv = ld4_any(x, i, xty);
-        const float4 dv = *reinterpret_cast<const float4*>(dy + i);
+        const float4 dv = ld4_any(dy, i, dyty);
         onej(xv.x, dv.x, 0, o[0][0], o[1][0]);
         onej(xv.y, dv.y, 1, o[0][1], o[1][1]);
         onej(xv.z, dv.z, 2, o[0][2], o[1][2]);
@@ -477,14 +478,14 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ dx, GnCoef k,
                                                             const float* __restrict__ m12, int rows, int act,
-                                                            const float* __restrict__ add, int xty = 0, int dxty = 0) {
-    // xty / dxty (VEC only): x read / dx written as fp32 (0), fp16 (1) or bf16 (2) values
+                                                            const float* __restrict__ add, int xty = 0, int dxty = 0, int dyty = 0) {
+    // xty / dxty / dyty (VEC only): x, dy read / dx written as fp32 (0), fp16 (1) or bf16 (2) values
     // add (optional, kernel-uniform): the gradient that reaches x through its OTHER consumer (the residual branch of a ResnetBlock),
     // summed here instead of in a separate pass over three tensors
     const int b = blockIdx.y, C = k.C, G = k.G, Cg = C / G;
     const size_t per = (size_t)rows * C;
     const float* xb = xty ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(x) + (size_t)b * per) : x + (size_t)b * per;
-    const float* dyb = dy + (size_t)b * per;
+    const float* dyb = dyty ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(dy) + (size_t)b * per) : dy + (size_t)b * per;
     const float* adb = add ? add + (size_t)b * per : nullptr;
     float* dxb = dxty ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(dx) + (size_t)b * per) : dx + (size_t)b * per;
     auto one = [&](float xv, float dyv, int c) -> float {
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 xv[u] = ld4_any(xb, (i + u * st) * 4, xty);
-                dv[u] = *reinterpret_cast<const float4*>(dyb + (i + u * st) * 4);
+                dv[u] = ld4_any(dyb, (i + u * st) * 4, dyty);
                 av[u] = adb ? *reinterpret_cast<const float4*>(adb + (i + u * st) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256) void gn_act_bwd_dx_kernel(const float* __restr
         }
         for (; i < n4; i += st) {
             const float4 xv = ld4_any(xb, i * 4, xty);
-            const float4 dv = *reinterpret_cast<const float4*>(dyb + i * 4);
+            const float4 dv = ld4_any(dyb, i * 4, dyty);
             const float4 av = adb ? *reinterpret_cast<const float4*>(adb + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 o;
             o.x = onej(xv.x, dv.x, 0) + av.x; o.y = onej(xv.y, dv.y, 1) + av.y;
@@ -2075,9 +2076,10 @@ static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
                            const float* gamma, const float* beta, const float* scale, const float* shift,
                            int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
                            size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream, const float* ext_partials,
-                           int ext_nblk, const float* dx_add = nullptr, int xty = 0, int dxty = 0) {
+                           int ext_nblk, const float* dx_add = nullptr, int xty = 0, int dxty = 0, int dyty = 0) {
     DIQT_REQUIRE(x && dy && mean && rstd && dx && workspace, DIQT_E_ALIGN, "gn_act_bwd: null pointer");
-    DIQT_REQUIRE(xty >= 0 && xty <= 2 && dxty >= 0 && dxty <= 2, DIQT_E_SHAPE, "gn_act_bwd: x / dx type is 0 (fp32), 1 (fp16) or 2 (bf16)");
+    DIQT_REQUIRE(xty >= 0 && xty <= 2 && dxty >= 0 && dxty <= 2 && dyty >= 0 && dyty <= 2, DIQT_E_SHAPE,
+                 "gn_act_bwd: x / dx / dy type is 0 (fp32), 1 (fp16) or 2 (bf16)");
     DIQT_REQUIRE(B > 0 && rows > 0 && C > 0 && G > 0 && C % G == 0, DIQT_E_SHAPE, "gn_act_bwd: bad shape");
     DIQT_REQUIRE(workspace_bytes >= diqt_reduce_workspace_bytes(B, C), DIQT_E_WORKSPACE, "gn_act_bwd: workspace too small");
     DIQT_REQUIRE(aligned16(workspace), DIQT_E_ALIGN, "gn_act_bwd: misaligned workspace");
@@ -2089,9 +2091,11 @@ static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
     float* m12 = S + (size_t)2 * B * C;
     const size_t per = (size_t)rows * C;
     const bool vec = vec_ok(x, dy, dx, per, C) && (!dx_add || aligned16(dx_add));
-    DIQT_REQUIRE(vec || (xty == 0 && dxty == 0), DIQT_E_UNSUPPORTED, "gn_act_bwd: 16-bit x / dx need C %% 4 == 0 and 16-byte aligned tensors");
+    DIQT_REQUIRE(vec || (xty == 0 && dxty == 0 && dyty == 0), DIQT_E_UNSUPPORTED,
+                 "gn_act_bwd: 16-bit x / dx / dy need C %% 4 == 0 and 16-byte aligned tensors");
     GnBwdF f{x, dy, k, act};
     f.xty = xty;
+    f.dyty = dyty;
     int rc = DIQT_OK;
     if (ext_partials) {
         DIQT_REQUIRE(ext_nblk > 0, DIQT_E_SHAPE, "gn_act_bwd_from_partials: nblk");
@@ -2112,7 +2116,7 @@ static int gn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
     rc = check_launch("gn_act_bwd/final");
     if (rc) return rc;
     const dim3 grid(gn_grid(per, C, B), B);
-    if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act, dx_add, xty, dxty);
+    if (vec) hipLaunchKernelGGL(gn_act_bwd_dx_kernel<true>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act, dx_add, xty, dxty, dyty);
     else hipLaunchKernelGGL(gn_act_bwd_dx_kernel<false>, grid, dim3(256), 0, STREAM, x, dy, dx, k, m12, rows, act, dx_add);
     return check_launch("gn_act_bwd/dx");
 }
@@ -2148,12 +2152,14 @@ extern "C" int diqt_gn_act_bwd_ex(const float* x, const float* dy, const float* 
 // The same with x read and / or dx written in a 16-bit type (x_type, dx_type: 0 fp32, 1 fp16, 2 bf16): a low-precision training step
 // keeps a ResnetBlock's block1 output -- a conv result, rounded to the operand type by autocast anyway -- in that type, and the gradient
 // that flows back into it is only ever read by 16-bit-operand conv kernels (backward-data, weight gradient), which would round it too.
-extern "C" int diqt_gn_act_bwd_h(const void* x, const float* dy, const float* partials, int nblk, const float* dx_add, const float* mean,
+extern "C" int diqt_gn_act_bwd_h(const void* x, const void* dy, const float* partials, int nblk, const float* dx_add, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
                                  int cond_stride, void* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
-                                 size_t workspace_bytes, int B, int rows, int C, int G, int act, int x_type, int dx_type, void* stream) {
-    return gn_act_bwd_impl(static_cast<const float*>(x), dy, mean, rstd, gamma, beta, scale, shift, cond_stride, static_cast<float*>(dx), dgamma,
-                           dbeta, dscale, dshift, workspace, workspace_bytes, B, rows, C, G, act, stream, partials, nblk, dx_add, x_type, dx_type);
+                                 size_t workspace_bytes, int B, int rows, int C, int G, int act, int x_type, int dx_type, int dy_type,
+                                 void* stream) {
+    return gn_act_bwd_impl(static_cast<const float*>(x), static_cast<const float*>(dy), mean, rstd, gamma, beta, scale, shift, cond_stride,
+                           static_cast<float*>(dx), dgamma, dbeta, dscale, dshift, workspace, workspace_bytes, B, rows, C, G, act, stream, partials,
+                           nblk, dx_add, x_type, dx_type, dy_type);
 }
 
 extern "C" int diqt_chan_layernorm_fwd_res(const float* x, const float* g, const float* b, const float* residual, float* y,

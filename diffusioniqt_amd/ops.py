@@ -930,6 +930,7 @@ def _lp_backward(lp):
 
 _NO_TRAIN_FUSE = os.environ.get("DIQT_NO_TRAIN_FUSE") == "1"      # A/B switch: bf16 training Blocks as two autograd nodes
 _NO_TRAIN_HALF = os.environ.get("DIQT_NO_TRAIN_HALF") == "1"      # A/B switch: fp32 tensor (and gradient) between block1 and block2
+_NO_DACT_HALF = os.environ.get("DIQT_NO_DACT_HALF") == "1"      # A/B: the backward-data output in front of a GroupNorm backward stays fp32
 
 
 class _GnActConvHFn(Function):
@@ -992,7 +993,11 @@ class _GnActConvHFn(Function):
         pd, ph, pw = pad
         bpad = (kd - 1 - pd, kh - 1 - ph, kw - 1 - pw)
         # ---- conv: dX on the 16-bit MFMA kernel (flipped weights; conv_f9h_kernel when dY is 16-bit), dW / db with the 16-bit activation ----
-        dact = _conv_fwd_half(dy, weight, None, None, bpad, (0, 0, 0), ctx.lp, mode=1, x_half=y_half)
+        # the gradient w.r.t. the activated tensor only feeds the GroupNorm backward's two passes: in the operand type when the 16-bit
+        # kernel writes it (what autocast's conv backward returns anyway) -- half the bytes written here and read twice there
+        dact_half = bool(y_half and not _NO_TRAIN_HALF and not _NO_DACT_HALF and Cin % 8 == 0
+                         and _lib.query("diqt_conv3d_fwd_h_io16_supported", B, D, H, W, Cout, Cin, kd, kh, kw, *bpad, 0, 0, 0, 1, 1))
+        dact = _conv_fwd_half(dy, weight, None, None, bpad, (0, 0, 0), ctx.lp, mode=1, x_half=y_half, y_half=dact_half)
         if dact is None:
             assert not y_half
             dact = _conv_fwd_raw(dy, _packed(weight, 1), None, None, Cin, (kd, kh, kw), bpad, (0, 0, 0))
@@ -1026,10 +1031,11 @@ class _GnActConvHFn(Function):
             scale, shift = ss.data_ptr(), ss.data_ptr() + 4 * C
             dscale, dshift = dss.data_ptr(), dss.data_ptr() + 4 * C
         ws, n = _reduce_ws(B, C, x.device)
-        if x_half:
+        if x_half or dact_half:
             ty = 2 if ctx.lp == 1 else 1
+            xt = ty if x_half else 0
             _lib.call("diqt_gn_act_bwd_h", x, dact, None, 0, dtap, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
-                      dscale, dshift, ws, n, B, rows, C, groups, act, ty, ty, _stream())
+                      dscale, dshift, ws, n, B, rows, C, groups, act, xt, xt, ty if dact_half else 0, _stream())
         else:
             _lib.call("diqt_gn_act_bwd_ex", x, dact, None, 0, dtap, mean, rstd, gamma, beta, scale, shift, cs, dx, dgamma, dbeta,
                       dscale, dshift, ws, n, B, rows, C, groups, act, _stream())

@@ -302,12 +302,13 @@ int diqt_gn_act_bwd_ex(const float* x, const float* dy, const float* partials, i
                        const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift,
                        int cond_stride, float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,
                        size_t workspace_bytes, int B, int rows, int C, int G, int act, void* stream);
-/* diqt_gn_act_bwd_ex with x read and / or dx written in a 16-bit type (x_type, dx_type: 0 fp32, 1 fp16, 2 bf16): the block1 output of a
- * ResnetBlock and the gradient flowing back into it during a low-precision training step (both only meet 16-bit-operand kernels). */
-int diqt_gn_act_bwd_h(const void* x, const float* dy, const float* partials, int nblk, const float* dx_add, const float* mean,
+/* diqt_gn_act_bwd_ex with x / dy read and / or dx written in a 16-bit type (x_type, dx_type, dy_type: 0 fp32, 1 fp16, 2 bf16): the block1
+ * output of a ResnetBlock and the gradient flowing back into it during a low-precision training step (both only meet 16-bit-operand
+ * kernels); dy: the output of the backward-data conv in front of this pass, which autocast's backward holds in the operand type. */
+int diqt_gn_act_bwd_h(const void* x, const void* dy, const float* partials, int nblk, const float* dx_add, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, const float* scale, const float* shift, int cond_stride,
                       void* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace, size_t workspace_bytes, int B,
-                      int rows, int C, int G, int act, int x_type, int dx_type, void* stream);
+                      int rows, int C, int G, int act, int x_type, int dx_type, int dy_type, void* stream);
 int diqt_gn_act_bwd_from_partials(const float* x, const float* dy, const float* partials, int nblk, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, const float* scale, const float* shift, int cond_stride,
                                   float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, void* workspace,

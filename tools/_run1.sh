@@ -1,3 +1,6 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1150 python -X faulthandler -m pytest tests -x -q -m gpu > gpurun_out/t48_gpu_suite.log 2>&1; echo "pytest rc=$?"; tail -8 gpurun_out/t48_gpu_suite.log
+for i in 1 2; do
+timeout -k 10 300 python tools/train_bf16_only.py 32 > gpurun_out/t50_a$i.log 2>&1; echo "half rc=$?"; tail -1 gpurun_out/t50_a$i.log
+DIQT_NO_DACT_HALF=1 timeout -k 10 300 python tools/train_bf16_only.py 32 > gpurun_out/t50_b$i.log 2>&1; echo "fp32 dact rc=$?"; tail -1 gpurun_out/t50_b$i.log
+done

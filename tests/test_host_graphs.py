@@ -74,3 +74,46 @@ def test_a_weight_update_drops_every_captured_graph():
     e = ops._WEIGHT_EPOCH
     ops.bump_weight_epoch()                                                      # nothing alive: just the counter
     assert ops._WEIGHT_EPOCH == e + 1
+
+
+def test_tensors_born_after_the_newest_capture_are_not_pinned():
+    """With a captured TRAINING step alive for a whole run, every validation / sampling pass in between re-packs the weights; those copies
+    were created after the newest capture began -- no graph can address them (or they live in that graph's own pool) -- and must not pile
+    up in ops._GRAPH_PINS; a copy made BEFORE a capture may be addressed by it and stays pinned."""
+    from diffusioniqt_amd import ops
+    ops.graphs_alive(-10 ** 6)
+    old = ops.born(torch.zeros(3))                   # cached before the capture: the graph may hold its address
+    ops.capture_begins()
+    ops.graphs_alive(+1)
+    new = ops.born(torch.zeros(4))                   # cached after it
+    ops.retire(new)
+    assert not ops._GRAPH_PINS
+    ops.retire(old)
+    assert [t.numel() for t in ops._GRAPH_PINS] == [3]
+    ops.capture_begins()                             # a later capture (a sampling graph) may address `new` after all
+    ops.retire(new)
+    assert [t.numel() for t in ops._GRAPH_PINS] == [3, 4]
+    ops.graphs_alive(-1)
+    assert not ops._GRAPH_PINS
+
+
+def test_train_step_graphs_stay_eager_when_switched_off_or_timed():
+    """graphs.TrainStepGraphs: with the switch off (or the kernel timer on) the micro-step function is simply called."""
+    from diffusioniqt_amd import ops
+    g = graphs.TrainStepGraphs()
+    calls = []
+    fn = lambda a, b: (calls.append(1), (a + 1, None))[1]
+    old = graphs.TRAIN_ENABLED
+    graphs.TRAIN_ENABLED = False
+    try:
+        for _ in range(6):
+            out = g.run(("k",), fn, (torch.zeros(2), None), lambda: None)
+    finally:
+        graphs.TRAIN_ENABLED = old
+    assert len(calls) == 6 and g.replays == 0 and not g.entries and torch.equal(out[0], torch.ones(2))
+    ops.TIMER.enabled = True
+    try:
+        g.run(("k",), fn, (torch.zeros(2), None), lambda: None)
+    finally:
+        ops.TIMER.enabled = False
+    assert len(calls) == 7 and not g.entries and g.summary() == []

@@ -34,6 +34,7 @@ echo "done sq"
 # C4 eval kernel stats; HBM traffic (two passes each) of the C4 eval, of one C5 stage-2 eval under autocast and of the Family-B eval
 stats c4_eval python3 $R/bench.py --config C4 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timer
 stats sample_autocast python3 $R/tools/autocast_bench.py
+stats train_bf16 python3 $R/tools/train_bf16_only.py 16
 traffic() {  # tag, command...
   local t=$1; shift
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmcf_$t -- "$@" > $OUT/pmc_fetch_$t.log 2>&1

@@ -1366,6 +1366,8 @@ class Imagen(nn.Module):
 
         tensors = (x_start, noise, alpha.to(device), sigma.to(device), (-sigma).to(device) if pred_objective == 'v' else None,
                    log_snr.to(device), lowres_cond_img, cond_images, weight)
+        # everything else `core` depends on by value: part of the key of a captured micro-step
+        core.static_key = (pred_objective, loss_type, min_bound, drop, bool(inner.training), id(inner))
         return (core, tensors) if deferred else core(*tensors)
 
     def forward(self, images, lowres_img=None, unet=None, text_embeds=None, text_masks=None, unet_number=None,

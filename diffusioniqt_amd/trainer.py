@@ -1008,7 +1008,7 @@ class ImagenTrainer(nn.Module):
                     arena.collect()
                     return out
                 key = (unet_number, self.mixed_precision, chunk_size_frac, back_scale, arena.grad.data_ptr(), arena.flat.data_ptr(),
-                       sum(1 for p in arena.params if p.requires_grad))
+                       sum(1 for p in arena.params if p.requires_grad), core.static_key)
                 loss, pred, x_noisy, lowres_cond_img_noisy = self._train_graphs.run(key, step, tensors, arena.reinstall_grads, stream)
             else:
                 loss, pred, x_noisy, lowres_cond_img_noisy = device_work(

@@ -168,6 +168,7 @@ PROTOTYPES = {
     "diqt_cast_to_h": (I, [P, P, Z, I, P]),
     "diqt_conv_packed_h_elems": (Z, [I, I, I, I, I]),
     "diqt_conv_pack_weight_h": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "diqt_conv_pack_weight_h_multi": (I, [P, I, I, P]),
     "diqt_conv3d_fwd_h_supported": (I, [I] * 15),
     "diqt_conv3d_fwd_h": (I, [P, P, P, P, P] + [I] * 17 + [P]),
 }

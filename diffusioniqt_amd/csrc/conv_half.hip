@@ -105,6 +105,35 @@ __global__ void conv_pack_weight_h_kernel(const float* __restrict__ w, unsigned 
     }
 }
 
+// the same for a whole set of weights in ONE launch (blockIdx.y = weight; the table travels in the kernel arguments): a captured training
+// micro-step re-derives every packed copy on each replay -- 86 launches of 4.8 us for the C2 U-Net as single packs
+constexpr int PK_ROWS = 64;
+struct PackRow { const float* w; unsigned short* packed; int Cout, Cin, T, mode, CoutPad; unsigned total; };
+struct PackTable { PackRow r[PK_ROWS]; };
+static_assert(sizeof(PackTable) + 16 <= 4096, "kernel arguments are limited to 4 KiB");
+template <bool BF>
+__global__ __launch_bounds__(256) void conv_pack_weight_h_multi_kernel(const PackTable t) {
+    const PackRow& e = t.r[blockIdx.y];
+    const float* __restrict__ w = e.w;
+    unsigned short* __restrict__ packed = e.packed;
+    const int Cout = e.Cout, Cin = e.Cin, T = e.T, mode = e.mode, CoutPad = e.CoutPad;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < e.total; i += gridDim.x * 256u) {
+        const int k = (int)(i % HCK);
+        unsigned r = i / HCK;
+        const int o = (int)(r % CoutPad);
+        r /= CoutPad;
+        const int tap = (int)(r % T);
+        const int in = (int)(r / T) * HCK + k;
+        float v = 0.f;
+        if (mode == 0) {
+            if (o < Cout && in < Cin) v = w[((size_t)o * Cin + in) * T + tap];
+        } else {
+            if (o < Cin && in < Cout) v = w[((size_t)in * Cin + o) * T + (T - 1 - tap)];
+        }
+        packed[i] = (unsigned short)(pack2<BF>(v, 0.f) & 0xffffu);
+    }
+}
+
 template <bool BF, bool PREF>
 __global__ __launch_bounds__(512, 1) void conv_fwd_h_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
                                                              const float* __restrict__ bias, const float* __restrict__ residual,
@@ -929,6 +958,34 @@ extern "C" int diqt_conv_pack_weight_h(const float* w, void* packed, int Cout, i
     hipLaunchKernelGGL(k, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, static_cast<unsigned short*>(packed), Cout,
                        Cin, T, mode, CoutPad, total);
     return check_launch("conv_pack_weight_h");
+}
+
+// host_table: rows of 8 x int64 {w (device pointer), packed (device pointer), Cout, Cin, kd, kh, kw, mode}; the same results as `count`
+// calls of diqt_conv_pack_weight_h
+extern "C" int diqt_conv_pack_weight_h_multi(const long long* host_table, int count, int bf16, void* stream) {
+    DIQT_REQUIRE(host_table && count >= 0, DIQT_E_ALIGN, "conv_pack_weight_h_multi: null table");
+    for (int lo = 0; lo < count; lo += PK_ROWS) {
+        const int m = count - lo < PK_ROWS ? count - lo : PK_ROWS;
+        PackTable t;
+        for (int i = 0; i < PK_ROWS; ++i) {
+            const long long* e = host_table + 8 * (size_t)(lo + (i < m ? i : 0));
+            const int Cout = (int)e[2], Cin = (int)e[3], kd = (int)e[4], kh = (int)e[5], kw = (int)e[6], mode = (int)e[7];
+            DIQT_REQUIRE(e[0] && e[1], DIQT_E_ALIGN, "conv_pack_weight_h_multi: null pointer in row %d", lo + i);
+            DIQT_REQUIRE(Cout > 0 && Cin > 0 && kd > 0 && kh > 0 && kw > 0 && (mode == 0 || mode == 1), DIQT_E_SHAPE,
+                         "conv_pack_weight_h_multi: bad shape/mode in row %d", lo + i);
+            const int T = kd * kh * kw, outEff = mode == 0 ? Cout : Cin, inEff = mode == 0 ? Cin : Cout;
+            const int CoutPad = hcdiv(outEff, HNT) * HNT;
+            const size_t total = (size_t)hcdiv(inEff, HCK) * T * CoutPad * HCK;
+            DIQT_REQUIRE(total < (1ull << 31), DIQT_E_SHAPE, "conv_pack_weight_h_multi: weight too large in row %d", lo + i);
+            t.r[i] = PackRow{reinterpret_cast<const float*>(e[0]), reinterpret_cast<unsigned short*>(e[1]), Cout, Cin, T, mode, CoutPad,
+                             (unsigned)total};
+        }
+        auto k = bf16 ? conv_pack_weight_h_multi_kernel<true> : conv_pack_weight_h_multi_kernel<false>;
+        hipLaunchKernelGGL(k, dim3(128, m), dim3(256), 0, (hipStream_t)stream, t);     // 128 workgroups per weight: the largest (256 x 256 x 27) sets the pace
+        const int rc = check_launch("conv_pack_weight_h_multi");
+        if (rc != DIQT_OK) return rc;
+    }
+    return DIQT_OK;
 }
 
 // 1 when diqt_conv3d_fwd_h takes this shape (Cin % 4 == 0, tensors < 1 GiB, halo tile within the LDS), else 0: the caller then

@@ -200,10 +200,11 @@ class TrainStepGraphs:
         return [dict(captured=e["graph"] is not None, calls=e["calls"], host_ms=round(e.get("host_ms", 0.0), 3), gpu_ms=round(e.get("gpu_ms", 0.0), 3),
                      **({"error": e["error"]} if e.get("error") else {})) for e in self.entries.values()]
 
-    def run(self, key, fn, tensors, recover, stream=None):
+    def run(self, key, fn, tensors, recover, stream=None, prepare=None):
         """``fn(*tensors)`` (tensors: device tensors or None) -> tuple of tensors / None.  ``recover()`` restores the host-side state a
         failed capture left half-changed (nothing has run on the GPU then).  ``stream``: the (non-default) stream the steps run on -- the
-        capture happens on it as well, so autograd nodes bound to it stay inside the capture."""
+        capture happens on it as well, so autograd nodes bound to it stay inside the capture.  ``prepare()``: launches to capture in front of
+        the step (the trainer re-derives all packed weights there with one multi-weight launch)."""
         if not TRAIN_ENABLED or ops.TIMER.enabled:
             return fn(*tensors)
         key = key + (_sig(tensors), ops.lp_mode(), _lib.SWITCH_EPOCH)
@@ -239,7 +240,11 @@ class TrainStepGraphs:
                 ops.bump_weight_epoch()                  # every weight-derived host cache misses: its launch becomes part of the graph
                 g = torch.cuda.CUDAGraph()
                 ops.capture_begins()
-                with torch.cuda.graph(g, stream=stream):
+                # thread_local: a capture lasts tens of milliseconds in the middle of a training run -- other threads of the process (a
+                # DataLoader's pin-memory thread allocating host memory, RCCL's watchdog) must not be refused their runtime calls meanwhile
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                    if prepare is not None:
+                        prepare()
                     out = fn(*static)
                 ent.update(graph=g, static=static, out=out)
                 ops.graphs_alive(+1)

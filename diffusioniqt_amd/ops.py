@@ -236,8 +236,36 @@ def _packed_h(weight5, bf16, mode=0):
     _lib.call("diqt_conv_pack_weight_h", weight5.detach(), packed, Cout, Cin, kd, kh, kw, mode, bf16, _stream())
     if hit is not None:
         retire(hit[1])
-    cache[slot] = (key, born(packed))
+    cache[slot] = (key, born(packed), weight5.detach())   # (a graph-free alias of) the weight: repack_cached_h re-derives the copy from it
     return packed
+
+
+def repack_cached_h(module, bf16):
+    """Re-derives every cached 16-bit packed copy (``_packed_h``) of ``module``'s weights for operand type ``bf16`` in ONE launch per 64
+    weights (``diqt_conv_pack_weight_h_multi``) into fresh tensors keyed on the current weight epoch.  graphs.TrainStepGraphs calls it as the
+    first thing inside the capture of a training micro-step: a replay then refreshes all packed weights with one or two launches instead
+    of one per conv and direction (86 for the C2 U-Net).  Returns the number of copies re-derived."""
+    rows, keep = [], []
+    for p in module.parameters():
+        cache = getattr(p, "_diqt_pack", None)
+        if not cache or not p.is_cuda:
+            continue
+        for slot, ent in list(cache.items()):
+            if not (isinstance(slot, tuple) and slot[0] == 'h' and slot[1] == bf16 and len(ent) == 3):
+                continue
+            w5 = ent[2]
+            if w5.data_ptr() != ent[0][1] or not w5.is_contiguous() or w5.dtype != torch.float32:
+                continue                                  # the parameter moved: the lazy path repacks it
+            mode = slot[2]
+            packed = torch.empty(ent[1].numel(), dtype=torch.int16, device=w5.device)
+            Cout, Cin, kd, kh, kw = w5.shape
+            rows.append((w5.data_ptr(), packed.data_ptr(), Cout, Cin, kd, kh, kw, mode))
+            retire(ent[1])
+            cache[slot] = ((slot, w5.data_ptr(), w5._version, _WEIGHT_EPOCH), born(packed), w5)
+            keep.append(packed)
+    if rows:
+        _lib.call("diqt_conv_pack_weight_h_multi", torch.tensor(rows, dtype=torch.int64), len(rows), int(bf16), _stream())
+    return len(rows)
 
 
 def _conv_fwd_half(x5, weight, bias, residual, pad, epad, bf16, mode=0, x_half=False, y_half=False, stats_out=None):

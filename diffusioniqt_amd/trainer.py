@@ -1009,7 +1009,10 @@ class ImagenTrainer(nn.Module):
                     return out
                 key = (unet_number, self.mixed_precision, chunk_size_frac, back_scale, arena.grad.data_ptr(), arena.flat.data_ptr(),
                        sum(1 for p in arena.params if p.requires_grad), core.static_key)
-                loss, pred, x_noisy, lowres_cond_img_noisy = self._train_graphs.run(key, step, tensors, arena.reinstall_grads, stream)
+                loss, pred, x_noisy, lowres_cond_img_noisy = self._train_graphs.run(
+                    key, step, tensors, arena.reinstall_grads, stream,
+                    prepare=(lambda: ops.repack_cached_h(self.unet_being_trained.module, 1 if self.mixed_precision == 'bf16' else 0))
+                    if self.mixed_precision != 'no' else None)
             else:
                 loss, pred, x_noisy, lowres_cond_img_noisy = device_work(
                     lambda: self.imagen(*chunked_args, unet=self.unet_being_trained, unet_number=unet_number, **chunked_kwargs), ())

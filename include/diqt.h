@@ -92,7 +92,10 @@ int diqt_conv3d_fwd(const float* x, const float* packed, const float* bias, cons
  * diqt_conv3d_fwd_h_supported() == 0 (Cin % 4 != 0, a tensor >= 1 GiB, halo tile beyond the LDS): stay on diqt_conv3d_fwd.   */
 size_t diqt_conv_packed_h_elems(int Cout, int Cin, int kd, int kh, int kw);
 int diqt_conv_pack_weight_h(const float* w_oidhw, void* packed_h, int Cout, int Cin, int kd, int kh, int kw, int mode, int bf16,
-                            void* stream);   /* mode as in diqt_conv_pack_weight: 1 = flipped / swapped packing for backward-data */
+                            void* stream);
+/* `count` such packs in one launch per 64 rows: host_table rows of 8 x int64 {w (device pointer), packed_h (device pointer), Cout, Cin, kd,
+ * kh, kw, mode} travel in the kernel arguments (what the captured training micro-step replays to re-derive every packed copy). */
+int diqt_conv_pack_weight_h_multi(const long long* host_table, int count, int bf16, void* stream);   /* mode as in diqt_conv_pack_weight: 1 = flipped / swapped packing for backward-data */
 int diqt_conv3d_fwd_h_supported(int B, int D, int H, int W, int Cin, int Cout, int kd, int kh, int kw, int pd, int ph, int pw,
                                 int epd, int eph, int epw);
 /* diqt_conv3d_fwd_h with 16-bit tensors at either end: x_half: x holds values of the operand type (fp16, or bf16 when `bf16`) instead of

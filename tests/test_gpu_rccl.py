@@ -93,3 +93,76 @@ def test_single_rank_rccl_group_carries_the_trainer_collectives(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+WORKER_GRAPH = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["DIQT_ROOT"])
+import numpy as np
+import torch
+import torch.distributed as dist
+from diffusioniqt_amd import distributed as D, graphs
+from diffusioniqt_amd.imagen_pytorch3D import SRUnet256, Imagen, NullUnet
+from diffusioniqt_amd.trainer import ImagenTrainer
+from oracle import iqt_oracle as O
+from tests.conftest import load_golden
+
+world, rank, device = D.init_from_env()
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+warm = torch.ones(4, device=device)
+dist.all_reduce(warm)                                      # communicator and its watchdog thread are up before any capture
+torch.cuda.synchronize()
+gu = load_golden('unetA_tiny')
+configs = {'Data': {'norm': 'z-score'}, 'Train': {'batch_sample': False, 'patch_size_sub': 8, 'pred_obj': 'x_start'}, 'Eval': {'repeat': 1}}
+
+
+def run(graph_mode):
+    unet = SRUnet256(**json.loads(str(gu['kwargs'])))
+    unet.load_state_dict(O.hash_fill_state_dict(unet.state_dict(), 0))
+    imagen = Imagen(unets=(NullUnet(), unet), configs=configs, min_bound=float(gu['min_bound']), image_sizes=(8, 8), channels=1,
+                    pred_objectives='x_start', timesteps=4, dynamic_thresholding=False, p2_loss_weight_gamma=0.0, cond_drop_prob=0.0).to(device)
+    ImagenTrainer.locked = False
+    tr = ImagenTrainer(configs=configs, imagen=imagen, verbose=False, gradient_accumulation_steps=2, precision='bf16')
+    tr.validate_and_set_unet_being_trained(2)
+    # what a multi-rank run has: a live bucketed reducer over the arena (one-rank RCCL mean = identity)
+    tr.unet_being_trained.reducer = D.BucketedGradReducer(tr._arena, bucket_cap_mb=0.05, first_bucket_mb=0.01, force=True)
+    graphs.TRAIN_ENABLED, graphs.TRAIN_FORCE = graph_mode != 0, graph_mode == 2
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(9)
+    losses = []
+    for i in range(12):
+        hr, lr = torch.randn(2, 1, 8, 8, 8, generator=g), torch.randn(2, 1, 8, 8, 8, generator=g)
+        losses.append(tr.forward(hr, lowres_img=lr, unet_number=2, max_batch_size=2)[0])
+    torch.cuda.synchronize()
+    out = (losses, [p.detach().clone() for p in imagen.unets[1].parameters()], tr._train_graphs.replays, tr._train_graphs.summary())
+    tr._train_graphs.clear()
+    return out
+
+
+la, wa, ra, sa = run(2)
+lb, wb, rb, sb = run(0)
+assert not any("error" in e for e in sa), sa
+# accumulation steps 2: every second micro-step is synchronised (eager, with the RCCL all-reduces); the others go through the graph
+assert ra >= 2 and rb == 0, (ra, sa)
+assert la == lb, (la, lb)
+assert all(torch.equal(a, b) for a, b in zip(wa, wb))
+dist.destroy_process_group()
+print("RCCL_GRAPH_OK replays=%d" % ra)
+'''
+
+
+@pytest.mark.gpu
+def test_captured_micro_steps_between_rccl_synchronised_ones(tmp_path):
+    """The accumulation micro-steps of a data-parallel run replay as a captured hipGraph while an RCCL communicator (and its watchdog
+    thread) is alive and the synchronised micro-steps in between run eagerly with the bucketed all-reduces: same losses and weights as
+    the all-eager run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rccl_graph_worker.py"
+    script.write_text(WORKER_GRAPH)
+    env = dict(os.environ, DIQT_ROOT=ROOT, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-X", "faulthandler", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

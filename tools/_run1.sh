@@ -1,21 +1,16 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python bench.py > gpurun_out/r04_bench_C2.json 2> gpurun_out/t53_bench.err; echo "bench rc=$?"
-timeout -k 10 600 python bench.py --config C4 > gpurun_out/r04_bench_C4.json 2> gpurun_out/t53_c4.err; echo "c4 rc=$?"
-timeout -k 10 900 python bench.py --config C5 > gpurun_out/r04_bench_C5.json 2> gpurun_out/t53_c5.err; echo "c5 rc=$?"
+R=$GRAFT_REPO_ROOT
+timeout -k 10 900 python -X faulthandler -m pytest tests/test_gpu_train_graph.py tests/test_gpu_lowprec.py tests/test_gpu_rccl.py tests/test_gpu_ddp_trace.py tests/test_gpu_trainer_trace.py -q -m gpu -x > gpurun_out/t55_test.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/t55_test.log | cut -c1-300
+for i in 1 2; do timeout -k 10 300 python tools/train_bf16_only.py 32 > gpurun_out/t55_tb$i.log 2>&1; tail -1 gpurun_out/t55_tb$i.log; done
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ptb -o tb -- python3 $R/tools/train_bf16_only.py 16 > $R/gpurun_out/t55_tb.log 2>&1; cd $R; grep "micro-step" gpurun_out/t55_tb.log
 python - <<'P'
-import json
-def last(f):
-    for line in open(f):
-        if line.startswith('{'): d=json.loads(line)
-    return d
-d=last('gpurun_out/r04_bench_C2.json')
-print("C2", d['value'], d['ms_per_step'], "roofline", d['roofline']['frac'], d['roofline'].get('achieved'))
-print(" train", d['train']['ms_per_step'], json.dumps(d['train'].get('step_graphs')))
-print(" train_bf16", d['train_bf16']['ms_per_step'], " autocast", d['autocast_fp16']['ms_per_step'])
-u=d['unet3d_edm']; print(" u3", u['eval_ms'],u['fwd_bwd_ms'],u['fwd_bwd_bf16_ms'])
-print(" c4", d['c4']['eval_ms'], d['c4']['autocast_fp16_eval_ms'], " c5_short", d['c5_short']['cascade_ms'])
-print(" cpu", json.dumps(d['cpu_baseline'])[:300])
-d=last('gpurun_out/r04_bench_C4.json'); print("C4", d['value'], d['ms_per_step'], json.dumps(d.get('autocast_fp16'))[:200])
-d=last('gpurun_out/r04_bench_C5.json'); print("C5", d['value'], d['ms_per_step'], d.get('whole_step_tflops'))
+import csv,glob,shutil
+f=sorted(glob.glob('/tmp/ptb/**/*kernel_stats.csv',recursive=True))[-1]
+rows=list(csv.DictReader(open(f)))
+tot=sum(float(r['TotalDurationNs']) for r in rows); calls=sum(int(r['Calls']) for r in rows)
+print(f"kernel time {tot/1e6/24:.2f} ms per micro-step over 24 steps, {calls/24:.0f} launches per step")
+for r in rows:
+    if 'pack' in r['Name']: print(f"{float(r['Percentage']):6.2f}%  {int(r['Calls'])/24:7.1f} x {float(r['AverageNs'])/1e3:9.2f} us  {r['Name'][:105]}")
+shutil.copy(f,'gpurun_out/r04_train_bf16_kernel_stats.csv')
 P

@@ -16,7 +16,7 @@ T = lambda a: torch.from_numpy(np.asarray(a))
 
 
 def run_trainer(graph_mode, precision, n_steps, max_grad_norm=None, sample_between=False):
-    from diffusioniqt_amd import graphs
+    from diffusioniqt_amd import graphs, ops
     from diffusioniqt_amd.imagen_pytorch3D import Imagen, NullUnet, SRUnet256
     from diffusioniqt_amd.trainer import ImagenTrainer
     gu = load_golden('unetA_tiny')
@@ -34,23 +34,26 @@ def run_trainer(graph_mode, precision, n_steps, max_grad_norm=None, sample_betwe
     try:
         torch.manual_seed(11)
         g = torch.Generator().manual_seed(3)
-        losses, preds = [], []
+        losses, preds, samples = [], [], []
         for i in range(n_steps):
             hr, lr = torch.randn(2, 1, 8, 8, 8, generator=g), torch.randn(2, 1, 8, 8, 8, generator=g)
             loss, pred, x_noisy, _ = trainer.forward(hr, lowres_img=lr, unet_number=2, max_batch_size=2)
             losses.append(loss)
             preds.append(pred.detach().clone())
             if sample_between and i == n_steps // 2:
-                with torch.no_grad():                    # an eager evaluation between two replays: re-packs the weights on its own
-                    imagen.unets[1].eval()
-                    imagen.unets[1](hr.to(DEV), torch.zeros(2, device=DEV), lowres_cond_img=lr.to(DEV))
-                    imagen.unets[1].train()
+                # sampling between two replays: the EMA swap, eager (or separately captured) U-Net evaluations that re-pack weights on
+                # their own, and the trainable U-Net put back -- the next replay must find everything it addresses untouched
+                gs = torch.Generator().manual_seed(21)
+                noise = [torch.randn(2, 1, 8, 8, 8, generator=gs) for _ in range(5)]
+                with ops.low_precision(precision if precision in ('fp16', 'bf16') else 'off'):
+                    img = trainer.sample(batch_size=2, start_image_or_video=lr, start_at_unet_number=2, noise=noise)[0]
+                samples.append(img.detach().clone())
         replays = trainer._train_graphs.replays
         errors = [e.get("error") for e in trainer._train_graphs.entries.values() if e.get("error")]
         trainer._train_graphs.clear()
     finally:
         graphs.TRAIN_ENABLED, graphs.TRAIN_FORCE = old
-    return losses, preds, [p.detach().clone() for p in imagen.unets[1].parameters()], replays, errors
+    return losses, preds + samples, [p.detach().clone() for p in imagen.unets[1].parameters()], replays, errors
 
 
 @pytest.mark.parametrize("precision,mgn,between", [('bf16', None, False), (None, None, True), ('bf16', 0.5, True), ('fp16', None, False)])

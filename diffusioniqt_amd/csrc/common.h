@@ -48,12 +48,14 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
         case DIQT_ACT_MISH: {
             // x * tanh(softplus(x)); with n = e^x: tanh(log(1+n)) = (n^2+2n)/(n^2+2n+2)
+            // (hardware reciprocal, 1 ulp, as conv_fwd9_kernel's fused GroupNorm-apply has always computed it: an IEEE division is ~12
+            // instructions, and the GroupNorm-apply passes writing 16-bit tensors are bound by this arithmetic, not by their bytes)
             if (x > 20.f) return x;
             const float n = __expf(x);
             const float m = n * (n + 2.f);
-            return x * (m / (m + 2.f));
+            return x * (m * __builtin_amdgcn_rcpf(m + 2.f));
         }
-        case DIQT_ACT_SILU: return x / (1.f + __expf(-x));
+        case DIQT_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
         case DIQT_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
         case DIQT_ACT_RELU: return x > 0.f ? x : 0.f;
         case DIQT_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));

@@ -15,7 +15,7 @@ DEV = "cuda"
 T = lambda a: torch.from_numpy(np.asarray(a))
 
 
-def run_trainer(graph_mode, precision, n_steps, max_grad_norm=None, sample_between=False):
+def run_trainer(graph_mode, precision, n_steps, max_grad_norm=None, sample_between=False, batch=2):
     from diffusioniqt_amd import graphs, ops
     from diffusioniqt_amd.imagen_pytorch3D import Imagen, NullUnet, SRUnet256
     from diffusioniqt_amd.trainer import ImagenTrainer
@@ -36,8 +36,8 @@ def run_trainer(graph_mode, precision, n_steps, max_grad_norm=None, sample_betwe
         g = torch.Generator().manual_seed(3)
         losses, preds, samples = [], [], []
         for i in range(n_steps):
-            hr, lr = torch.randn(2, 1, 8, 8, 8, generator=g), torch.randn(2, 1, 8, 8, 8, generator=g)
-            loss, pred, x_noisy, _ = trainer.forward(hr, lowres_img=lr, unet_number=2, max_batch_size=2)
+            hr, lr = torch.randn(batch, 1, 8, 8, 8, generator=g), torch.randn(batch, 1, 8, 8, 8, generator=g)
+            loss, pred, x_noisy, _ = trainer.forward(hr, lowres_img=lr, unet_number=2, max_batch_size=2)     # batch 4: two chunks per call
             losses.append(loss)
             preds.append(pred.detach().clone())
             if sample_between and i == n_steps // 2:
@@ -46,7 +46,7 @@ def run_trainer(graph_mode, precision, n_steps, max_grad_norm=None, sample_betwe
                 gs = torch.Generator().manual_seed(21)
                 noise = [torch.randn(2, 1, 8, 8, 8, generator=gs) for _ in range(5)]
                 with ops.low_precision(precision if precision in ('fp16', 'bf16') else 'off'):
-                    img = trainer.sample(batch_size=2, start_image_or_video=lr, start_at_unet_number=2, noise=noise)[0]
+                    img = trainer.sample(batch_size=2, start_image_or_video=lr[:2], start_at_unet_number=2, noise=noise)[0]
                 samples.append(img.detach().clone())
         replays = trainer._train_graphs.replays
         errors = [e.get("error") for e in trainer._train_graphs.entries.values() if e.get("error")]
@@ -78,3 +78,14 @@ def test_gpu_bound_steps_stay_eager_and_the_switch_turns_capture_off():
     assert graphs.TRAIN_ENABLED                          # the default
     _, _, _, r0, _ = run_trainer(0, 'bf16', 6)
     assert r0 == 0
+
+
+def test_two_chunks_per_forward_call_replay_the_same_graph():
+    """``max_batch_size`` splits a batch of 4 into two micro-steps per ``forward`` call (trainer.py:1104-1123: chunk fraction 0.5 in the
+    loss): both chunks go through the one captured graph, losses and weights as in the eager run."""
+    n = 6
+    la, pa, wa, ra, ea = run_trainer(2, 'bf16', n, batch=4)
+    lb, pb, wb, rb, eb = run_trainer(0, 'bf16', n, batch=4)
+    assert not ea and ra == 2 * n - 3 and rb == 0
+    assert la == lb
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb)) and all(torch.equal(a, b) for a, b in zip(wa, wb))

@@ -841,6 +841,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_smallcin_kernel(const float* 
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const bool two = n0 + 32 < g.Cout;                   // kernel-uniform per workgroup: the block's second 32 output channels exist
     const int wrow = tid >> 3, wc4 = (tid & 7) * 4;
     for (int chunk = 0; chunk < nCh; ++chunk) {
         __syncthreads();                                 // previous chunk's fragment reads (and the halo stores) are done
@@ -877,25 +878,44 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_smallcin_kernel(const float* 
         const float* bp = wbuf + l31 * LDSROW + 4 * h;
         float4 a = *reinterpret_cast<const float4*>(ap);
         float4 b0 = *reinterpret_cast<const float4*>(bp);
-        float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
+        if (two) {
+            float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSROW);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 an, b0n, b1n;
-            if (q < 3) {
-                an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
-                b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
-                b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+            for (int q = 0; q < 4; ++q) {
+                float4 an, b0n, b1n;
+                if (q < 3) {
+                    an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+                    b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+                    b1n = *reinterpret_cast<const float4*>(bp + 32 * LDSROW + 8 * (q + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+                if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
-            if (q < 3) { a = an; b0 = b0n; b1 = b1n; }
+        } else {
+            // at most 32 output channels in this block (the cross-embed convs of the pseudo-3D U-Net: 16 / 32 channels from 2): the
+            // second 32-channel accumulator would multiply padding -- half the MFMAs of the kernel
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 an, b0n;
+                if (q < 3) {
+                    an = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+                    b0n = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                if (q < 3) { a = an; b0 = b0n; }
+            }
         }
     }
     const int co0 = n0 + l31, co1 = n0 + 32 + l31;

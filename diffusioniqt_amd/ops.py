@@ -245,7 +245,7 @@ def repack_cached_h(module, bf16):
     weights (``diqt_conv_pack_weight_h_multi``) into fresh tensors keyed on the current weight epoch.  graphs.TrainStepGraphs calls it as the
     first thing inside the capture of a training micro-step: a replay then refreshes all packed weights with one or two launches instead
     of one per conv and direction (86 for the C2 U-Net).  Returns the number of copies re-derived."""
-    rows, keep = [], []
+    rows = []
     for p in module.parameters():
         cache = getattr(p, "_diqt_pack", None)
         if not cache or not p.is_cuda:
@@ -262,7 +262,6 @@ def repack_cached_h(module, bf16):
             rows.append((w5.data_ptr(), packed.data_ptr(), Cout, Cin, kd, kh, kw, mode))
             retire(ent[1])
             cache[slot] = ((slot, w5.data_ptr(), w5._version, _WEIGHT_EPOCH), born(packed), w5)
-            keep.append(packed)
     if rows:
         _lib.call("diqt_conv_pack_weight_h_multi", torch.tensor(rows, dtype=torch.int64), len(rows), int(bf16), _stream())
     return len(rows)

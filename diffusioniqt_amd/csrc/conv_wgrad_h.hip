@@ -12,6 +12,10 @@
 //   * the next tile's dY rows and X halo rows are loaded global -> registers (range-checked buffer loads: zero padding, ragged tiles)
 //     before the current tile's MFMAs and converted + written to LDS behind them (two barriers per tile);
 //   * LDS rows: X 64 B (32 ci), dY 192 B (64 co + pad): the 4 rows x 2 channel blocks of a 32-lane half fall on disjoint bank groups;
+//   * tried and dropped (round 4, in-situ timing of the bf16 training step on one box): 256-voxel tiles (4 x 4 x 16: 59.7 vs 60 us) and a
+//     wave split by tap residue mod 4 with both co halves per wave, so that a B fragment read from the LDS feeds two MFMAs (61-64 us):
+//     the kernel is not bound by its LDS fragment reads but by what sits around the MFMA loop (staging of the next tile between two
+//     barriers, 221 KB of slab per workgroup through the LDS at the end of a 16-tile walk);
 //   * partial slabs [slice][Cout][Cin][taps] and bias partials [slice][CoutPad] as conv_wgrad3_kernel writes them: the same fixed-order
 //     reduce (conv_reduce_dw3_kernel) finishes the gradient -- deterministic.
 #include "common.h"

@@ -1008,3 +1008,56 @@ def test_concat_with_column_sums_for_the_next_groupnorm(B, rows, Ca, Cb):
     with torch.no_grad():
         z0 = ops.groupnorm_act(y0, gamma, beta, None, 4, ops.ACT_SILU, 1e-5)
     assert (z1 - z0).abs().max().item() <= 2e-5 * z0.abs().max().item()
+
+
+def test_multi_accumulate_with_the_table_in_the_kernel_arguments(ops):
+    """diqt_multi_accumulate_host (the gradient hand-over of a captured training micro-step: rows travel in the kernel arguments, 120 per
+    launch) against diqt_multi_accumulate with the table in device memory and against plain adds -- bit-exact, also past one launch's rows."""
+    from diffusioniqt_amd import _lib
+    torch.manual_seed(9)
+    sizes = [int(v) for v in torch.randint(1, 700, (300,))] + [70001, 4, 3]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    d0 = torch.randn(off)
+    srcs = [torch.randn(n) for n in sizes]
+    want = d0.clone()
+    for t, o in zip(srcs, offs):
+        want[o:o + t.numel()] += t
+    dev = [t.to(DEV) for t in srcs]
+    rows = torch.tensor([(t.data_ptr(), o, t.numel()) for t, o in zip(dev, offs)], dtype=torch.int64)
+    st = torch.cuda.current_stream().cuda_stream
+    a = d0.to(DEV)
+    _lib.call("diqt_multi_accumulate_host", a, rows, len(sizes), 16, st)
+    b = d0.to(DEV)
+    _lib.call("diqt_multi_accumulate", b, rows.to(DEV), len(sizes), 16, st)
+    torch.cuda.synchronize()
+    assert torch.equal(a.cpu(), want) and torch.equal(b.cpu(), want)
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_many_weights_packed_by_one_launch_equal_the_single_packs(bf16):
+    """diqt_conv_pack_weight_h_multi (a captured training micro-step re-derives every 16-bit packed weight with it) == one
+    diqt_conv_pack_weight_h per weight, bit for bit: forward and backward-data layouts, ragged channel counts, more than 64 weights."""
+    from diffusioniqt_amd import _lib
+    torch.manual_seed(4)
+    shapes = [(64, 64, 3, 3, 3), (128, 64, 3, 3, 3), (40, 24, 1, 3, 3), (64, 128, 3, 1, 1), (256, 256, 1, 1, 1), (8, 96, 3, 3, 3)] * 12
+    st = torch.cuda.current_stream().cuda_stream
+    rows, singles, multis, ws = [], [], [], []
+    for k, shp in enumerate(shapes):
+        mode = k % 2
+        w = torch.randn(*shp, device=DEV)
+        Cout, Cin, kd, kh, kw = shp
+        eff = (Cout, Cin) if mode == 0 else (Cin, Cout)
+        n = _lib.query("diqt_conv_packed_h_elems", eff[0], eff[1], kd, kh, kw)
+        s = torch.zeros(n, dtype=torch.int16, device=DEV)
+        m = torch.zeros(n, dtype=torch.int16, device=DEV)
+        _lib.call("diqt_conv_pack_weight_h", w, s, Cout, Cin, kd, kh, kw, mode, bf16, st)
+        rows.append((w.data_ptr(), m.data_ptr(), Cout, Cin, kd, kh, kw, mode))
+        singles.append(s); multis.append(m); ws.append(w)
+    _lib.call("diqt_conv_pack_weight_h_multi", torch.tensor(rows, dtype=torch.int64), len(rows), bf16, st)
+    torch.cuda.synchronize()
+    assert len(rows) > 64
+    for s, m in zip(singles, multis):
+        assert torch.equal(s, m)

@@ -89,3 +89,14 @@ def test_two_chunks_per_forward_call_replay_the_same_graph():
     assert not ea and ra == 2 * n - 3 and rb == 0
     assert la == lb
     assert all(torch.equal(a, b) for a, b in zip(pa, pb)) and all(torch.equal(a, b) for a, b in zip(wa, wb))
+
+
+def test_ragged_last_chunk_gets_its_own_graph():
+    """A batch of 3 with ``max_batch_size = 2`` splits into chunks of 2 and 1 (chunk fractions 2/3 and 1/3, trainer.py:1104-1123): two
+    keys, two captured graphs, results as in the eager run."""
+    n = 6
+    la, pa, wa, ra, ea = run_trainer(2, 'bf16', n, batch=3)
+    lb, pb, wb, rb, eb = run_trainer(0, 'bf16', n, batch=3)
+    assert not ea and ra == 2 * (n - 3) and rb == 0
+    assert la == lb
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb)) and all(torch.equal(a, b) for a, b in zip(wa, wb))
